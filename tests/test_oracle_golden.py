@@ -1,0 +1,109 @@
+"""CPU: the oracle against the committed golden vectors (tests/golden/, made by oracle/make_golden.py
+after the oracle matched transformers 5.15 BART and the reference's own fine_tune loop)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import goldenlib as G
+from oracle import kmbart_oracle as O
+
+
+def _batch(fx, prefix=""):
+    b = {k: torch.from_numpy(fx[prefix + k]) for k in
+         ("input_ids", "attention_mask", "decoder_input_ids", "decoder_attention_mask", "labels")}
+    b["image_features"] = G.golden_features([int(r) for r in fx[prefix + "regions"]])
+    return b
+
+
+def test_lcg_is_exact():
+    u = G.lcg_uniform(5, 3)
+    assert u.dtype == np.float32
+    # closed-form generator: these five values are part of the fixture definition
+    assert np.array_equal(u, G.lcg_uniform(5, 3))
+    assert np.all(np.abs(u) <= 1.0)
+    sd = G.golden_state_dict(G.tiny_config())
+    assert abs(float(sd["model.shared.weight"].std()) - 0.02) < 2e-3
+    assert float(sd["model.shared.weight"][1].abs().sum()) == 0.0
+
+
+def test_forward_backward_matches_golden(gold_dir):
+    fx = np.load(os.path.join(gold_dir, "tiny_train.npz"))
+    cfg = G.tiny_config()
+    sd = {k: v.clone().requires_grad_(k != "final_logits_bias") for k, v in G.golden_state_dict(cfg).items()}
+    b = _batch(fx)
+    loss, logits, enc = O.forward(sd, cfg, b["input_ids"], b["image_features"], b["attention_mask"],
+                                  b["decoder_input_ids"], b["decoder_attention_mask"], b["labels"])
+    loss.backward()
+    assert abs(float(loss) - float(fx["loss"])) < 2e-5
+    assert np.allclose(logits.detach().numpy(), fx["logits"], atol=2e-5)
+    assert np.allclose(enc.detach().numpy(), fx["encoder_out"], atol=2e-5)
+    names = [k for k in sd if k != "final_logits_bias"]
+    norms = np.array([float(sd[n].grad.norm()) for n in names])
+    assert np.allclose(norms, fx["grad_norms"], rtol=1e-4, atol=1e-8)
+    assert np.allclose(sd["model.encoder.embed_images.linear.bias"].grad.numpy(), fx["grad_img_bias"], atol=1e-6)
+    assert np.allclose(sd["model.decoder.layers.1.fc2.bias"].grad.numpy(), fx["grad_dec_l1_fc2_bias"], atol=1e-6)
+
+
+def test_three_adamw_steps_match_golden(gold_dir):
+    fx = np.load(os.path.join(gold_dir, "tiny_train.npz"))
+    cfg = G.tiny_config()
+    model = O.OracleModel(cfg, state_dict=G.golden_state_dict(cfg)).train()
+    opt = O.HFAdamW(model.parameters(), lr=1e-3)
+    losses = []
+    for i in range(3):
+        b = _batch(fx, f"step{i}_")
+        loss = model(b["input_ids"], b["image_features"], b["attention_mask"],
+                     decoder_input_ids=b["decoder_input_ids"],
+                     decoder_attention_mask=b["decoder_attention_mask"], labels=b["labels"])[0]
+        losses.append(float(loss))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    assert np.allclose(losses, fx["step_losses"], atol=3e-5)
+    sums = np.array([float(p.double().sum()) for p in model.params])
+    assert np.allclose(sums, fx["step_param_sums"], rtol=1e-5, atol=1e-4)
+
+
+def test_adamw_is_hf_form():
+    """eps outside the bias correction: one step on a scalar against the closed form."""
+    p = torch.nn.Parameter(torch.tensor([1.0]))
+    p.grad = torch.tensor([0.5])
+    opt = O.HFAdamW([p], lr=0.1, eps=1e-6)
+    opt.step()
+    m, v = 0.05, 0.00025
+    step = 0.1 * (1 - 0.999) ** 0.5 / (1 - 0.9)
+    assert abs(float(p) - (1.0 - step * m / (v ** 0.5 + 1e-6))) < 1e-6
+
+
+def test_generation_matches_golden(gold_dir):
+    gen = json.load(open(os.path.join(gold_dir, "tiny_generate.json")))
+    cfg = G.tiny_config(init_std=0.2)
+    sd = G.golden_state_dict(cfg, seed=9)
+    sd["final_logits_bias"][0, cfg.eos_token_id] += 3.0
+    ids = torch.tensor(gen["input_ids"])
+    am = torch.tensor(gen["attention_mask"])
+    feats = G.golden_features(gen["regions"])
+    for case in gen["cases"]:
+        kw = case["kwargs"]
+        r = O.generate(sd, cfg, ids, feats, am, return_scores="scores" in case, **kw)
+        if "scores" in case:
+            assert r[0].tolist() == case["ids"], kw
+            assert np.allclose(r[1].numpy(), case["scores"], atol=1e-4)
+        else:
+            assert r.tolist() == case["ids"], kw
+
+
+def test_ragged_and_empty_regions():
+    """R_i = 0 rows pass through as plain token rows; a count mismatch raises (modules.py:98-100)."""
+    cfg = G.tiny_config()
+    sd = G.golden_state_dict(cfg)
+    ids = torch.tensor([[3, cfg.img_feat_id, cfg.img_feat_id, 4], [5, 6, 7, 8]])
+    feats = G.golden_features([2, 0])
+    e = O.embed_multi_modal(sd, cfg, ids, feats)
+    assert torch.equal(e[1], sd["model.shared.weight"][ids[1]])
+    assert torch.allclose(e[0, 1:3], O.image_embedding(sd, feats)[0])
+    import pytest
+    with pytest.raises(RuntimeError):
+        O.embed_multi_modal(sd, cfg, ids, G.golden_features([3, 0]))
