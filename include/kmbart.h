@@ -1,0 +1,195 @@
+/* libkmbart_hip.so -- C ABI of the MI355X-native KM-BART hot path.
+ *
+ * The reference (fomalhautb/KM-BART) has no native interface: its hot path is reached through the
+ * Python API of src.model / src.training / src.generation.  This header is
+ * the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md).  Every entry point
+ * cites the reference code whose arithmetic it replaces (paths into the reference checkout).
+ *
+ * Conventions: plain pointers and sizes only; all data pointers are DEVICE pointers unless the
+ * name ends in _host; `stream` is a hipStream_t passed as void*; every function returns 0 on
+ * success, non-zero on failure with the message available from kmb_last_error().  Nothing here
+ * allocates device memory: the host binds arenas / workspace it owns (torch tensors in the
+ * Python host code).  A handle is not thread-safe (one host thread per process per GPU, as
+ * the reference's mp.spawn layout, vcg_train.py:350-355).
+ */
+#ifndef KMBART_H
+#define KMBART_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t kmb_bf16;            /* raw bfloat16 bits */
+typedef struct kmb_handle kmb_handle;
+
+/* src/model/config.py:4-92 + config/vcg_base.json */
+typedef struct kmb_config {
+  int32_t vocab_size, d_model;
+  int32_t encoder_layers, decoder_layers;
+  int32_t encoder_attention_heads, decoder_attention_heads;
+  int32_t encoder_ffn_dim, decoder_ffn_dim;
+  int32_t max_position_embeddings, extra_pos_embeddings;
+  int32_t image_feature_size;
+  int32_t pad_token_id, bos_token_id, eos_token_id, img_feat_id, cls_token_id;
+  int32_t scale_embedding;
+  float dropout, attention_dropout, activation_dropout;
+  float layer_norm_eps;
+} kmb_config;
+
+/* one training / scoring batch; layout = what the reference Collator emits
+ * (src/data/collation.py:68-213), region features packed row-wise with CSR offsets */
+typedef struct kmb_batch {
+  int32_t B, S, T;                     /* batch, encoder length, decoder length */
+  const int64_t* input_ids;            /* [B,S] */
+  const int64_t* attention_mask;       /* [B,S] 1 = keep, or NULL (all ones) */
+  const float* image_features;         /* [Ntot, image_feature_size] fp32, rows of sample i at feat_offsets[i] */
+  const int32_t* feat_offsets;         /* [B+1] device */
+  int32_t n_features;                  /* Ntot (host copy of feat_offsets[B]) */
+  const int64_t* decoder_input_ids;    /* [B,T] */
+  const int64_t* decoder_attention_mask; /* [B,T] or NULL */
+  const int64_t* labels;               /* [B,T], -100 = ignore, or NULL */
+} kmb_batch;
+
+/* ---- GEMM with fused epilogue (csrc/gemm.hip) --------------------------------------------- */
+typedef struct KmbGemm {
+  const kmb_bf16* A; const kmb_bf16* B;
+  int32_t lda, ldb;
+  int32_t a_kc, b_kc;
+  int32_t M, N, K;
+  const float* bias;
+  float col_scale; int32_t col_scale_n;
+  int32_t act;
+  kmb_bf16* preact; int32_t ld_preact;
+  const kmb_bf16* aux; int32_t ld_aux;
+  uint32_t drop_thr16; uint32_t drop_seed; float drop_scale;
+  const kmb_bf16* residual; int32_t ld_res;
+  kmb_bf16* out_bf16; int32_t ld_out_bf16;
+  float* out_f32; int32_t ld_out_f32; float beta;
+} KmbGemm;
+
+/* ---- fused attention (csrc/attention.hip) -------------------------------------------------- */
+typedef struct KmbAttn {
+  const kmb_bf16* Q; const kmb_bf16* K; const kmb_bf16* V;
+  int32_t ldq, ldk, ldv;
+  int32_t B, H, Tq, Tk;
+  const int64_t* key_mask;
+  int32_t causal;
+  kmb_bf16* O; int32_t ldo;
+  float* lse;
+  const kmb_bf16* dO; int32_t lddo;
+  kmb_bf16* dQ; kmb_bf16* dK; kmb_bf16* dV; int32_t lddq, lddk, lddv;
+  float dq_scale;
+} KmbAttn;
+
+typedef struct KmbAttnDecode {
+  const kmb_bf16* Q; int32_t ldq;
+  const kmb_bf16* Kc; const kmb_bf16* Vc;
+  int32_t Tmax; int32_t ldc;      /* cache element (row,t,h,e) at X[(row*Tmax + t)*ldc + h*64 + e] */
+  const int32_t* kv_row;
+  const int64_t* key_mask; int32_t mask_ld;
+  const int32_t* mask_row;
+  int32_t R, H, Tk;
+  kmb_bf16* O; int32_t ldo;
+} KmbAttnDecode;
+
+typedef struct KmbDrop { uint32_t thr16; uint32_t seed; float scale; } KmbDrop;
+typedef struct KmbAdamW { double lr, beta1, beta2, eps, weight_decay; int32_t step; int32_t correct_bias; float grad_scale; } KmbAdamW;
+
+const char* kmb_last_error(void);
+int kmb_version(void);
+
+/* ================= model handle ================= */
+/* MultiModalBartForConditionalGeneration(config): src/model/model.py:317-323 */
+int kmb_create(const kmb_config* cfg, kmb_handle** out);
+void kmb_destroy(kmb_handle* h);
+
+/* parameter census (state-dict names are the reference's: HF BART keys +
+ * model.encoder.embed_images.linear.{weight,bias}); offsets are in ELEMENTS into the flat arenas */
+int kmb_param_count(const kmb_handle* h);
+int kmb_param_info(const kmb_handle* h, int idx, const char** name, int64_t* offset, int32_t* rows, int32_t* cols);
+int64_t kmb_arena_elems(const kmb_handle* h);        /* fp32 arenas: params / grads / exp_avg / exp_avg_sq */
+int64_t kmb_bf16_arena_elems(const kmb_handle* h);   /* bf16 mirror (+ padded tied matrix + padded image weight) */
+int kmb_bind_arenas(kmb_handle* h, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                    kmb_bf16* params_bf16, float* final_logits_bias);
+int64_t kmb_workspace_bytes(const kmb_handle* h, int B, int S, int T, int n_features);
+int kmb_bind_workspace(kmb_handle* h, void* ws, int64_t bytes);
+/* refresh the bf16 mirror from the fp32 master parameters (after init / load_state_dict) */
+int kmb_sync_params(kmb_handle* h, void* stream);
+int kmb_set_seed(kmb_handle* h, uint64_t seed);
+
+/* gradient buckets for data-parallel overlap (DDP reducer, vcg_train.py:98): bucket i is complete
+ * on the compute stream once kmb_backward has passed its event */
+int kmb_bucket_count(const kmb_handle* h);
+int kmb_bucket_range(const kmb_handle* h, int i, int64_t* offset, int64_t* count);
+int kmb_stream_wait_bucket(kmb_handle* h, int i, void* stream);
+
+/* ================= training step ================= */
+/* MultiModalBartForConditionalGeneration.forward, src/model/model.py:325-405
+ * (encoder src/model/modules.py:104-165, ImageEmbedding :24-41, _embed_multi_modal :89-102).
+ *   train       : dropout active (model.train())
+ *   need_grad   : also produce what kmb_backward needs (and the tied-head gradients)
+ *   loss_out    : device float[1] (mean CE over labels != -100), may be NULL when labels == NULL
+ *   logits_out  : device float [B*T, kmb_logits_ld()] or NULL; columns >= vocab_size are padding
+ *   enc_out     : device bf16 [B*S, d_model] or NULL (encoder_last_hidden_state copy) */
+int kmb_logits_ld(const kmb_handle* h);
+int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad, float* loss_out,
+                float* logits_out, kmb_bf16* enc_out, void* stream);
+/* loss.backward() (src/training.py:138,142); loss_scale multiplies every gradient */
+int kmb_backward(kmb_handle* h, float loss_scale, void* stream);
+/* transformers.AdamW.step (vcg_train.py:100, src/training.py:139,143) over [offset, offset+count) */
+int kmb_adamw_step(kmb_handle* h, const KmbAdamW* hp, int64_t offset, int64_t count, void* stream);
+/* status word written by device-side input validation (bit 0: #<img_feat> ids != #region rows) */
+int kmb_read_status(kmb_handle* h, int32_t* status_host, void* stream);
+
+/* ================= generation ================= */
+/* encoder once (src/model/mixins.py:281-283) + cross-attention K/V of every decoder layer */
+int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_length, void* stream);
+/* one cached decoder step (src/model/mixins.py:386-398 -> model.py:384-397): tokens [B*num_beams]
+ * at position `step` (0-based), logits_out fp32 [B*num_beams, kmb_logits_ld()] */
+int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_out, void* stream);
+/* _reorder_cache (src/model/mixins.py:419-434): self-attention caches follow beam_idx [B*num_beams] */
+int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stream);
+/* log_softmax + top-k per row of (logp + add[row]); force_token >= 0 forces that token
+ * (adjust_logits_during_generation, src/model/mixins.py:400-417) */
+int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int k,
+                        float* out_val, int32_t* out_idx, void* stream);
+int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
+
+/* ================= single operators (unit tests / profiling) ================= */
+int kmb_op_gemm(const KmbGemm* p, void* stream);
+int kmb_op_attn_fwd(const KmbAttn* p, void* stream);
+int kmb_op_attn_bwd(const KmbAttn* p, void* stream);
+int kmb_op_attn_decode(const KmbAttnDecode* p, void* stream);
+int kmb_op_ln_fwd(const kmb_bf16* z, const float* gamma, const float* beta, kmb_bf16* y, float* mean, float* rstd,
+                  int M, int D, float eps, void* stream);
+/* partials: device float scratch of kmb_op_ln_bwd_scratch(M, D) floats */
+int64_t kmb_op_ln_bwd_scratch(int M, int D);
+int kmb_op_ln_bwd(const kmb_bf16* dy, const kmb_bf16* z, const float* mean, const float* rstd, const float* gamma,
+                  kmb_bf16* dz, kmb_bf16* out2, const KmbDrop* dy_drop, const KmbDrop* out2_drop, float* dgamma,
+                  float* dbeta, float* scratch, int M, int D, void* stream);
+int64_t kmb_op_colsum_scratch(int M, int N);
+int kmb_op_colsum(const kmb_bf16* X, int ld, int M, int N, float* out, float* scratch, void* stream);
+int kmb_op_img_rowmap(const int64_t* ids, const int32_t* feat_off, int B, int S, int64_t img_feat_id, int64_t cls_id,
+                      int32_t* img_src, int32_t* status, void* stream);
+int kmb_op_cast_pad(const float* x, int N, int Fin, kmb_bf16* y, int Fpad, void* stream);
+int kmb_op_embed_ln_fwd(const int64_t* ids, const int32_t* img_src, const float* E, const float* img_emb,
+                        const float* P, int pos_base, int S, float scale, const float* gamma, const float* beta,
+                        kmb_bf16* z, kmb_bf16* y, float* mean, float* rstd, int M, int D, float eps,
+                        const KmbDrop* drop, void* stream);
+int kmb_op_embed_bwd(const kmb_bf16* dz, const int64_t* ids, const int32_t* img_src, float scale, float* dE,
+                     kmb_bf16* dimg, int64_t pad_id, int M, int D, void* stream);
+int kmb_op_pos_bwd(const kmb_bf16* dz, int B, int S, int D, float* dP, int pos_base, int P_rows, void* stream);
+int kmb_op_ce(const float* logits, int ldv, int V, const int64_t* labels, int rows, float grad_scale,
+              float* loss_rows, kmb_bf16* dlogits, int32_t* count, float* loss, void* stream);
+int kmb_op_adamw(float* p, const float* g, float* m, float* v, kmb_bf16* p_bf16, int64_t n, const KmbAdamW* hp,
+                 void* stream);
+int kmb_op_cast_bf16(const float* x, kmb_bf16* y, int64_t n, void* stream);
+/* keep[i] = 1 if the dropout generator keeps element (row, col) for this site seed / probability */
+int kmb_op_dropout_mask(uint32_t seed, float p, int rows, int cols, uint8_t* keep, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMBART_H */

@@ -1,0 +1,402 @@
+// Fused scaled-dot-product attention for KM-BART's tiny tiles (head_dim = 64; S <= 64..256).
+//
+// Semantics (transformers 3.0.2 SelfAttention as used by the reference, src/model/modules.py:84,
+// src/model/model.py:35): q already carries the head_dim**-0.5 scale (applied by the projection
+// epilogue), scores get -inf at padded keys (key_mask == 0) and above the diagonal (causal),
+// softmax in fp32, attention_dropout = 0.
+//
+// Forward : grid (B*H, ceil(Tq/64)), 4 waves, wave w owns 16 query rows; K/V tiles of 64 keys are
+//           staged once per workgroup in LDS; online softmax over key tiles.
+// Backward: grid (B*H); loops key tiles (outer) and query tiles (inner); P is recomputed from the
+//           saved log-sum-exp; dK/dV live in registers across the inner loop, dQ in LDS (fp32).
+// One LDS image per tile serves both MFMA operand shapes: row reads (ds_read_b128) and
+// transposed reads (ds_read_b64_tr_b16); the XOR swizzle below makes both conflict-free.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dim
+constexpr int TILE_BYTES = 64 * 128;
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+// byte offset of 16-byte chunk `c16` (0..7) of row `row` in a [rows][64] bf16 tile
+__device__ __forceinline__ int tile_off(int row, int c16) {
+  return row * 128 + (((c16 >> 1) ^ swz(row)) << 5) + ((c16 & 1) << 4);
+}
+__device__ __forceinline__ int elem_off(int row, int col) { return tile_off(row, col >> 3) + ((col & 7) << 1); }
+
+// A/B fragment whose 16 "rows" are tile rows and whose k runs along the 64 columns
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row16, int kk, int r, int g) {
+  return *reinterpret_cast<const bf16x8*>(tile + tile_off(row16 * 16 + r, kk * 4 + g));
+}
+// A/B fragment whose 16 "rows" are tile COLUMNS col16*16.. and whose k runs along tile rows
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int col16, int kk, int r, int g) {
+  bf16x8 out;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int krow = kk * 32 + g * 8 + hh * 4 + (r >> 2);
+    const int off = krow * 128 + ((col16 ^ swz(krow)) << 5) + ((r & 3) << 3);
+    const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off));
+    out[hh * 4 + 0] = t[0]; out[hh * 4 + 1] = t[1]; out[hh * 4 + 2] = t[2]; out[hh * 4 + 3] = t[3];
+  }
+  return out;
+}
+
+// stage a [64][64] bf16 tile: rows t0.. of X (row stride ld), clamped to the last valid row
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* __restrict__ X, size_t base_row, int t0, int T,
+                                           int ld, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id >> 3, c = id & 7;
+    int t = t0 + row;
+    t = t < T ? t : T - 1;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(X + (base_row + t) * (size_t)ld + c * 8);
+    *reinterpret_cast<u32x4*>(tile + tile_off(row, c)) = v;
+  }
+}
+
+__device__ __forceinline__ float group16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const KmbAttn p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 4 * 2048];
+  char* Ks = smem;
+  char* Vs = smem + TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  char* Ps = smem + 2 * TILE_BYTES + wave * 2048;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int q0 = blockIdx.y * 64 + wave * 16;
+  const bf16_t* Qh = p.Q + h * HD;
+  const bf16_t* Kh = p.K + h * HD;
+  const bf16_t* Vh = p.V + h * HD;
+
+  bf16x8 qf[2];
+  {
+    int q = q0 + r;
+    q = q < p.Tq ? q : p.Tq - 1;
+    const bf16_t* qrow = Qh + ((size_t)b * p.Tq + q) * p.ldq;
+    qf[0] = *reinterpret_cast<const bf16x8*>(qrow + g * 8);
+    qf[1] = *reinterpret_cast<const bf16x8*>(qrow + 32 + g * 8);
+  }
+  float m_run[4], l_run[4];
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { m_run[i] = -INFINITY; l_run[i] = 0.f; o[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nkt = (p.Tk + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_tile(Ks, Kh, (size_t)b * p.Tk, kt * 64, p.Tk, p.ldk, tid);
+    stage_tile(Vs, Vh, (size_t)b * p.Tk, kt * 64, p.Tk, p.ldv, tid);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], frag_rows(Ks, j, kk, r, g), s[j], 0, 0, 0);
+    // masks
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = kt * 64 + j * 16 + r;
+      bool kv = key < p.Tk;
+      if (kv && p.key_mask != nullptr) kv = p.key_mask[(size_t)b * p.Tk + key] != 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int qi = q0 + g * 4 + q;
+        const bool ok = kv && (!p.causal || key <= qi);
+        s[j][q] = ok ? s[j][q] : -INFINITY;
+      }
+    }
+    // online softmax (row = g*4 + q, spread over the 16 lanes of the group)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float mx = fmaxf(fmaxf(s[0][q], s[1][q]), fmaxf(s[2][q], s[3][q]));
+      mx = group16_max(mx);
+      const float m_new = fmaxf(m_run[q], mx);
+      const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run[q] - m_new);
+      float lsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = (m_new == -INFINITY) ? 0.f : __expf(s[j][q] - m_new);
+        s[j][q] = pv;
+        lsum += pv;
+      }
+      l_run[q] = l_run[q] * alpha + lsum;
+      m_run[q] = m_new;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j][q] *= alpha;
+    }
+    // P (C layout) -> LDS -> A layout
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<bf16_t*>(Ps + elem_off(g * 4 + q, j * 16 + r)) = f2bf(s[j][q]);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 pf = frag_rows(Ps, 0, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_cols(Vs, j, kk, r, g), o[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float l = group16_sum(l_run[q]);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const int qi = q0 + g * 4 + q;
+    if (qi < p.Tq) {
+      bf16_t* orow = p.O + ((size_t)b * p.Tq + qi) * p.ldo + h * HD;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) orow[j * 16 + r] = f2bf(o[j][q] * inv);
+      if (r == 0 && p.lse != nullptr)
+        p.lse[((size_t)b * p.H + h) * p.Tq + qi] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
+    }
+  }
+}
+
+// ----------------------------------------------------------------- backward
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = smem + TILE_BYTES;
+  char* Ks = smem + 2 * TILE_BYTES;
+  char* Vs = smem + 3 * TILE_BYTES;
+  char* Ps = smem + 4 * TILE_BYTES;
+  char* dSs = smem + 5 * TILE_BYTES;
+  float* lse_s = reinterpret_cast<float*>(smem + 6 * TILE_BYTES);
+  float* del_s = lse_s + 64;
+  float* dQacc = del_s + 64;  // [nqt*64][64] fp32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const bf16_t* Qh = p.Q + h * HD;
+  const bf16_t* Kh = p.K + h * HD;
+  const bf16_t* Vh = p.V + h * HD;
+  const bf16_t* Oh = p.O + h * HD;
+  const bf16_t* dOh = p.dO + h * HD;
+
+  const int nkt = (p.Tk + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_tile(Ks, Kh, (size_t)b * p.Tk, kt * 64, p.Tk, p.ldk, tid);
+    stage_tile(Vs, Vh, (size_t)b * p.Tk, kt * 64, p.Tk, p.ldv, tid);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dk[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int qt = 0; qt < nqt; ++qt) {
+      __syncthreads();
+      stage_tile(Qs, Qh, (size_t)b * p.Tq, qt * 64, p.Tq, p.ldq, tid);
+      stage_tile(dOs, dOh, (size_t)b * p.Tq, qt * 64, p.Tq, p.lddo, tid);
+      {  // delta = rowsum(dO * O), lse: wave w owns rows w*16..w*16+15 of the tile
+        int q = qt * 64 + wave * 16 + r;
+        q = q < p.Tq ? q : p.Tq - 1;
+        const bf16_t* orow = Oh + ((size_t)b * p.Tq + q) * p.ldo;
+        const bf16_t* drow = dOh + ((size_t)b * p.Tq + q) * p.lddo;
+        float a8[8], b8[8], acc = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          unpack8(*reinterpret_cast<const u32x4*>(orow + half * 32 + g * 8), a8);
+          unpack8(*reinterpret_cast<const u32x4*>(drow + half * 32 + g * 8), b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc += a8[e] * b8[e];
+        }
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (g == 0) {
+          del_s[wave * 16 + r] = acc;
+          lse_s[wave * 16 + r] = p.lse[((size_t)b * p.H + h) * p.Tq + q];
+        }
+      }
+      __syncthreads();
+      // S = Q K^T and dP = dO V^T for this wave's 16 query rows x 64 keys
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 qf = frag_rows(Qs, wave, kk, r, g);
+        const bf16x8 df = frag_rows(dOs, wave, kk, r, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, frag_rows(Ks, j, kk, r, g), s[j], 0, 0, 0);
+          dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, frag_rows(Vs, j, kk, r, g), dp[j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kt * 64 + j * 16 + r;
+        bool kv = key < p.Tk;
+        if (kv && p.key_mask != nullptr) kv = p.key_mask[(size_t)b * p.Tk + key] != 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lrow = wave * 16 + g * 4 + q;
+          const int qi = qt * 64 + lrow;
+          const bool ok = kv && qi < p.Tq && (!p.causal || key <= qi);
+          const float lse = lse_s[lrow];
+          const float pv = (ok && lse != -INFINITY) ? __expf(s[j][q] - lse) : 0.f;
+          const float ds = pv * (dp[j][q] - del_s[lrow]);
+          *reinterpret_cast<bf16_t*>(Ps + elem_off(lrow, j * 16 + r)) = f2bf(pv);
+          *reinterpret_cast<bf16_t*>(dSs + elem_off(lrow, j * 16 + r)) = f2bf(ds);
+        }
+      }
+      __syncthreads();
+      // dQ[16 rows of this wave] += dS K ; dV[16 keys of this wave] += P^T dO ; dK += dS^T Q
+      f32x4 dq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 dsf = frag_rows(dSs, wave, kk, r, g);
+        const bf16x8 ptf = frag_cols(Ps, wave, kk, r, g);
+        const bf16x8 dstf = frag_cols(dSs, wave, kk, r, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_cols(Ks, j, kk, r, g), dq[j], 0, 0, 0);
+          dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ptf, frag_cols(dOs, j, kk, r, g), dv[j], 0, 0, 0);
+          dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dstf, frag_cols(Qs, j, kk, r, g), dk[j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float* a = dQacc + (size_t)(qt * 64 + wave * 16 + g * 4 + q) * 64 + j * 16 + r;
+          *a = (kt == 0) ? dq[j][q] : (*a + dq[j][q]);
+        }
+    }
+    // this wave's 16 keys of dK / dV
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int key = kt * 64 + wave * 16 + g * 4 + q;
+      if (key < p.Tk) {
+        bf16_t* kr = p.dK + ((size_t)b * p.Tk + key) * p.lddk + h * HD;
+        bf16_t* vr = p.dV + ((size_t)b * p.Tk + key) * p.lddv + h * HD;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          kr[j * 16 + r] = f2bf(dk[j][q]);
+          vr[j * 16 + r] = f2bf(dv[j][q]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < p.Tq * 8; i += 256) {
+    const int q = i >> 3, c = i & 7;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = dQacc[(size_t)q * 64 + c * 8 + e] * p.dq_scale;
+    *reinterpret_cast<u32x4*>(p.dQ + ((size_t)b * p.Tq + q) * p.lddq + h * HD + c * 8) = pack8(v);
+  }
+}
+
+// ------------------------------------------------- single-query decode step
+// one wave per (row, head): scores over the cached keys, softmax, weighted sum of cached values
+__global__ __launch_bounds__(256) void attn_decode_kernel(const KmbAttnDecode p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave;
+  float* sc = reinterpret_cast<float*>(smem) + (size_t)wave * p.Tk;
+  if (item >= p.R * p.H) return;  // whole wave exits together; no block barrier is used below
+  const int row = item / p.H, h = item % p.H;
+  const int crow = p.kv_row != nullptr ? p.kv_row[row] : row;
+  const int mrow = p.mask_row != nullptr ? p.mask_row[row] : row;
+  const int HDm = p.ldc;
+  const bf16_t* Kc = p.Kc + (size_t)crow * p.Tmax * HDm + h * HD;
+  const bf16_t* Vc = p.Vc + (size_t)crow * p.Tmax * HDm + h * HD;
+  float q[HD];
+  {
+    const bf16_t* qrow = p.Q + (size_t)row * p.ldq + h * HD;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) unpack8(*reinterpret_cast<const u32x4*>(qrow + c * 8), q + c * 8);
+  }
+  float mx = -INFINITY;
+  for (int t = lane; t < p.Tk; t += 64) {
+    float s = 0.f;
+    const bf16_t* krow = Kc + (size_t)t * HDm;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float k8[8];
+      unpack8(*reinterpret_cast<const u32x4*>(krow + c * 8), k8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += q[c * 8 + e] * k8[e];
+    }
+    if (p.key_mask != nullptr && p.key_mask[(size_t)mrow * p.mask_ld + t] == 0) s = -INFINITY;
+    sc[t] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float l = 0.f;
+  for (int t = lane; t < p.Tk; t += 64) {
+    const float e = (mx == -INFINITY) ? 0.f : __expf(sc[t] - mx);
+    sc[t] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float acc = 0.f;
+  for (int t = 0; t < p.Tk; ++t) acc += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
+  p.O[(size_t)row * p.ldo + h * HD + lane] = f2bf(acc * inv);
+}
+
+}  // namespace
+
+const char* kmb_attn_check(const KmbAttn& p, int backward) {
+  if (p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return "attention: empty problem";
+  if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 7)) return "attention: row strides must be multiples of 8";
+  if (((uintptr_t)p.Q & 15) || ((uintptr_t)p.K & 15) || ((uintptr_t)p.V & 15) || ((uintptr_t)p.O & 15))
+    return "attention: pointers must be 16-byte aligned";
+  if (backward) {
+    if (!p.dO || !p.dQ || !p.dK || !p.dV || !p.lse) return "attention backward: missing tensor";
+    if ((p.lddo & 7) || (p.lddq & 7) || (p.lddk & 7) || (p.lddv & 7)) return "attention backward: row strides";
+    if (((uintptr_t)p.dO & 15) || ((uintptr_t)p.dQ & 15)) return "attention backward: alignment";
+    if (p.Tq > 384) return "attention backward: Tq > 384 is not supported (dQ accumulator lives in LDS)";
+  }
+  return nullptr;
+}
+
+hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
+  dim3 grid(p.B * p.H, (p.Tq + 63) / 64), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream) {
+  const int nqt = (p.Tq + 63) / 64;
+  const size_t lds = 6 * TILE_BYTES + 128 * sizeof(float) + (size_t)nqt * 64 * 64 * sizeof(float);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.B * p.H), dim3(256), lds, stream, p, nqt);
+  return hipGetLastError();
+}
+
+hipError_t kmb_attn_decode_launch(const KmbAttnDecode& p, hipStream_t stream) {
+  const int items = p.R * p.H;
+  if (items <= 0) return hipSuccess;
+  const size_t lds = (size_t)4 * p.Tk * sizeof(float);
+  hipLaunchKernelGGL(attn_decode_kernel, dim3((items + 3) / 4), dim3(256), lds, stream, p);
+  return hipGetLastError();
+}

@@ -1,0 +1,114 @@
+// C-ABI wrappers around single kernels (unit tests, profiling).  See include/kmbart.h.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <string>
+
+#include "kernels.h"
+
+extern "C" const char* kmb_last_error(void);
+int kmb_set_error(const char* msg);  // engine.cpp
+
+namespace {
+int hipfail(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  return kmb_set_error(buf);
+}
+}  // namespace
+
+extern "C" {
+
+int kmb_op_gemm(const KmbGemm* p, void* stream) {
+  const char* why = kmb_gemm_check(*p);
+  if (why) return kmb_set_error(why);
+  return hipfail(kmb_gemm_launch(*p, (hipStream_t)stream), "gemm");
+}
+int kmb_op_attn_fwd(const KmbAttn* p, void* stream) {
+  const char* why = kmb_attn_check(*p, 0);
+  if (why) return kmb_set_error(why);
+  return hipfail(kmb_attn_fwd_launch(*p, (hipStream_t)stream), "attn_fwd");
+}
+int kmb_op_attn_bwd(const KmbAttn* p, void* stream) {
+  const char* why = kmb_attn_check(*p, 1);
+  if (why) return kmb_set_error(why);
+  return hipfail(kmb_attn_bwd_launch(*p, (hipStream_t)stream), "attn_bwd");
+}
+int kmb_op_attn_decode(const KmbAttnDecode* p, void* stream) {
+  return hipfail(kmb_attn_decode_launch(*p, (hipStream_t)stream), "attn_decode");
+}
+int kmb_op_ln_fwd(const kmb_bf16* z, const float* gamma, const float* beta, kmb_bf16* y, float* mean, float* rstd,
+                  int M, int D, float eps, void* stream) {
+  return hipfail(kmb_ln_fwd_launch(z, gamma, beta, y, mean, rstd, M, D, eps, (hipStream_t)stream), "ln_fwd");
+}
+int64_t kmb_op_ln_bwd_scratch(int M, int D) { return (int64_t)kmb_ln_bwd_parts(M) * 2 * D; }
+int kmb_op_ln_bwd(const kmb_bf16* dy, const kmb_bf16* z, const float* mean, const float* rstd, const float* gamma,
+                  kmb_bf16* dz, kmb_bf16* out2, const KmbDrop* dy_drop, const KmbDrop* out2_drop, float* dgamma,
+                  float* dbeta, float* scratch, int M, int D, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const KmbDrop none{0u, 0u, 1.f};
+  int rc = hipfail(kmb_ln_bwd_launch(dy, z, mean, rstd, gamma, dz, out2, dy_drop ? *dy_drop : none,
+                                     out2_drop ? *out2_drop : none, scratch, M, D, s), "ln_bwd");
+  if (rc) return rc;
+  const int np = kmb_ln_bwd_parts(M);
+  rc = hipfail(kmb_reduce_parts_launch(scratch, np, 2 * D, dgamma, D, s), "ln_bwd reduce");
+  if (rc) return rc;
+  return hipfail(kmb_reduce_parts_launch(scratch + D, np, 2 * D, dbeta, D, s), "ln_bwd reduce");
+}
+int64_t kmb_op_colsum_scratch(int M, int N) { return (int64_t)kmb_colsum_parts(M) * N; }
+int kmb_op_colsum(const kmb_bf16* X, int ld, int M, int N, float* out, float* scratch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc = hipfail(kmb_colsum_launch(X, ld, M, N, scratch, s), "colsum");
+  if (rc) return rc;
+  return hipfail(kmb_reduce_parts_launch(scratch, kmb_colsum_parts(M), N, out, N, s), "colsum reduce");
+}
+int kmb_op_img_rowmap(const int64_t* ids, const int32_t* feat_off, int B, int S, int64_t img_feat_id, int64_t cls_id,
+                      int32_t* img_src, int32_t* status, void* stream) {
+  return hipfail(kmb_img_rowmap_launch(ids, feat_off, B, S, img_feat_id, cls_id, img_src, status, (hipStream_t)stream), "img_rowmap");
+}
+int kmb_op_cast_pad(const float* x, int N, int Fin, kmb_bf16* y, int Fpad, void* stream) {
+  return hipfail(kmb_cast_pad_launch(x, N, Fin, y, Fpad, (hipStream_t)stream), "cast_pad");
+}
+int kmb_op_embed_ln_fwd(const int64_t* ids, const int32_t* img_src, const float* E, const float* img_emb,
+                        const float* P, int pos_base, int S, float scale, const float* gamma, const float* beta,
+                        kmb_bf16* z, kmb_bf16* y, float* mean, float* rstd, int M, int D, float eps,
+                        const KmbDrop* drop, void* stream) {
+  const KmbDrop none{0u, 0u, 1.f};
+  return hipfail(kmb_embed_ln_fwd_launch(ids, img_src, E, img_emb, P, pos_base, S, scale, gamma, beta, z, y, mean,
+                                         rstd, M, D, eps, drop ? *drop : none, (hipStream_t)stream), "embed_ln_fwd");
+}
+int kmb_op_embed_bwd(const kmb_bf16* dz, const int64_t* ids, const int32_t* img_src, float scale, float* dE,
+                     kmb_bf16* dimg, int64_t pad_id, int M, int D, void* stream) {
+  return hipfail(kmb_embed_bwd_launch(dz, ids, img_src, scale, dE, dimg, pad_id, M, D, (hipStream_t)stream), "embed_bwd");
+}
+int kmb_op_pos_bwd(const kmb_bf16* dz, int B, int S, int D, float* dP, int pos_base, int P_rows, void* stream) {
+  return hipfail(kmb_pos_bwd_launch(dz, B, S, D, dP, pos_base, P_rows, (hipStream_t)stream), "pos_bwd");
+}
+int kmb_op_ce(const float* logits, int ldv, int V, const int64_t* labels, int rows, float grad_scale,
+              float* loss_rows, kmb_bf16* dlogits, int32_t* count, float* loss, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc = hipfail(kmb_count_valid_launch(labels, rows, count, s), "count_valid");
+  if (rc) return rc;
+  rc = hipfail(kmb_ce_launch(logits, ldv, V, labels, rows, count, grad_scale, loss_rows, dlogits, s), "ce");
+  if (rc) return rc;
+  return hipfail(kmb_loss_finish_launch(loss_rows, rows, count, loss, s), "loss_finish");
+}
+int kmb_op_adamw(float* p, const float* g, float* m, float* v, kmb_bf16* p_bf16, int64_t n, const KmbAdamW* hp,
+                 void* stream) {
+  return hipfail(kmb_adamw_launch(p, g, m, v, p_bf16, (size_t)n, *hp, (hipStream_t)stream), "adamw");
+}
+int kmb_op_cast_bf16(const float* x, kmb_bf16* y, int64_t n, void* stream) {
+  return hipfail(kmb_cast_f32_bf16_launch(x, y, (size_t)n, (hipStream_t)stream), "cast");
+}
+int kmb_op_dropout_mask(uint32_t seed, float p, int rows, int cols, uint8_t* keep, void* stream) {
+  uint32_t thr = (uint32_t)lrintf(p * 65536.f);
+  if (thr > 65535u) thr = 65535u;
+  return hipfail(kmb_dropout_mask_launch(seed, thr, rows, cols, keep, (hipStream_t)stream), "dropout_mask");
+}
+int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int k,
+                        float* out_val, int32_t* out_idx, void* stream) {
+  return hipfail(kmb_logsoftmax_topk_launch(logits, ld, V, rows, add, force_token, k, out_val, out_idx, (hipStream_t)stream), "logsoftmax_topk");
+}
+
+}  // extern "C"

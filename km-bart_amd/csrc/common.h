@@ -1,0 +1,71 @@
+// Shared device helpers for the KM-BART HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; arithmetic is always done in f32
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (8 bf16 = 4 VGPR)
+typedef __attribute__((ext_vector_type(4))) short s16x4;    // ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4; // one 16-byte chunk
+
+#define KMB_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float lo_bf(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+__device__ __forceinline__ void unpack8(const u32x4& c, float* f) {
+  f[0] = lo_bf(c[0]); f[1] = hi_bf(c[0]); f[2] = lo_bf(c[1]); f[3] = hi_bf(c[1]);
+  f[4] = lo_bf(c[2]); f[5] = hi_bf(c[2]); f[6] = lo_bf(c[3]); f[7] = hi_bf(c[3]);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 c;
+  c[0] = pack2bf(f[0], f[1]); c[1] = pack2bf(f[2], f[3]);
+  c[2] = pack2bf(f[4], f[5]); c[3] = pack2bf(f[6], f[7]);
+  return c;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GeLU, the reference's "activation_function": "gelu" (config/vcg_base.json:3)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- dropout: counter-based keep decision, identical in forward epilogues and backward ----
+// keep(row, col) depends only on (site_seed, row, col); site_seed = mix(seed, step, site) on host.
+__device__ __forceinline__ uint32_t kmb_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t site_seed, uint32_t row, uint32_t col, uint32_t thr16) {
+  const uint32_t h = kmb_hash32((row * 0x9E3779B1u) ^ (col * 0x85EBCA77u + 0x165667B1u) ^ site_seed);
+  return (h >> 16) >= thr16;  // P(drop) = thr16 / 65536
+}

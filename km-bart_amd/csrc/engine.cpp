@@ -1,0 +1,946 @@
+// Host-side driver of the KM-BART hot path: owns the parameter census, lays activations out in the
+// caller's workspace and enqueues the HIP kernels of one training step / decode step on a stream.
+// No device allocation, no synchronisation: the Python host (torch) owns memory and streams.
+//
+// Reference call path being replaced:
+//   src/training.py:118-143 -> src/model/model.py:325-405 -> src/model/modules.py:104-165
+//   + transformers 3.0.2 EncoderLayer / BartDecoder / AdamW.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define KCHK(expr)                 \
+  do {                             \
+    int rc_ = (expr);              \
+    if (rc_ != 0) return rc_;      \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline uint64_t splitmix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+struct ParamInfo { std::string name; size_t off; int rows, cols; };
+struct AttnP { size_t qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
+struct LayerP { AttnP sa, ca; size_t fc1_w, fc1_b, fc2_w, fc2_b, ln_g, ln_b; };
+struct Bucket { size_t off, count; };
+
+struct EncAct { bf16_t *qkv, *o, *z1, *y1, *u, *hh, *z2; float *lse, *m1, *r1, *m2, *r2; };
+struct DecAct {
+  bf16_t *qkv, *o1, *z1, *y1, *cq, *ckv, *o2, *z2, *y2, *u, *hh, *z3;
+  float *lse1, *lse2, *m1, *r1, *m2, *r2, *m3, *r3;
+};
+
+class Bump {
+ public:
+  Bump(char* base, size_t cap) : base_(base), cap_(cap), off_(0) {}
+  template <typename T> T* take(size_t n) {
+    off_ = align_up(off_, 256);
+    T* p = reinterpret_cast<T*>(base_ + off_);
+    off_ += n * sizeof(T);
+    return p;
+  }
+  size_t used() const { return align_up(off_, 256); }
+  bool ok() const { return base_ == nullptr || off_ <= cap_; }
+ private:
+  char* base_; size_t cap_, off_;
+};
+
+}  // namespace
+
+struct kmb_handle {
+  kmb_config cfg;
+  int d, He, Hd, Fe, Fd, V, Vpad, Fin, Fpad, Prows;
+  std::vector<ParamInfo> params;
+  size_t arena = 0;
+  size_t img_w, img_b, enc_pos, enc_lne_g, enc_lne_b, dec_pos, dec_lne_g, dec_lne_b, shared;
+  std::vector<LayerP> enc, dec;
+  std::vector<Bucket> buckets;      // in backward completion order
+  std::vector<hipEvent_t> events;
+  // bound memory
+  float *P = nullptr, *G = nullptr, *M1 = nullptr, *M2 = nullptr, *flb = nullptr;
+  bf16_t* PB = nullptr;
+  bf16_t* imgw_pad = nullptr;       // inside the bf16 arena tail: [d, Fpad]
+  char* ws = nullptr; size_t ws_bytes = 0;
+  uint64_t seed = 0x5eedULL; uint64_t step = 0;
+  int lm_chunk = 512;
+  // ---- state of the last forward (consumed by backward)
+  kmb_batch bt{}; bool have_fwd = false; bool fwd_train = false;
+  int Me = 0, Md = 0, Ntot = 0;
+  std::vector<EncAct> ea; std::vector<DecAct> da;
+  std::vector<bf16_t*> xe, xd;
+  bf16_t *ze0 = nullptr, *zd0 = nullptr; float *me0, *re0, *md0, *rd0;
+  bf16_t* xf = nullptr; float* img_emb = nullptr; int32_t* img_src = nullptr; bf16_t* dimg = nullptr;
+  float* logits_c = nullptr; bf16_t* dlogits_c = nullptr; float* loss_rows = nullptr; int32_t* count = nullptr;
+  int32_t* status = nullptr; float* loss_dev = nullptr;
+  bf16_t *dhdec, *dyA, *dyB, *dz, *dsub, *du, *dqkv, *dcq, *dckv, *dob, *denc;
+  float* parts = nullptr;
+  // ---- generation state
+  struct Gen {
+    bool active = false; int B = 0, S = 0, nb = 0, R = 0, Tmax = 0;
+    kmb_batch bt{};
+    std::vector<bf16_t*> ckv;              // per layer [B*S, 2d]
+    std::vector<bf16_t*> kc[2], vc[2];     // per layer self caches, double buffered [R, Tmax, d]
+    int cur = 0;
+    int32_t *kv_row = nullptr;             // [R] -> batch item
+    bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd;
+  } gen;
+
+  KmbDrop drop_site(int site, bool train) const {
+    KmbDrop dr{0u, 0u, 1.f};
+    if (!train || cfg.dropout <= 0.f) return dr;
+    uint32_t thr = (uint32_t)lrintf(cfg.dropout * 65536.f);
+    if (thr > 65535u) thr = 65535u;
+    dr.thr16 = thr;
+    dr.seed = (uint32_t)splitmix(seed ^ splitmix(step * 0x10001ull + (uint64_t)site));
+    dr.scale = 1.f / (1.f - (float)thr / 65536.f);
+    return dr;
+  }
+  bf16_t* wb(size_t off) const { return PB + off; }
+  float* pf(size_t off) const { return P + off; }
+  float* gf(size_t off) const { return G + off; }
+};
+
+namespace {
+
+size_t add_param(kmb_handle* h, const std::string& name, int rows, int cols) {
+  h->arena = align_up(h->arena, 64);
+  const size_t off = h->arena;
+  h->params.push_back({name, off, rows, cols});
+  h->arena += (size_t)rows * cols;
+  return off;
+}
+
+void add_attn(kmb_handle* h, const std::string& p, const std::string& ln, AttnP& a) {
+  const int d = h->d;
+  a.qkv_w = add_param(h, p + "q_proj.weight", d, d);
+  add_param(h, p + "k_proj.weight", d, d);
+  add_param(h, p + "v_proj.weight", d, d);
+  a.qkv_b = add_param(h, p + "q_proj.bias", 1, d);
+  add_param(h, p + "k_proj.bias", 1, d);
+  add_param(h, p + "v_proj.bias", 1, d);
+  a.o_w = add_param(h, p + "out_proj.weight", d, d);
+  a.o_b = add_param(h, p + "out_proj.bias", 1, d);
+  a.ln_g = add_param(h, ln + ".weight", 1, d);
+  a.ln_b = add_param(h, ln + ".bias", 1, d);
+}
+
+void add_ffn(kmb_handle* h, const std::string& p, int F, LayerP& L) {
+  const int d = h->d;
+  L.fc1_w = add_param(h, p + "fc1.weight", F, d);
+  L.fc1_b = add_param(h, p + "fc1.bias", 1, F);
+  L.fc2_w = add_param(h, p + "fc2.weight", d, F);
+  L.fc2_b = add_param(h, p + "fc2.bias", 1, d);
+  L.ln_g = add_param(h, p + "final_layer_norm.weight", 1, d);
+  L.ln_b = add_param(h, p + "final_layer_norm.bias", 1, d);
+}
+
+KmbGemm gemm0() { KmbGemm g; memset(&g, 0, sizeof(g)); g.col_scale = 1.f; g.drop_scale = 1.f; return g; }
+
+int run_gemm(const KmbGemm& g, hipStream_t s) {
+  const char* why = kmb_gemm_check(g);
+  if (why) return fail("%s (M=%d N=%d K=%d lda=%d ldb=%d akc=%d bkc=%d)", why, g.M, g.N, g.K, g.lda, g.ldb, g.a_kc, g.b_kc);
+  HIPCHK(kmb_gemm_launch(g, s));
+  return 0;
+}
+
+// Y[M,N] = X[M,K] W[N,K]^T + b
+KmbGemm lin_fwd(const bf16_t* x, int ldx, const bf16_t* w, const float* b, int M, int N, int K) {
+  KmbGemm g = gemm0();
+  g.A = x; g.lda = ldx; g.a_kc = 1; g.B = w; g.ldb = K; g.b_kc = 1; g.M = M; g.N = N; g.K = K; g.bias = b;
+  return g;
+}
+// dX[M,K] = dY[M,N] W[N,K]
+KmbGemm lin_dgrad(const bf16_t* dy, int lddy, const bf16_t* w, int M, int N, int K) {
+  KmbGemm g = gemm0();
+  g.A = dy; g.lda = lddy; g.a_kc = 1; g.B = w; g.ldb = K; g.b_kc = 0; g.M = M; g.N = K; g.K = N;
+  return g;
+}
+// dW[N,K] = dY[M,N]^T X[M,K]   (fp32, written straight into the gradient arena)
+KmbGemm lin_wgrad(const bf16_t* dy, int lddy, const bf16_t* x, int ldx, float* dW, int M, int N, int K, float beta) {
+  KmbGemm g = gemm0();
+  g.A = dy; g.lda = lddy; g.a_kc = 0; g.B = x; g.ldb = ldx; g.b_kc = 0; g.M = N; g.N = K; g.K = M;
+  g.out_f32 = dW; g.ld_out_f32 = K; g.beta = beta;
+  return g;
+}
+
+int bias_grad(kmb_handle* h, const bf16_t* dy, int ld, int M, int N, float* out, hipStream_t s) {
+  HIPCHK(kmb_colsum_launch(dy, ld, M, N, h->parts, s));
+  HIPCHK(kmb_reduce_parts_launch(h->parts, kmb_colsum_parts(M), N, out, N, s));
+  return 0;
+}
+
+int ln_backward(kmb_handle* h, const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, size_t g_off,
+                size_t b_off, bf16_t* dz, bf16_t* out2, KmbDrop dy_drop, KmbDrop out2_drop, int M, hipStream_t s) {
+  const int d = h->d;
+  HIPCHK(kmb_ln_bwd_launch(dy, z, mean, rstd, h->pf(g_off), dz, out2, dy_drop, out2_drop, h->parts, M, d, s));
+  const int np = kmb_ln_bwd_parts(M);
+  // partials are [np][2][d]: dgamma rows at stride 2d offset 0, dbeta at offset d
+  HIPCHK(kmb_reduce_parts_launch(h->parts, np, 2 * d, h->gf(g_off), d, s));
+  HIPCHK(kmb_reduce_parts_launch(h->parts + d, np, 2 * d, h->gf(b_off), d, s));
+  return 0;
+}
+
+size_t parts_floats(const kmb_handle* h, int Mmax) {
+  const int d = h->d;
+  int maxN = 3 * d;
+  if (h->Fe > maxN) maxN = h->Fe;
+  if (h->Fd > maxN) maxN = h->Fd;
+  size_t a = (size_t)kmb_ln_bwd_parts(Mmax) * 2 * d;
+  size_t b = (size_t)kmb_colsum_parts(Mmax) * maxN;
+  // colsum parts grows for small M (rows_per_part floor): bound it
+  if (b < (size_t)64 * maxN) b = (size_t)64 * maxN;
+  if (a < (size_t)512 * 2 * d) a = (size_t)512 * 2 * d;
+  return a > b ? a : b;
+}
+
+// ------------------------------------------------------------------ workspace layout (training)
+// With base == nullptr this only measures.
+size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, int Ntot, bool assign) {
+  const int d = h->d, Fe = h->Fe, Fd = h->Fd;
+  const size_t Me = (size_t)B * S, Md = (size_t)B * T;
+  const size_t Mmax = Me > Md ? Me : Md;
+  const int Le = h->cfg.encoder_layers, Ld = h->cfg.decoder_layers;
+  Bump bp(base, cap);
+  auto* H = h;
+  int32_t* status = bp.take<int32_t>(4);
+  int32_t* count = bp.take<int32_t>(4);
+  float* loss_dev = bp.take<float>(4);
+  bf16_t* xf = bp.take<bf16_t>((size_t)(Ntot > 0 ? Ntot : 1) * h->Fpad);
+  float* img_emb = bp.take<float>((size_t)(Ntot > 0 ? Ntot : 1) * d);
+  bf16_t* dimg = bp.take<bf16_t>((size_t)(Ntot > 0 ? Ntot : 1) * d);
+  int32_t* img_src = bp.take<int32_t>(Me);
+  bf16_t* ze0 = bp.take<bf16_t>(Me * d);
+  float* me0 = bp.take<float>(Me); float* re0 = bp.take<float>(Me);
+  bf16_t* zd0 = bp.take<bf16_t>(Md * d);
+  float* md0 = bp.take<float>(Md); float* rd0 = bp.take<float>(Md);
+  std::vector<bf16_t*> xe(Le + 1), xd(Ld + 1);
+  for (int l = 0; l <= Le; ++l) xe[l] = bp.take<bf16_t>(Me * d);
+  for (int l = 0; l <= Ld; ++l) xd[l] = bp.take<bf16_t>(Md * d);
+  std::vector<EncAct> ea(Le);
+  for (int l = 0; l < Le; ++l) {
+    EncAct& a = ea[l];
+    a.qkv = bp.take<bf16_t>(Me * 3 * d); a.o = bp.take<bf16_t>(Me * d); a.z1 = bp.take<bf16_t>(Me * d);
+    a.y1 = bp.take<bf16_t>(Me * d); a.u = bp.take<bf16_t>(Me * Fe); a.hh = bp.take<bf16_t>(Me * Fe);
+    a.z2 = bp.take<bf16_t>(Me * d);
+    a.lse = bp.take<float>((size_t)B * h->He * S);
+    a.m1 = bp.take<float>(Me); a.r1 = bp.take<float>(Me); a.m2 = bp.take<float>(Me); a.r2 = bp.take<float>(Me);
+  }
+  std::vector<DecAct> da(Ld);
+  for (int l = 0; l < Ld; ++l) {
+    DecAct& a = da[l];
+    a.qkv = bp.take<bf16_t>(Md * 3 * d); a.o1 = bp.take<bf16_t>(Md * d); a.z1 = bp.take<bf16_t>(Md * d);
+    a.y1 = bp.take<bf16_t>(Md * d); a.cq = bp.take<bf16_t>(Md * d); a.ckv = bp.take<bf16_t>(Me * 2 * d);
+    a.o2 = bp.take<bf16_t>(Md * d); a.z2 = bp.take<bf16_t>(Md * d); a.y2 = bp.take<bf16_t>(Md * d);
+    a.u = bp.take<bf16_t>(Md * Fd); a.hh = bp.take<bf16_t>(Md * Fd); a.z3 = bp.take<bf16_t>(Md * d);
+    a.lse1 = bp.take<float>((size_t)B * h->Hd * T); a.lse2 = bp.take<float>((size_t)B * h->Hd * T);
+    a.m1 = bp.take<float>(Md); a.r1 = bp.take<float>(Md); a.m2 = bp.take<float>(Md); a.r2 = bp.take<float>(Md);
+    a.m3 = bp.take<float>(Md); a.r3 = bp.take<float>(Md);
+  }
+  const size_t CH = Md < (size_t)h->lm_chunk ? Md : (size_t)h->lm_chunk;
+  float* logits_c = bp.take<float>(CH * h->Vpad);
+  bf16_t* dlogits_c = bp.take<bf16_t>(CH * h->Vpad);
+  float* loss_rows = bp.take<float>(Md);
+  bf16_t* dhdec = bp.take<bf16_t>(Md * d);
+  bf16_t* dyA = bp.take<bf16_t>(Mmax * d); bf16_t* dyB = bp.take<bf16_t>(Mmax * d);
+  bf16_t* dz = bp.take<bf16_t>(Mmax * d); bf16_t* dsub = bp.take<bf16_t>(Mmax * d);
+  const int Fmax = Fe > Fd ? Fe : Fd;
+  bf16_t* du = bp.take<bf16_t>(Mmax * Fmax);
+  bf16_t* dqkv = bp.take<bf16_t>(Mmax * 3 * d);
+  bf16_t* dcq = bp.take<bf16_t>(Md * d); bf16_t* dckv = bp.take<bf16_t>(Me * 2 * d);
+  bf16_t* dob = bp.take<bf16_t>(Mmax * d); bf16_t* denc = bp.take<bf16_t>(Me * d);
+  float* parts = bp.take<float>(parts_floats(h, (int)Mmax));
+  if (assign) {
+    H->status = status; H->count = count; H->loss_dev = loss_dev; H->xf = xf; H->img_emb = img_emb; H->dimg = dimg;
+    H->img_src = img_src; H->ze0 = ze0; H->me0 = me0; H->re0 = re0; H->zd0 = zd0; H->md0 = md0; H->rd0 = rd0;
+    H->xe = xe; H->xd = xd; H->ea = ea; H->da = da; H->logits_c = logits_c; H->dlogits_c = dlogits_c;
+    H->loss_rows = loss_rows; H->dhdec = dhdec; H->dyA = dyA; H->dyB = dyB; H->dz = dz; H->dsub = dsub; H->du = du;
+    H->dqkv = dqkv; H->dcq = dcq; H->dckv = dckv; H->dob = dob; H->denc = denc; H->parts = parts;
+  }
+  return bp.used();
+}
+
+int check_bound(const kmb_handle* h) {
+  if (!h->P || !h->G || !h->PB) return fail("arenas are not bound (kmb_bind_arenas)");
+  if (!h->ws) return fail("workspace is not bound (kmb_bind_workspace)");
+  return 0;
+}
+
+// ------------------------------------------------------------------ shared sub-graphs
+struct AttnIO { const bf16_t* q; int ldq; const bf16_t* k; const bf16_t* v; int ldkv; int Tq, Tk; const int64_t* mask; int causal; };
+
+int attn_forward(kmb_handle* h, const AttnIO& io, int B, int H, bf16_t* o, float* lse, hipStream_t s) {
+  KmbAttn a; memset(&a, 0, sizeof(a));
+  a.Q = io.q; a.K = io.k; a.V = io.v; a.ldq = io.ldq; a.ldk = io.ldkv; a.ldv = io.ldkv;
+  a.B = B; a.H = H; a.Tq = io.Tq; a.Tk = io.Tk; a.key_mask = io.mask; a.causal = io.causal;
+  a.O = o; a.ldo = h->d; a.lse = lse;
+  const char* why = kmb_attn_check(a, 0);
+  if (why) return fail("%s", why);
+  HIPCHK(kmb_attn_fwd_launch(a, s));
+  return 0;
+}
+
+int attn_backward(kmb_handle* h, const AttnIO& io, int B, int H, bf16_t* o, float* lse, const bf16_t* dO, bf16_t* dq,
+                  int lddq, bf16_t* dk, bf16_t* dv, int lddkv, hipStream_t s) {
+  KmbAttn a; memset(&a, 0, sizeof(a));
+  a.Q = io.q; a.K = io.k; a.V = io.v; a.ldq = io.ldq; a.ldk = io.ldkv; a.ldv = io.ldkv;
+  a.B = B; a.H = H; a.Tq = io.Tq; a.Tk = io.Tk; a.key_mask = io.mask; a.causal = io.causal;
+  a.O = o; a.ldo = h->d; a.lse = lse; a.dO = dO; a.lddo = h->d;
+  a.dQ = dq; a.lddq = lddq; a.dK = dk; a.dV = dv; a.lddk = lddkv; a.lddv = lddkv; a.dq_scale = 0.125f;
+  const char* why = kmb_attn_check(a, 1);
+  if (why) return fail("%s", why);
+  HIPCHK(kmb_attn_bwd_launch(a, s));
+  return 0;
+}
+
+// post-LN FFN block forward: z = x + drop(fc2(gelu(fc1(x)))) ; out = LN(z)
+int ffn_forward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, bf16_t* u, bf16_t* hh, bf16_t* z, float* mean,
+                float* rstd, bf16_t* out, int M, KmbDrop dr, hipStream_t s) {
+  const int d = h->d;
+  KmbGemm g = lin_fwd(x, d, h->wb(L.fc1_w), h->pf(L.fc1_b), M, F, d);
+  g.act = 1; g.preact = u; g.ld_preact = F; g.out_bf16 = hh; g.ld_out_bf16 = F;
+  KCHK(run_gemm(g, s));
+  g = lin_fwd(hh, F, h->wb(L.fc2_w), h->pf(L.fc2_b), M, d, F);
+  g.drop_thr16 = dr.thr16; g.drop_seed = dr.seed; g.drop_scale = dr.scale;
+  g.residual = x; g.ld_res = d; g.out_bf16 = z; g.ld_out_bf16 = d;
+  KCHK(run_gemm(g, s));
+  HIPCHK(kmb_ln_fwd_launch(z, h->pf(L.ln_g), h->pf(L.ln_b), out, mean, rstd, M, d, h->cfg.layer_norm_eps, s));
+  return 0;
+}
+
+// backward of the FFN block.  dy: grad wrt LN output.  Result: grad wrt block input x in dx_out.
+int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const bf16_t* u, const bf16_t* hh,
+                 const bf16_t* z, const float* mean, const float* rstd, const bf16_t* dy, bf16_t* dx_out, int M,
+                 KmbDrop dr, hipStream_t s) {
+  const int d = h->d;
+  bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
+  KCHK(ln_backward(h, dy, z, mean, rstd, L.ln_g, L.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s));
+  KCHK(bias_grad(h, dsub, d, M, d, h->gf(L.fc2_b), s));
+  KCHK(run_gemm(lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
+  KmbGemm g = lin_dgrad(dsub, d, h->wb(L.fc2_w), M, d, F);
+  g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = h->du; g.ld_out_bf16 = F;
+  KCHK(run_gemm(g, s));
+  KCHK(bias_grad(h, h->du, F, M, F, h->gf(L.fc1_b), s));
+  KCHK(run_gemm(lin_wgrad(h->du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
+  g = lin_dgrad(h->du, F, h->wb(L.fc1_w), M, F, d);
+  g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
+  KCHK(run_gemm(g, s));
+  return 0;
+}
+
+// self-attention block forward: z = x + drop(out_proj(attn(qkv(x)))) ; out = LN(z)
+int self_attn_forward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf16_t* qkv, bf16_t* o, float* lse,
+                      bf16_t* z, float* mean, float* rstd, bf16_t* out, int B, int T, const int64_t* mask, int causal,
+                      KmbDrop dr, hipStream_t s) {
+  const int d = h->d, M = B * T;
+  KmbGemm g = lin_fwd(x, d, h->wb(A.qkv_w), h->pf(A.qkv_b), M, 3 * d, d);
+  g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = qkv; g.ld_out_bf16 = 3 * d;
+  KCHK(run_gemm(g, s));
+  AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
+  KCHK(attn_forward(h, io, B, H, o, lse, s));
+  g = lin_fwd(o, d, h->wb(A.o_w), h->pf(A.o_b), M, d, d);
+  g.drop_thr16 = dr.thr16; g.drop_seed = dr.seed; g.drop_scale = dr.scale;
+  g.residual = x; g.ld_res = d; g.out_bf16 = z; g.ld_out_bf16 = d;
+  KCHK(run_gemm(g, s));
+  HIPCHK(kmb_ln_fwd_launch(z, h->pf(A.ln_g), h->pf(A.ln_b), out, mean, rstd, M, d, h->cfg.layer_norm_eps, s));
+  return 0;
+}
+
+int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf16_t* qkv, bf16_t* o, float* lse,
+                       const bf16_t* z, const float* mean, const float* rstd, const bf16_t* dy, bf16_t* dx_out, int B,
+                       int T, const int64_t* mask, int causal, KmbDrop dr, hipStream_t s) {
+  const int d = h->d, M = B * T;
+  bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
+  KCHK(ln_backward(h, dy, z, mean, rstd, A.ln_g, A.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s));
+  KCHK(bias_grad(h, dsub, d, M, d, h->gf(A.o_b), s));
+  KCHK(run_gemm(lin_wgrad(dsub, d, o, d, h->gf(A.o_w), M, d, d, 0.f), s));
+  KmbGemm g = lin_dgrad(dsub, d, h->wb(A.o_w), M, d, d);
+  g.out_bf16 = h->dob; g.ld_out_bf16 = d;
+  KCHK(run_gemm(g, s));
+  AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
+  KCHK(attn_backward(h, io, B, H, o, lse, h->dob, h->dqkv, 3 * d, h->dqkv + d, h->dqkv + 2 * d, 3 * d, s));
+  KCHK(bias_grad(h, h->dqkv, 3 * d, M, 3 * d, h->gf(A.qkv_b), s));
+  KCHK(run_gemm(lin_wgrad(h->dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
+  g = lin_dgrad(h->dqkv, 3 * d, h->wb(A.qkv_w), M, 3 * d, d);
+  g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
+  KCHK(run_gemm(g, s));
+  return 0;
+}
+
+int encoder_forward(kmb_handle* h, const kmb_batch& bt, bool train, hipStream_t s) {
+  const int d = h->d, B = bt.B, S = bt.S, Me = B * S;
+  const float eps = h->cfg.layer_norm_eps;
+  const float scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f;
+  if (bt.n_features > 0) {
+    HIPCHK(kmb_cast_pad_launch(bt.image_features, bt.n_features, h->Fin, h->xf, h->Fpad, s));
+    KmbGemm g = lin_fwd(h->xf, h->Fpad, h->imgw_pad, h->pf(h->img_b), bt.n_features, d, h->Fpad);
+    g.out_f32 = h->img_emb; g.ld_out_f32 = d;
+    KCHK(run_gemm(g, s));
+  }
+  HIPCHK(kmb_img_rowmap_launch(bt.input_ids, bt.feat_offsets, B, S, h->cfg.img_feat_id, h->cfg.cls_token_id,
+                               h->img_src, h->status, s));
+  HIPCHK(kmb_embed_ln_fwd_launch(bt.input_ids, h->img_src, h->pf(h->shared), h->img_emb, h->pf(h->enc_pos),
+                                 h->cfg.extra_pos_embeddings, S, scale, h->pf(h->enc_lne_g), h->pf(h->enc_lne_b),
+                                 h->ze0, h->xe[0], h->me0, h->re0, Me, d, eps, h->drop_site(1, train), s));
+  for (int l = 0; l < h->cfg.encoder_layers; ++l) {
+    const LayerP& L = h->enc[l];
+    EncAct& a = h->ea[l];
+    KCHK(self_attn_forward(h, L.sa, h->He, h->xe[l], a.qkv, a.o, a.lse, a.z1, a.m1, a.r1, a.y1, B, S,
+                           bt.attention_mask, 0, h->drop_site(10 + 2 * l, train), s));
+    KCHK(ffn_forward(h, L, h->Fe, a.y1, a.u, a.hh, a.z2, a.m2, a.r2, h->xe[l + 1], Me, h->drop_site(11 + 2 * l, train), s));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+int kmb_set_error(const char* msg) { g_err = msg ? msg : ""; return 1; }
+
+extern "C" {
+
+const char* kmb_last_error(void) { return g_err.c_str(); }
+int kmb_version(void) { return 1; }
+
+int kmb_create(const kmb_config* cfg, kmb_handle** out) {
+  if (!cfg || !out) return fail("kmb_create: null argument");
+  if (cfg->d_model != cfg->encoder_attention_heads * 64 || cfg->d_model != cfg->decoder_attention_heads * 64)
+    return fail("kmb_create: head_dim must be 64 (d_model=%d heads=%d/%d)", cfg->d_model, cfg->encoder_attention_heads,
+                cfg->decoder_attention_heads);
+  if (cfg->d_model > 2048) return fail("kmb_create: d_model > 2048 is not supported");
+  if ((cfg->encoder_ffn_dim & 63) || (cfg->decoder_ffn_dim & 63)) return fail("kmb_create: ffn dims must be multiples of 64");
+  if (cfg->attention_dropout != 0.f || cfg->activation_dropout != 0.f)
+    return fail("kmb_create: attention_dropout / activation_dropout != 0 are not implemented (vcg_base uses 0.0)");
+  kmb_handle* h = new kmb_handle();
+  h->cfg = *cfg;
+  if (h->cfg.layer_norm_eps <= 0.f) h->cfg.layer_norm_eps = 1e-5f;
+  h->d = cfg->d_model; h->He = cfg->encoder_attention_heads; h->Hd = cfg->decoder_attention_heads;
+  h->Fe = cfg->encoder_ffn_dim; h->Fd = cfg->decoder_ffn_dim; h->V = cfg->vocab_size;
+  h->Vpad = (int)align_up((size_t)cfg->vocab_size, 128);
+  h->Fin = cfg->image_feature_size; h->Fpad = (int)align_up((size_t)cfg->image_feature_size, 8);
+  h->Prows = cfg->max_position_embeddings + cfg->extra_pos_embeddings;
+  const int d = h->d;
+  h->img_w = add_param(h, "model.encoder.embed_images.linear.weight", d, h->Fin);
+  h->img_b = add_param(h, "model.encoder.embed_images.linear.bias", 1, d);
+  h->enc_pos = add_param(h, "model.encoder.embed_positions.weight", h->Prows, d);
+  h->enc_lne_g = add_param(h, "model.encoder.layernorm_embedding.weight", 1, d);
+  h->enc_lne_b = add_param(h, "model.encoder.layernorm_embedding.bias", 1, d);
+  std::vector<size_t> marks;  // bucket boundaries in arena order
+  h->enc.resize(cfg->encoder_layers);
+  for (int l = 0; l < cfg->encoder_layers; ++l) {
+    marks.push_back(align_up(h->arena, 64));
+    const std::string p = "model.encoder.layers." + std::to_string(l) + ".";
+    add_attn(h, p + "self_attn.", p + "self_attn_layer_norm", h->enc[l].sa);
+    add_ffn(h, p, h->Fe, h->enc[l]);
+  }
+  marks.push_back(align_up(h->arena, 64));
+  h->dec_pos = add_param(h, "model.decoder.embed_positions.weight", h->Prows, d);
+  h->dec_lne_g = add_param(h, "model.decoder.layernorm_embedding.weight", 1, d);
+  h->dec_lne_b = add_param(h, "model.decoder.layernorm_embedding.bias", 1, d);
+  h->dec.resize(cfg->decoder_layers);
+  for (int l = 0; l < cfg->decoder_layers; ++l) {
+    marks.push_back(align_up(h->arena, 64));
+    const std::string p = "model.decoder.layers." + std::to_string(l) + ".";
+    add_attn(h, p + "self_attn.", p + "self_attn_layer_norm", h->dec[l].sa);
+    add_attn(h, p + "encoder_attn.", p + "encoder_attn_layer_norm", h->dec[l].ca);
+    add_ffn(h, p, h->Fd, h->dec[l]);
+  }
+  marks.push_back(align_up(h->arena, 64));
+  h->shared = add_param(h, "model.shared.weight", h->V, d);
+  h->arena = align_up(h->arena, 64);
+  // arena segments: [0,m0) enc embed+img | enc layers | dec embed | dec layers | shared
+  // completion order in backward: dec layers (last..first), dec embed, enc layers (last..first), enc embed, shared
+  const int Le = cfg->encoder_layers, Ld = cfg->decoder_layers;
+  auto seg = [&](size_t a, size_t b) { h->buckets.push_back({a, b - a}); };
+  for (int l = Ld - 1; l >= 0; --l) seg(marks[Le + 1 + l], marks[Le + 2 + l]);
+  seg(marks[Le], marks[Le + 1]);
+  for (int l = Le - 1; l >= 0; --l) seg(marks[l], marks[l + 1]);
+  seg(0, marks[0]);
+  seg(h->shared, h->arena);
+  h->events.resize(h->buckets.size());
+  for (auto& e : h->events) {
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      // no device (CPU build container): events are created lazily in kmb_backward instead
+      e = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  const char* ch = getenv("KMB_LM_CHUNK");
+  if (ch && atoi(ch) > 0) h->lm_chunk = atoi(ch);
+  *out = h;
+  return 0;
+}
+
+void kmb_destroy(kmb_handle* h) {
+  if (!h) return;
+  for (auto e : h->events) if (e) (void)hipEventDestroy(e);
+  delete h;
+}
+
+int kmb_param_count(const kmb_handle* h) { return (int)h->params.size(); }
+int kmb_param_info(const kmb_handle* h, int idx, const char** name, int64_t* offset, int32_t* rows, int32_t* cols) {
+  if (idx < 0 || idx >= (int)h->params.size()) return fail("kmb_param_info: index %d out of range", idx);
+  const ParamInfo& p = h->params[idx];
+  if (name) *name = p.name.c_str();
+  if (offset) *offset = (int64_t)p.off;
+  if (rows) *rows = p.rows;
+  if (cols) *cols = p.cols;
+  return 0;
+}
+int64_t kmb_arena_elems(const kmb_handle* h) { return (int64_t)h->arena; }
+int64_t kmb_bf16_arena_elems(const kmb_handle* h) {
+  // mirror + zero rows padding the tied matrix to Vpad + padded image weight [d, Fpad]
+  return (int64_t)(h->shared + (size_t)h->Vpad * h->d + (size_t)h->d * h->Fpad + 64);
+}
+int kmb_logits_ld(const kmb_handle* h) { return h->Vpad; }
+
+int kmb_bind_arenas(kmb_handle* h, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                    kmb_bf16* params_bf16, float* final_logits_bias) {
+  if (!params || !params_bf16 || !final_logits_bias) return fail("kmb_bind_arenas: params, bf16 mirror and final_logits_bias are required");
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)params_bf16) & 255)
+    return fail("kmb_bind_arenas: arenas must be 256-byte aligned");
+  h->P = params; h->G = grads; h->M1 = exp_avg; h->M2 = exp_avg_sq; h->PB = params_bf16; h->flb = final_logits_bias;
+  h->imgw_pad = h->PB + align_up(h->shared + (size_t)h->Vpad * h->d, 64);
+  return 0;
+}
+
+int64_t kmb_workspace_bytes(const kmb_handle* h, int B, int S, int T, int n_features) {
+  return (int64_t)layout_train(const_cast<kmb_handle*>(h), nullptr, 0, B, S, T, n_features, false);
+}
+int kmb_bind_workspace(kmb_handle* h, void* ws, int64_t bytes) {
+  if (((uintptr_t)ws) & 255) return fail("kmb_bind_workspace: workspace must be 256-byte aligned");
+  h->ws = (char*)ws; h->ws_bytes = (size_t)bytes; h->have_fwd = false; h->gen.active = false;
+  return 0;
+}
+
+int kmb_set_seed(kmb_handle* h, uint64_t seed) { h->seed = seed; h->step = 0; return 0; }
+
+int kmb_sync_params(kmb_handle* h, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->P || !h->PB) return fail("kmb_sync_params: arenas are not bound");
+  HIPCHK(kmb_cast_f32_bf16_launch(h->P, h->PB, h->arena, s));
+  // zero rows [V, Vpad) of the tied matrix mirror; padded image weight [d, Fpad]
+  HIPCHK(hipMemsetAsync(h->PB + h->shared + (size_t)h->V * h->d, 0, (size_t)(h->Vpad - h->V) * h->d * sizeof(bf16_t), s));
+  HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, s));
+  return 0;
+}
+
+int kmb_bucket_count(const kmb_handle* h) { return (int)h->buckets.size(); }
+int kmb_bucket_range(const kmb_handle* h, int i, int64_t* offset, int64_t* count) {
+  if (i < 0 || i >= (int)h->buckets.size()) return fail("kmb_bucket_range: index out of range");
+  *offset = (int64_t)h->buckets[i].off; *count = (int64_t)h->buckets[i].count;
+  return 0;
+}
+int kmb_stream_wait_bucket(kmb_handle* h, int i, void* stream) {
+  if (i < 0 || i >= (int)h->events.size() || !h->events[i]) return fail("kmb_stream_wait_bucket: no event %d", i);
+  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->events[i], 0));
+  return 0;
+}
+
+int kmb_read_status(kmb_handle* h, int32_t* status_host, void* stream) {
+  if (!h->status) return fail("kmb_read_status: no forward has run");
+  HIPCHK(hipMemcpyAsync(status_host, h->status, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+// --------------------------------------------------------------------------------- forward
+int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad, float* loss_out, float* logits_out,
+                kmb_bf16* enc_out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  KCHK(check_bound(h));
+  if (!batch || !batch->input_ids || !batch->decoder_input_ids || !batch->feat_offsets)
+    return fail("kmb_forward: input_ids, decoder_input_ids and feat_offsets are required");
+  const kmb_batch& bt = *batch;
+  if (bt.B <= 0 || bt.S <= 0 || bt.T <= 0) return fail("kmb_forward: empty batch");
+  if (bt.S > h->cfg.max_position_embeddings || bt.T > h->cfg.max_position_embeddings)
+    return fail("kmb_forward: sequence longer than max_position_embeddings");
+  if (need_grad && !bt.labels) return fail("kmb_forward: need_grad requires labels");
+  if (need_grad && (!h->G)) return fail("kmb_forward: gradient arena is not bound");
+  const size_t need = layout_train(h, nullptr, 0, bt.B, bt.S, bt.T, bt.n_features, false);
+  if (need > h->ws_bytes) return fail("kmb_forward: workspace too small (%zu > %zu bytes)", need, h->ws_bytes);
+  layout_train(h, h->ws, h->ws_bytes, bt.B, bt.S, bt.T, bt.n_features, true);
+  h->gen.active = false;
+  const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = B * S, Md = B * T;
+  h->bt = bt; h->Me = Me; h->Md = Md; h->Ntot = bt.n_features;
+  h->fwd_train = train != 0; h->have_fwd = false;
+  if (train) h->step += 1;
+  const bool tr = train != 0;
+  const float eps = h->cfg.layer_norm_eps;
+  const float scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f;
+  HIPCHK(hipMemsetAsync(h->status, 0, 16, s));
+
+  KCHK(encoder_forward(h, bt, tr, s));
+  const bf16_t* enc = h->xe[h->cfg.encoder_layers];
+  if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, enc, (size_t)Me * d * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
+
+  // ---- decoder (teacher forced): HF3.0.2 BartDecoder.forward via src/model/model.py:87-97
+  HIPCHK(kmb_embed_ln_fwd_launch(bt.decoder_input_ids, nullptr, h->pf(h->shared), nullptr, h->pf(h->dec_pos),
+                                 h->cfg.extra_pos_embeddings, T, scale, h->pf(h->dec_lne_g), h->pf(h->dec_lne_b),
+                                 h->zd0, h->xd[0], h->md0, h->rd0, Md, d, eps, h->drop_site(2, tr), s));
+  for (int l = 0; l < h->cfg.decoder_layers; ++l) {
+    const LayerP& L = h->dec[l];
+    DecAct& a = h->da[l];
+    KCHK(self_attn_forward(h, L.sa, h->Hd, h->xd[l], a.qkv, a.o1, a.lse1, a.z1, a.m1, a.r1, a.y1, B, T,
+                           bt.decoder_attention_mask, 1, h->drop_site(100 + 3 * l, tr), s));
+    // cross attention: q from decoder states (scaled), k|v from the encoder output
+    KmbGemm g = lin_fwd(a.y1, d, h->wb(L.ca.qkv_w), h->pf(L.ca.qkv_b), Md, d, d);
+    g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = a.cq; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    g = lin_fwd(enc, d, h->wb(L.ca.qkv_w) + (size_t)d * d, h->pf(L.ca.qkv_b) + d, Me, 2 * d, d);
+    g.out_bf16 = a.ckv; g.ld_out_bf16 = 2 * d;
+    KCHK(run_gemm(g, s));
+    AttnIO io{a.cq, d, a.ckv, a.ckv + d, 2 * d, T, S, bt.attention_mask, 0};
+    KCHK(attn_forward(h, io, B, h->Hd, a.o2, a.lse2, s));
+    const KmbDrop dr = h->drop_site(101 + 3 * l, tr);
+    g = lin_fwd(a.o2, d, h->wb(L.ca.o_w), h->pf(L.ca.o_b), Md, d, d);
+    g.drop_thr16 = dr.thr16; g.drop_seed = dr.seed; g.drop_scale = dr.scale;
+    g.residual = a.y1; g.ld_res = d; g.out_bf16 = a.z2; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    HIPCHK(kmb_ln_fwd_launch(a.z2, h->pf(L.ca.ln_g), h->pf(L.ca.ln_b), a.y2, a.m2, a.r2, Md, d, eps, s));
+    KCHK(ffn_forward(h, L, h->Fd, a.y2, a.u, a.hh, a.z3, a.m3, a.r3, h->xd[l + 1], Md, h->drop_site(102 + 3 * l, tr), s));
+  }
+  const bf16_t* hdec = h->xd[h->cfg.decoder_layers];
+
+  // ---- tied LM head + CE (src/model/model.py:397-403), row-chunked so that the fp32 logits of a
+  // chunk stay on-die; with need_grad the head's dgrad / wgrad run right behind each chunk.
+  if (bt.labels) HIPCHK(kmb_count_valid_launch(bt.labels, Md, h->count, s));
+  if (bt.labels || logits_out) {
+    const int CH = Md < h->lm_chunk ? Md : h->lm_chunk;
+    const bf16_t* Eb = h->wb(h->shared);
+    for (int r0 = 0, c = 0; r0 < Md; r0 += CH, ++c) {
+      const int rows = (Md - r0) < CH ? (Md - r0) : CH;
+      float* lg = logits_out ? logits_out + (size_t)r0 * h->Vpad : h->logits_c;
+      KmbGemm g = lin_fwd(hdec + (size_t)r0 * d, d, Eb, h->flb, rows, h->V, d);
+      g.out_f32 = lg; g.ld_out_f32 = h->Vpad;
+      KCHK(run_gemm(g, s));
+      if (!bt.labels) continue;
+      HIPCHK(kmb_ce_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, 1.f, h->loss_rows + r0,
+                           need_grad ? h->dlogits_c : nullptr, s));
+      if (need_grad) {
+        // dH = dlogits E  (reduction over the padded vocabulary; pad columns / rows are zero)
+        KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, rows, h->Vpad, d);
+        gd.out_bf16 = h->dhdec + (size_t)r0 * d; gd.ld_out_bf16 = d;
+        KCHK(run_gemm(gd, s));
+        // dE[V,d] (+)= dlogits^T H
+        KCHK(run_gemm(lin_wgrad(h->dlogits_c, h->Vpad, hdec + (size_t)r0 * d, d, h->gf(h->shared), rows, h->V, d,
+                                c == 0 ? 0.f : 1.f), s));
+      }
+    }
+    if (bt.labels) {
+      HIPCHK(kmb_loss_finish_launch(h->loss_rows, Md, h->count, h->loss_dev, s));
+      if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  h->have_fwd = need_grad != 0;
+  return 0;
+}
+
+// --------------------------------------------------------------------------------- backward
+int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  KCHK(check_bound(h));
+  if (!h->have_fwd) return fail("kmb_backward: no forward with need_grad=1 to differentiate");
+  h->have_fwd = false;
+  const kmb_batch& bt = h->bt;
+  const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = h->Me, Md = h->Md;
+  const bool tr = h->fwd_train;
+  const float scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f;
+  const int Le = h->cfg.encoder_layers, Ld = h->cfg.decoder_layers;
+  for (auto& e : h->events)
+    if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  int ev = 0;
+  if (loss_scale != 1.f) {
+    HIPCHK(kmb_scale_bf16_launch(h->dhdec, (size_t)Md * d, loss_scale, s));
+    HIPCHK(kmb_scale_f32_launch(h->gf(h->shared), (size_t)h->V * d, loss_scale, s));
+  }
+  const bf16_t* enc = h->xe[Le];
+  const bf16_t* dy = h->dhdec;
+  bf16_t* pp[2] = {h->dyA, h->dyB};
+  int cur = 0;
+  bool denc_init = false;
+  // ---- decoder layers
+  for (int l = Ld - 1; l >= 0; --l) {
+    const LayerP& L = h->dec[l];
+    DecAct& a = h->da[l];
+    bf16_t* t0 = pp[cur]; bf16_t* t1 = pp[cur ^ 1];
+    KCHK(ffn_backward(h, L, h->Fd, a.y2, a.u, a.hh, a.z3, a.m3, a.r3, dy, t0, Md, h->drop_site(102 + 3 * l, tr), s));
+    {  // cross-attention block: y2 = LN(z2), z2 = y1 + drop(out_proj(attn(cq, ckv)))
+      const KmbDrop dr = h->drop_site(101 + 3 * l, tr);
+      bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
+      KCHK(ln_backward(h, t0, a.z2, a.m2, a.r2, L.ca.ln_g, L.ca.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr,
+                       KmbDrop{0u, 0u, 1.f}, dr, Md, s));
+      KCHK(bias_grad(h, dsub, d, Md, d, h->gf(L.ca.o_b), s));
+      KCHK(run_gemm(lin_wgrad(dsub, d, a.o2, d, h->gf(L.ca.o_w), Md, d, d, 0.f), s));
+      KmbGemm g = lin_dgrad(dsub, d, h->wb(L.ca.o_w), Md, d, d);
+      g.out_bf16 = h->dob; g.ld_out_bf16 = d;
+      KCHK(run_gemm(g, s));
+      AttnIO io{a.cq, d, a.ckv, a.ckv + d, 2 * d, T, S, bt.attention_mask, 0};
+      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, h->dcq, d, h->dckv, h->dckv + d, 2 * d, s));
+      // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn
+      KCHK(bias_grad(h, h->dcq, d, Md, d, h->gf(L.ca.qkv_b), s));
+      KCHK(run_gemm(lin_wgrad(h->dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
+      g = lin_dgrad(h->dcq, d, h->wb(L.ca.qkv_w), Md, d, d);
+      g.residual = h->dz; g.ld_res = d; g.out_bf16 = t1; g.ld_out_bf16 = d;
+      KCHK(run_gemm(g, s));
+      KCHK(bias_grad(h, h->dckv, 2 * d, Me, 2 * d, h->gf(L.ca.qkv_b) + d, s));
+      KCHK(run_gemm(lin_wgrad(h->dckv, 2 * d, enc, d, h->gf(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d, 0.f), s));
+      g = lin_dgrad(h->dckv, 2 * d, h->wb(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d);
+      if (denc_init) { g.residual = h->denc; g.ld_res = d; }
+      g.out_bf16 = h->denc; g.ld_out_bf16 = d;
+      KCHK(run_gemm(g, s));
+      denc_init = true;
+    }
+    KCHK(self_attn_backward(h, L.sa, h->Hd, h->xd[l], a.qkv, a.o1, a.lse1, a.z1, a.m1, a.r1, t1, t0, B, T,
+                            bt.decoder_attention_mask, 1, h->drop_site(100 + 3 * l, tr), s));
+    dy = t0;  // t0 now holds d(loss)/d(xd[l]); keep it as the input of the next iteration
+    cur ^= 1;  // next iteration writes its first result into the other buffer
+    HIPCHK(hipEventRecord(h->events[ev++], s));
+  }
+  // ---- decoder embedding: xd[0] = drop(LN(zd0))
+  KCHK(ln_backward(h, dy, h->zd0, h->md0, h->rd0, h->dec_lne_g, h->dec_lne_b, h->dz, nullptr, h->drop_site(2, tr),
+                   KmbDrop{0u, 0u, 1.f}, Md, s));
+  HIPCHK(kmb_embed_bwd_launch(h->dz, bt.decoder_input_ids, nullptr, scale, h->gf(h->shared), nullptr,
+                              h->cfg.pad_token_id, Md, d, s));
+  HIPCHK(kmb_pos_bwd_launch(h->dz, B, T, d, h->gf(h->dec_pos), h->cfg.extra_pos_embeddings, h->Prows, s));
+  HIPCHK(hipEventRecord(h->events[ev++], s));
+  // ---- encoder layers
+  if (!denc_init) HIPCHK(hipMemsetAsync(h->denc, 0, (size_t)Me * d * sizeof(bf16_t), s));
+  dy = h->denc;
+  cur = 0;
+  for (int l = Le - 1; l >= 0; --l) {
+    const LayerP& L = h->enc[l];
+    EncAct& a = h->ea[l];
+    bf16_t* t0 = pp[cur]; bf16_t* t1 = pp[cur ^ 1];
+    KCHK(ffn_backward(h, L, h->Fe, a.y1, a.u, a.hh, a.z2, a.m2, a.r2, dy, t0, Me, h->drop_site(11 + 2 * l, tr), s));
+    KCHK(self_attn_backward(h, L.sa, h->He, h->xe[l], a.qkv, a.o, a.lse, a.z1, a.m1, a.r1, t0, t1, B, S,
+                            bt.attention_mask, 0, h->drop_site(10 + 2 * l, tr), s));
+    dy = t1;  // t0 / t1 keep their roles: the next ffn_backward reads t1 and writes t0
+    HIPCHK(hipEventRecord(h->events[ev++], s));
+  }
+  // ---- encoder embedding (+ image projection, src/model/modules.py:24-41)
+  KCHK(ln_backward(h, dy, h->ze0, h->me0, h->re0, h->enc_lne_g, h->enc_lne_b, h->dz, nullptr, h->drop_site(1, tr),
+                   KmbDrop{0u, 0u, 1.f}, Me, s));
+  HIPCHK(kmb_embed_bwd_launch(h->dz, bt.input_ids, h->img_src, scale, h->gf(h->shared), h->dimg, h->cfg.pad_token_id,
+                              Me, d, s));
+  HIPCHK(kmb_pos_bwd_launch(h->dz, B, S, d, h->gf(h->enc_pos), h->cfg.extra_pos_embeddings, h->Prows, s));
+  if (h->Ntot > 0) {
+    KCHK(bias_grad(h, h->dimg, d, h->Ntot, d, h->gf(h->img_b), s));
+    KCHK(run_gemm(lin_wgrad(h->dimg, d, h->xf, h->Fpad, h->gf(h->img_w), h->Ntot, d, h->Fin, 0.f), s));
+  } else {
+    HIPCHK(hipMemsetAsync(h->gf(h->img_w), 0, ((size_t)d * h->Fin) * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(h->gf(h->img_b), 0, (size_t)d * sizeof(float), s));
+  }
+  HIPCHK(hipEventRecord(h->events[ev++], s));
+  HIPCHK(hipEventRecord(h->events[ev++], s));  // tied matrix: complete once the encoder-side scatter-add is in
+  return 0;
+}
+
+int kmb_adamw_step(kmb_handle* h, const KmbAdamW* hp, int64_t offset, int64_t count, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->P || !h->G || !h->M1 || !h->M2) return fail("kmb_adamw_step: arenas are not bound");
+  if (offset < 0 || count < 0 || (size_t)(offset + count) > h->arena) return fail("kmb_adamw_step: range out of the arena");
+  if (offset & 7) return fail("kmb_adamw_step: offset must be a multiple of 8 elements");
+  HIPCHK(kmb_adamw_launch(h->P + offset, h->G + offset, h->M1 + offset, h->M2 + offset, h->PB + offset, (size_t)count, *hp, s));
+  // the padded image-weight mirror lives outside the flat mirror
+  const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
+  if ((size_t)offset < iw1 && (size_t)(offset + count) > iw0)
+    HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, s));
+  return 0;
+}
+
+}  // extern "C"
+
+// ================================================================================= generation
+namespace {
+
+struct GenLayout {
+  int32_t* status; bf16_t* xf; float* img_emb; int32_t* img_src; bf16_t* xe[2]; EncAct ea;
+  std::vector<bf16_t*> ckv, kc[2], vc[2];
+  int32_t* kv_row; bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd;
+};
+
+size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int nb, int Tmax, int Ntot, GenLayout* out) {
+  const int d = h->d, Fe = h->Fe, Fd = h->Fd, Ld = h->cfg.decoder_layers;
+  const size_t Me = (size_t)B * S, R = (size_t)B * nb;
+  Bump bp(base, cap);
+  GenLayout g;
+  g.status = bp.take<int32_t>(4);
+  g.xf = bp.take<bf16_t>((size_t)(Ntot > 0 ? Ntot : 1) * h->Fpad);
+  g.img_emb = bp.take<float>((size_t)(Ntot > 0 ? Ntot : 1) * d);
+  g.img_src = bp.take<int32_t>(Me);
+  g.xe[0] = bp.take<bf16_t>(Me * d); g.xe[1] = bp.take<bf16_t>(Me * d);
+  EncAct& a = g.ea;
+  a.qkv = bp.take<bf16_t>(Me * 3 * d); a.o = bp.take<bf16_t>(Me * d); a.z1 = bp.take<bf16_t>(Me * d);
+  a.y1 = bp.take<bf16_t>(Me * d); a.u = bp.take<bf16_t>(Me * Fe); a.hh = bp.take<bf16_t>(Me * Fe);
+  a.z2 = bp.take<bf16_t>(Me * d); a.lse = bp.take<float>((size_t)B * h->He * S);
+  a.m1 = bp.take<float>(Me); a.r1 = bp.take<float>(Me); a.m2 = bp.take<float>(Me); a.r2 = bp.take<float>(Me);
+  g.ckv.resize(Ld);
+  for (int i = 0; i < 2; ++i) { g.kc[i].resize(Ld); g.vc[i].resize(Ld); }
+  for (int l = 0; l < Ld; ++l) {
+    g.ckv[l] = bp.take<bf16_t>(Me * 2 * d);
+    for (int i = 0; i < 2; ++i) { g.kc[i][l] = bp.take<bf16_t>(R * Tmax * d); g.vc[i][l] = bp.take<bf16_t>(R * Tmax * d); }
+  }
+  g.kv_row = bp.take<int32_t>(R);
+  g.x0 = bp.take<bf16_t>(R * d); g.x1 = bp.take<bf16_t>(R * d); g.qkv = bp.take<bf16_t>(R * 3 * d);
+  g.o = bp.take<bf16_t>(R * d); g.z = bp.take<bf16_t>(R * d); g.y = bp.take<bf16_t>(R * d); g.cq = bp.take<bf16_t>(R * d);
+  g.u = bp.take<bf16_t>(R * Fd); g.hh = bp.take<bf16_t>(R * Fd);
+  g.mean = bp.take<float>(R); g.rstd = bp.take<float>(R);
+  if (out) *out = g;
+  return bp.used();
+}
+
+std::vector<int32_t> g_kvrow_host;  // staging for the beam -> batch-item table
+
+}  // namespace
+
+extern "C" {
+
+int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features) {
+  return (int64_t)layout_gen(h, nullptr, 0, B, S, num_beams, max_length, n_features, nullptr);
+}
+
+int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_length, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  KCHK(check_bound(h));
+  if (!batch || !batch->input_ids || !batch->feat_offsets) return fail("kmb_gen_begin: input_ids and feat_offsets are required");
+  if (num_beams < 1 || max_length < 2) return fail("kmb_gen_begin: bad num_beams / max_length");
+  if (max_length > h->cfg.max_position_embeddings) return fail("kmb_gen_begin: max_length exceeds max_position_embeddings");
+  const kmb_batch& bt = *batch;
+  const int d = h->d, B = bt.B, S = bt.S, Me = B * S;
+  GenLayout g;
+  const size_t need = layout_gen(h, h->ws, h->ws_bytes, B, S, num_beams, max_length, bt.n_features, &g);
+  if (need > h->ws_bytes) return fail("kmb_gen_begin: workspace too small (%zu > %zu bytes)", need, h->ws_bytes);
+  h->have_fwd = false;
+  // point the encoder sub-graph at the (layer-shared) generation buffers
+  const int Le = h->cfg.encoder_layers, Ld = h->cfg.decoder_layers;
+  h->status = g.status; h->xf = g.xf; h->img_emb = g.img_emb; h->img_src = g.img_src;
+  h->ze0 = nullptr; h->me0 = nullptr; h->re0 = nullptr;
+  h->xe.assign(Le + 1, nullptr);
+  for (int l = 0; l <= Le; ++l) h->xe[l] = g.xe[l & 1];
+  h->ea.assign(Le, g.ea);
+  HIPCHK(hipMemsetAsync(h->status, 0, 16, s));
+  KCHK(encoder_forward(h, bt, false, s));
+  const bf16_t* enc = h->xe[Le];
+  auto& G = h->gen;
+  G.active = true; G.B = B; G.S = S; G.nb = num_beams; G.R = B * num_beams; G.Tmax = max_length; G.bt = bt; G.cur = 0;
+  G.ckv = g.ckv; G.kc[0] = g.kc[0]; G.kc[1] = g.kc[1]; G.vc[0] = g.vc[0]; G.vc[1] = g.vc[1];
+  G.kv_row = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
+  G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd;
+  // cross-attention K|V of every decoder layer, computed once per batch item (not per beam)
+  for (int l = 0; l < Ld; ++l) {
+    const LayerP& L = h->dec[l];
+    KmbGemm gm = lin_fwd(enc, d, h->wb(L.ca.qkv_w) + (size_t)d * d, h->pf(L.ca.qkv_b) + d, Me, 2 * d, d);
+    gm.out_bf16 = G.ckv[l]; gm.ld_out_bf16 = 2 * d;
+    KCHK(run_gemm(gm, s));
+  }
+  g_kvrow_host.resize(G.R);
+  for (int i = 0; i < G.R; ++i) g_kvrow_host[i] = i / num_beams;
+  HIPCHK(hipMemcpyAsync(G.kv_row, g_kvrow_host.data(), (size_t)G.R * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // the staging vector may be reused by the next call
+  return 0;
+}
+
+int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  auto& G = h->gen;
+  if (!G.active) return fail("kmb_gen_step: call kmb_gen_begin first");
+  if (step < 0 || step >= G.Tmax) return fail("kmb_gen_step: step %d outside the cache (Tmax=%d)", step, G.Tmax);
+  const int d = h->d, R = G.R, F = h->Fd;
+  const float eps = h->cfg.layer_norm_eps;
+  const float scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f;
+  const KmbDrop nodrop{0u, 0u, 1.f};
+  // BartDecoder with use_cache: only the last token, learned position (len-1) + 2
+  HIPCHK(kmb_embed_ln_fwd_launch(tokens, nullptr, h->pf(h->shared), nullptr, h->pf(h->dec_pos),
+                                 h->cfg.extra_pos_embeddings + step, 1, scale, h->pf(h->dec_lne_g),
+                                 h->pf(h->dec_lne_b), nullptr, G.x0, nullptr, nullptr, R, d, eps, nodrop, s));
+  bf16_t* x = G.x0; bf16_t* xn = G.x1;
+  for (int l = 0; l < h->cfg.decoder_layers; ++l) {
+    const LayerP& L = h->dec[l];
+    KmbGemm g = lin_fwd(x, d, h->wb(L.sa.qkv_w), h->pf(L.sa.qkv_b), R, 3 * d, d);
+    g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = G.qkv; g.ld_out_bf16 = 3 * d;
+    KCHK(run_gemm(g, s));
+    HIPCHK(kmb_kv_append_launch(G.qkv + d, 3 * d, G.kc[G.cur][l], G.Tmax, d, step, R, s));
+    HIPCHK(kmb_kv_append_launch(G.qkv + 2 * d, 3 * d, G.vc[G.cur][l], G.Tmax, d, step, R, s));
+    KmbAttnDecode a; memset(&a, 0, sizeof(a));
+    a.Q = G.qkv; a.ldq = 3 * d; a.Kc = G.kc[G.cur][l]; a.Vc = G.vc[G.cur][l]; a.Tmax = G.Tmax; a.ldc = d;
+    a.R = R; a.H = h->Hd; a.Tk = step + 1; a.O = G.o; a.ldo = d;
+    HIPCHK(kmb_attn_decode_launch(a, s));
+    g = lin_fwd(G.o, d, h->wb(L.sa.o_w), h->pf(L.sa.o_b), R, d, d);
+    g.residual = x; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(L.sa.ln_g), h->pf(L.sa.ln_b), G.y, G.mean, G.rstd, R, d, eps, s));
+    // cross attention over the cached encoder K|V of the row's batch item
+    g = lin_fwd(G.y, d, h->wb(L.ca.qkv_w), h->pf(L.ca.qkv_b), R, d, d);
+    g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = G.cq; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    memset(&a, 0, sizeof(a));
+    a.Q = G.cq; a.ldq = d; a.Kc = G.ckv[l]; a.Vc = G.ckv[l] + d; a.Tmax = G.S; a.ldc = 2 * d; a.kv_row = G.kv_row;
+    a.key_mask = G.bt.attention_mask; a.mask_ld = G.S; a.mask_row = G.kv_row;
+    a.R = R; a.H = h->Hd; a.Tk = G.S; a.O = G.o; a.ldo = d;
+    HIPCHK(kmb_attn_decode_launch(a, s));
+    g = lin_fwd(G.o, d, h->wb(L.ca.o_w), h->pf(L.ca.o_b), R, d, d);
+    g.residual = G.y; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(L.ca.ln_g), h->pf(L.ca.ln_b), G.y, G.mean, G.rstd, R, d, eps, s));
+    // FFN
+    g = lin_fwd(G.y, d, h->wb(L.fc1_w), h->pf(L.fc1_b), R, F, d);
+    g.act = 1; g.out_bf16 = G.hh; g.ld_out_bf16 = F;
+    KCHK(run_gemm(g, s));
+    g = lin_fwd(G.hh, F, h->wb(L.fc2_w), h->pf(L.fc2_b), R, d, F);
+    g.residual = G.y; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(L.ln_g), h->pf(L.ln_b), xn, G.mean, G.rstd, R, d, eps, s));
+    bf16_t* t = x; x = xn; xn = t;
+  }
+  if (logits_out) {
+    KmbGemm g = lin_fwd(x, d, h->wb(h->shared), h->flb, R, h->V, d);
+    g.out_f32 = logits_out; g.ld_out_f32 = h->Vpad;
+    KCHK(run_gemm(g, s));
+  }
+  return 0;
+}
+
+int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  auto& G = h->gen;
+  if (!G.active) return fail("kmb_gen_reorder: call kmb_gen_begin first");
+  const int d = h->d;
+  const int row_bytes = (step + 1) * d * (int)sizeof(bf16_t);
+  const size_t stride = (size_t)G.Tmax * d * sizeof(bf16_t);
+  for (int l = 0; l < h->cfg.decoder_layers; ++l) {
+    HIPCHK(kmb_gather_rows_launch(G.kc[G.cur][l], beam_idx, G.kc[G.cur ^ 1][l], G.R, row_bytes, stride, s));
+    HIPCHK(kmb_gather_rows_launch(G.vc[G.cur][l], beam_idx, G.vc[G.cur ^ 1][l], G.R, row_bytes, stride, s));
+  }
+  G.cur ^= 1;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues.
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// A is logical [M,K], B is logical [N,K] (a torch Linear weight is [out,in] = [N,K]).
+// Each operand is either K-contiguous ("KC": X[m*ld + k]) or M/N-contiguous (X[k*ld + m]).
+//   forward  Y  = X  W^T      : A=X  (KC)       B=W   (KC)
+//   dgrad    dX = dY W        : A=dY (KC)       B=W   (N-contig, i.e. W[k'=n][n'=k])
+//   wgrad    dW = dY^T X      : A=dY (M-contig) B=X   (N-contig), reduction over tokens
+// Tile: 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16.
+// LDS: two 32 KB stages (A tile + B tile), XOR-swizzled so the fragment reads are conflict-free:
+//   KC tile      [128][64]  : 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7)   (ds_read_b128)
+//   non-KC tile  [64][128]  : 32-B chunk c of k-row r stored at chunk c ^ f(r),
+//                             f(r) = (r&3) | ((r>>3)&1)<<2                           (ds_read_b64_tr_b16)
+// The epilogue round-trips the fp32 accumulators through LDS so that bias / GeLU / dropout /
+// residual math and the stores run row-major with 16-byte accesses.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;  // 32 KB
+constexpr int EPI_LD = BN + 4;                        // fp32 staging row stride
+constexpr int LDS_BYTES = (BM * EPI_LD * 4 > 2 * STAGE_BYTES) ? BM * EPI_LD * 4 : 2 * STAGE_BYTES;
+
+__device__ __forceinline__ int swz_nkc(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+// ---- global -> register staging of one 128x64 (KC) or 64x128 (non-KC) tile: 4 chunks / thread ----
+template <bool KC>
+__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ X, int ld, int r0, int R, int k0, int K,
+                                          int tid, u32x4 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 256 * i;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (KC) {
+      int row = r0 + (id >> 3);
+      const int k = k0 + (id & 7) * 8;
+      row = row < R ? row : R - 1;  // rows past the edge are never stored: clamp to stay in bounds
+      if (k < K) v = *reinterpret_cast<const u32x4*>(X + (size_t)row * ld + k);
+    } else {
+      const int k = k0 + (id >> 4);
+      int m = r0 + (id & 15) * 8;
+      const int mlast = ((R - 1) >> 3) << 3;
+      m = m < R ? m : mlast;
+      if (k < K) v = *reinterpret_cast<const u32x4*>(X + (size_t)k * ld + m);
+    }
+    regs[i] = v;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const u32x4 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 256 * i;
+    int off;
+    if (KC) {
+      const int row = id >> 3, c = id & 7;
+      off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+    } else {
+      const int krow = id >> 4, piece = id & 15;
+      off = krow * 256 + (((piece >> 1) ^ swz_nkc(krow)) << 5) + ((piece & 1) << 4);
+    }
+    *reinterpret_cast<u32x4*>(lds + off) = regs[i];
+  }
+}
+
+// fragment for MFMA 16x16x32: 16 rows (r = lane&15) x 32 k (8 per lane group g = lane>>4)
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int kk, int r, int g) {
+  if (KC) {
+    const int row = rowtile16 * 16 + r;
+    const int c = kk * 4 + g;
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  } else {
+    bf16x8 out;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int krow = kk * 32 + g * 8 + hh * 4 + (r >> 2);
+      const int off = krow * 256 + ((rowtile16 ^ swz_nkc(krow)) << 5) + ((r & 3) << 3);
+      const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(lds + off));
+      out[hh * 4 + 0] = t[0]; out[hh * 4 + 1] = t[1]; out[hh * 4 + 2] = t[2]; out[hh * 4 + 3] = t[3];
+    }
+    return out;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (p.K + BK - 1) / BK;
+  u32x4 ra[4], rb[4];
+  load_tile<A_KC>(p.A, p.lda, row0, p.M, 0, p.K, tid, ra);
+  load_tile<B_KC>(p.B, p.ldb, col0, p.N, 0, p.K, tid, rb);
+  store_tile<A_KC>(smem, tid, ra);
+  store_tile<B_KC>(smem + BM * BK * 2, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * STAGE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+    const bool more = (t + 1) < nt;
+    if (more) {
+      load_tile<A_KC>(p.A, p.lda, row0, p.M, (t + 1) * BK, p.K, tid, ra);
+      load_tile<B_KC>(p.B, p.ldb, col0, p.N, (t + 1) * BK, p.K, tid, rb);
+    }
+    const char* la = cur;
+    const char* lb = cur + BM * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(la, wm * 4 + i, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(lb, wn * 4 + j, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<A_KC>(nxt, tid, ra);
+      store_tile<B_KC>(nxt + BM * BK * 2, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue phase 1: accumulators -> LDS fp32 [128][EPI_LD] ----
+  float* ef = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        ef[(wm * 64 + i * 16 + g * 4 + q) * EPI_LD + wn * 64 + j * 16 + r] = acc[i][j][q];
+  __syncthreads();
+
+  // ---- phase 2: row-major math + 16-byte stores ----
+  const int c8 = (tid & 15) * 8;
+  const int gcol = col0 + c8;
+  if (gcol >= p.N) return;
+  const int nvalid = (p.N - gcol) < 8 ? (p.N - gcol) : 8;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = (p.bias != nullptr && e < nvalid) ? p.bias[gcol + e] : 0.f;
+
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int lrow = (tid >> 4) + 16 * it;
+    const int grow = row0 + lrow;
+    if (grow >= p.M) break;
+    float v[8];
+    {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8 + 4);
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] += bias8[e];
+      if (gcol + e < p.col_scale_n) v[e] *= p.col_scale;
+    }
+    if (p.act == 1) {
+      if (p.preact != nullptr) {
+        if (nvalid == 8) {
+          *reinterpret_cast<u32x4*>(p.preact + (size_t)grow * p.ld_preact + gcol) = pack8(v);
+        } else {
+          for (int e = 0; e < nvalid; ++e) p.preact[(size_t)grow * p.ld_preact + gcol + e] = f2bf(v[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    } else if (p.act == 2) {
+      float u[8];
+      if (nvalid == 8) {
+        unpack8(*reinterpret_cast<const u32x4*>(p.aux + (size_t)grow * p.ld_aux + gcol), u);
+      } else {
+        for (int e = 0; e < 8; ++e) u[e] = e < nvalid ? bf2f(p.aux[(size_t)grow * p.ld_aux + gcol + e]) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
+    }
+    if (p.drop_thr16 != 0u) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = drop_keep(p.drop_seed, (uint32_t)grow, (uint32_t)(gcol + e), p.drop_thr16) ? v[e] * p.drop_scale : 0.f;
+    }
+    if (p.residual != nullptr) {
+      float rr[8];
+      if (nvalid == 8) {
+        unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)grow * p.ld_res + gcol), rr);
+      } else {
+        for (int e = 0; e < 8; ++e) rr[e] = e < nvalid ? bf2f(p.residual[(size_t)grow * p.ld_res + gcol + e]) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rr[e];
+    }
+    if (p.out_bf16 != nullptr) {
+      if (nvalid == 8) {
+        *reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol) = pack8(v);
+      } else {
+        for (int e = 0; e < nvalid; ++e) p.out_bf16[(size_t)grow * p.ld_out_bf16 + gcol + e] = f2bf(v[e]);
+      }
+    }
+    if (p.out_f32 != nullptr) {
+      float* o = p.out_f32 + (size_t)grow * p.ld_out_f32 + gcol;
+      const bool vec = (nvalid == 8) && ((p.ld_out_f32 & 3) == 0);
+      if (p.beta != 0.f) {
+        for (int e = 0; e < nvalid; ++e) v[e] += p.beta * o[e];
+      }
+      if (vec) {
+        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+const char* kmb_gemm_check(const KmbGemm& p) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
+  if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return "gemm: operand not 16-byte aligned";
+  if ((p.lda & 7) || (p.ldb & 7)) return "gemm: leading dimension must be a multiple of 8";
+  if (p.a_kc && (p.K & 7)) return "gemm: K must be a multiple of 8 for a K-contiguous A";
+  if (p.b_kc && (p.K & 7)) return "gemm: K must be a multiple of 8 for a K-contiguous B";
+  if (!p.a_kc && (((p.M + 7) & ~7) > p.lda)) return "gemm: M-contiguous A needs lda >= roundup8(M)";
+  if (!p.b_kc && (((p.N + 7) & ~7) > p.ldb)) return "gemm: N-contiguous B needs ldb >= roundup8(N)";
+  if (p.out_bf16 && ((p.ld_out_bf16 & 7) || ((uintptr_t)p.out_bf16 & 15))) return "gemm: bf16 output alignment";
+  if (p.residual && ((p.ld_res & 7) || ((uintptr_t)p.residual & 15))) return "gemm: residual alignment";
+  if (p.aux && ((p.ld_aux & 7) || ((uintptr_t)p.aux & 15))) return "gemm: aux alignment";
+  if (p.preact && ((p.ld_preact & 7) || ((uintptr_t)p.preact & 15))) return "gemm: preact alignment";
+  if (p.out_f32 && ((uintptr_t)p.out_f32 & 15)) return "gemm: f32 output alignment";
+  if (p.act == 2 && !p.aux) return "gemm: gelu-backward epilogue needs aux";
+  if (!p.a_kc && p.b_kc) return "gemm: (M-contiguous A, K-contiguous B) is not instantiated";
+  return nullptr;
+}
+
+hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles), block(256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  if (p.a_kc && p.b_kc) {
+    hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
+  } else if (p.a_kc && !p.b_kc) {
+    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, LDS_BYTES, stream, p);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, LDS_BYTES, stream, p);
+  }
+  return hipGetLastError();
+}

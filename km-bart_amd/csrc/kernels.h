@@ -1,0 +1,94 @@
+// Internal launch API of the HIP kernels (host side).  Every launcher enqueues on `stream`
+// and returns hipGetLastError(); none of them allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/kmbart.h"
+
+typedef uint16_t bf16_t;
+
+// ------------------------------------------------------------------ gemm.hip
+const char* kmb_gemm_check(const KmbGemm& p);
+hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream);
+
+// ------------------------------------------------------------- attention.hip
+hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream);
+hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream);
+const char* kmb_attn_check(const KmbAttn& p, int backward);
+
+// single-query attention over a KV cache (generation): one query row per (row, head)
+hipError_t kmb_attn_decode_launch(const KmbAttnDecode& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- norm.hip
+
+// y = LN(z) * gamma + beta ; saves mean / rstd.  z, y bf16 [M, D]
+hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* beta, bf16_t* y,
+                             float* mean, float* rstd, int M, int D, float eps, hipStream_t stream);
+// dz = LN backward; partial dgamma/dbeta go to `partials` [nparts][2][D] (nparts returned by kmb_ln_bwd_parts)
+// dy_drop: dropout that was applied to the LN OUTPUT in forward (embedding LN), thr16 == 0 if none.
+// dz_drop: if out2 != null, out2 = dz * keep(out2 site) * scale (gradient of a dropped sub-layer output).
+int kmb_ln_bwd_parts(int M);
+hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd,
+                             const float* gamma, bf16_t* dz, bf16_t* out2, KmbDrop dy_drop, KmbDrop out2_drop,
+                             float* partials, int M, int D, hipStream_t stream);
+// out[c] = sum_p partials[p*stride + c]  for c < n   (overwrites)
+hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride, float* out, int n,
+                                   hipStream_t stream);
+// column sums of a bf16 matrix -> partials [nparts][N]; nparts = kmb_colsum_parts(M)
+int kmb_colsum_parts(int M);
+hipError_t kmb_colsum_launch(const bf16_t* X, int ld, int M, int N, float* partials, hipStream_t stream);
+
+// ---------------------------------------------------------------- embed.hip
+// img_src[b*S + s] = packed feature row feeding token (b,s), or -1.  status[0] |= 1 on a count mismatch.
+hipError_t kmb_img_rowmap_launch(const int64_t* ids, const int32_t* feat_off, int B, int S, int64_t img_feat_id,
+                                 int64_t cls_id, int32_t* img_src, int32_t* status, hipStream_t stream);
+// fp32 region features [N, Fin] -> bf16 [N, Fpad] (zero padded)
+hipError_t kmb_cast_pad_launch(const float* x, int N, int Fin, bf16_t* y, int Fpad, hipStream_t stream);
+// z = (img_src>=0 ? img_emb[img_src] : E[id]) * scale + P[pos_base + (row % S)] ; y = dropout(LN(z))
+hipError_t kmb_embed_ln_fwd_launch(const int64_t* ids, const int32_t* img_src, const float* E, const float* img_emb,
+                                   const float* P, int pos_base, int S, float scale, const float* gamma,
+                                   const float* beta, bf16_t* z, bf16_t* y, float* mean, float* rstd, int M, int D,
+                                   float eps, KmbDrop drop, hipStream_t stream);
+// token rows: dE[id] += dz*scale (atomic); image rows: dimg[img_src] = dz*scale (bf16, packed)
+// (token rows whose id == pad_id get no gradient: nn.Embedding(padding_idx))
+hipError_t kmb_embed_bwd_launch(const bf16_t* dz, const int64_t* ids, const int32_t* img_src, float scale,
+                                float* dE, bf16_t* dimg, int64_t pad_id, int M, int D, hipStream_t stream);
+// dP[pos_base + s] = sum_b dz[b*S + s]; every other row of dP[0:P_rows] is zeroed
+hipError_t kmb_pos_bwd_launch(const bf16_t* dz, int B, int S, int D, float* dP, int pos_base, int P_rows,
+                              hipStream_t stream);
+
+// ----------------------------------------------------------------- loss.hip
+// count[0] = number of labels != -100
+hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, hipStream_t stream);
+// per row: loss_rows[r] = lse - logit[label] (0 if ignored); dlogits (bf16, ld = ldv, pad columns zeroed)
+//          = (softmax - onehot) * grad_scale / count   (0 rows if ignored).  dlogits may be null.
+hipError_t kmb_ce_launch(const float* logits, int ldv, int V, const int64_t* labels, int rows,
+                         const int32_t* count, float grad_scale, float* loss_rows, bf16_t* dlogits,
+                         hipStream_t stream);
+// loss[0] = sum(loss_rows) / count
+hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
+                                  hipStream_t stream);
+// generation: per row log_softmax over V then top-k of (logp + add[row]); writes k (value, index) pairs
+hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
+                                      int force_token, int k, float* out_val, int32_t* out_idx,
+                                      hipStream_t stream);
+
+// ---------------------------------------------------------------- optim.hip
+// transformers-3.0.2 AdamW on a flat fp32 arena; also refreshes the bf16 mirror of the parameters
+hipError_t kmb_adamw_launch(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n,
+                            KmbAdamW h, hipStream_t stream);
+hipError_t kmb_cast_f32_bf16_launch(const float* x, bf16_t* y, size_t n, hipStream_t stream);
+hipError_t kmb_fill_f32_launch(float* x, float v, size_t n, hipStream_t stream);
+// y[r*ldy + c] = bf16(x[r*ldx + c]) for c < cols, zero for cols <= c < ldy
+hipError_t kmb_cast_rows_launch(const float* x, int ldx, bf16_t* y, int ldy, int rows, int cols, hipStream_t stream);
+// copy a KV projection [R, ld] slice into a cache [R, Tmax, HD] at position t
+hipError_t kmb_kv_append_launch(const bf16_t* src, int ld_src, bf16_t* cache, int Tmax, int HD, int t, int R,
+                                hipStream_t stream);
+// gather rows: dst[i] = src[idx[i]]  (16-byte chunks, row_bytes % 16 == 0; rows are `stride_bytes` apart)
+hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst, int rows, int row_bytes,
+                                  size_t stride_bytes, hipStream_t stream);
+
+// keep-mask dump of the dropout generator (tests)
+hipError_t kmb_dropout_mask_launch(uint32_t seed, uint32_t thr16, int rows, int cols, uint8_t* keep, hipStream_t stream);
+hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, hipStream_t stream);
+hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, hipStream_t stream);

@@ -1,0 +1,192 @@
+// Tied-vocabulary cross-entropy on fp32 logits (reference src/model/model.py:397-403:
+// CrossEntropyLoss(), mean over labels != -100) and the generation-side log_softmax + top-k.
+// One 256-thread block per logits row; the row (V = 50320 fp32 = 197 KB) is read twice and is
+// L2 / Infinity-Cache resident for the second pass.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+  const float mn = fmaxf(m, m2);
+  if (mn == -INFINITY) { m = mn; s = 0.f; return; }
+  s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+  m = mn;
+}
+
+// block-wide (max, sumexp) of row[0:V]; result broadcast to all threads
+__device__ __forceinline__ void row_lse(const float* __restrict__ row, int V, float* sh, float& m_out, float& s_out) {
+  const int tid = threadIdx.x;
+  float m = -INFINITY, s = 0.f;
+  const int V4 = V & ~3;
+  for (int i = tid * 4; i < V4; i += 1024) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(row + i);
+    const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+    if (mx > m) { s *= __expf(m - mx); m = mx; }
+    if (m != -INFINITY) s += __expf(x[0] - m) + __expf(x[1] - m) + __expf(x[2] - m) + __expf(x[3] - m);
+  }
+  for (int i = V4 + tid; i < V; i += 256) {
+    const float x = row[i];
+    if (x > m) { s *= __expf(m - x); m = x; }
+    if (m != -INFINITY) s += __expf(x - m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    online_merge(m, s, m2, s2);
+  }
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) { sh[wave * 2] = m; sh[wave * 2 + 1] = s; }
+  __syncthreads();
+  m = sh[0]; s = sh[1];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) online_merge(m, s, sh[w * 2], sh[w * 2 + 1]);
+  __syncthreads();
+  m_out = m; s_out = s;
+}
+
+__global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ labels, int n,
+                                                          int32_t* __restrict__ count) {
+  __shared__ int sh[4];
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) c += (labels[i] != -100) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) count[0] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, int ldv, int V,
+                                                 const int64_t* __restrict__ labels, const int32_t* __restrict__ count,
+                                                 float grad_scale, float* __restrict__ loss_rows,
+                                                 bf16_t* __restrict__ dlogits) {
+  __shared__ float sh[8];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (size_t)r * ldv;
+  const int64_t label = labels[r];
+  const bool valid = (label != -100);
+  float m = 0.f, s = 1.f;
+  if (valid) row_lse(row, V, sh, m, s);  // block-uniform branch
+  const float lse = m + __logf(s);
+  if (tid == 0) loss_rows[r] = valid ? (lse - row[label]) : 0.f;
+  if (dlogits == nullptr) return;
+  bf16_t* drow = dlogits + (size_t)r * ldv;
+  const int n = count[0];
+  const float gs = (valid && n > 0) ? grad_scale / (float)n : 0.f;
+  for (int i = tid * 8; i < ldv; i += 2048) {
+    float o[8];
+    if (valid) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = i + e;
+        float p = 0.f;
+        if (c < V) {
+          p = __expf(row[c] - lse);
+          if (c == (int)label) p -= 1.f;
+        }
+        o[e] = p * gs;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    }
+    *reinterpret_cast<u32x4*>(drow + i) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ loss_rows, int rows,
+                                                          const int32_t* __restrict__ count, float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 256) a += loss_rows[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = count[0];
+    // torch CrossEntropyLoss(mean) over zero valid targets is NaN
+    loss[0] = n > 0 ? (sh[0] + sh[1] + sh[2] + sh[3]) / (float)n : __uint_as_float(0x7fc00000u);
+  }
+}
+
+// Per row: logp = log_softmax(row) (or the forced-token distribution), then the k best of
+// logp + add[row] in (value desc, index asc) order by k block-wide arg-max sweeps.
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, int ldv, int V,
+                                                              const float* __restrict__ add, int force_token, int k,
+                                                              float* __restrict__ out_val,
+                                                              int32_t* __restrict__ out_idx) {
+  __shared__ float sh[8];
+  __shared__ float shv[4];
+  __shared__ int shi[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (size_t)r * ldv;
+  const float a = add != nullptr ? add[r] : 0.f;
+  float lse;
+  if (force_token >= 0) {
+    lse = row[force_token];  // all other logits are -inf: log_softmax gives 0 at the forced token
+  } else {
+    float m, s;
+    row_lse(row, V, sh, m, s);
+    lse = m + __logf(s);
+  }
+  float last_v = INFINITY;
+  int last_i = -1;
+  for (int j = 0; j < k; ++j) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      float x = row[i];
+      if (force_token >= 0 && i != force_token) x = -INFINITY;
+      // candidates strictly after (last_v, last_i) in (value desc, index asc) order
+      const bool after = (x < last_v) || (x == last_v && i > last_i);
+      if (after && (x > bv || (x == bv && i < bi))) { bv = x; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(bv, o, 64);
+      const int i2 = __shfl_xor(bi, o, 64);
+      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    }
+    if ((tid & 63) == 0) { shv[tid >> 6] = bv; shi[tid >> 6] = bi; }
+    __syncthreads();
+    bv = shv[0]; bi = shi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+    __syncthreads();
+    last_v = bv; last_i = bi;
+    if (tid == 0) {
+      out_val[(size_t)r * k + j] = (bv - lse) + a;
+      out_idx[(size_t)r * k + j] = bi;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, hipStream_t stream) {
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, stream, labels, n, count);
+  return hipGetLastError();
+}
+
+hipError_t kmb_ce_launch(const float* logits, int ldv, int V, const int64_t* labels, int rows, const int32_t* count,
+                         float grad_scale, float* loss_rows, bf16_t* dlogits, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if ((ldv & 7) || ((uintptr_t)logits & 15)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, labels, count, grad_scale, loss_rows, dlogits);
+  return hipGetLastError();
+}
+
+hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, stream, loss_rows, rows, count, loss);
+  return hipGetLastError();
+}
+
+hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
+                                      int force_token, int k, float* out_val, int32_t* out_idx, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, add, force_token, k, out_val, out_idx);
+  return hipGetLastError();
+}

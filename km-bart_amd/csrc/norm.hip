@@ -1,0 +1,259 @@
+// LayerNorm forward / backward, column-sum (bias gradient) and partial reducers.
+// All of these are HBM-bound row kernels: one 64-lane wave per row, 16-byte accesses,
+// fp32 statistics.  D must be a multiple of 8 and <= 2048.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ z, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                     float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nch = D >> 3;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      unpack8(*reinterpret_cast<const u32x4*>(z + (size_t)row * D + c * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * gamma[c * 8 + e] + beta[c * 8 + e];
+      *reinterpret_cast<u32x4*>(y + (size_t)row * D + c * 8) = pack8(o);
+    }
+  }
+}
+
+// Each block owns rows [blockIdx.x * rows_per_block, ...); its 4 waves take them round-robin.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, bf16_t* __restrict__ dz,
+                                                     bf16_t* __restrict__ out2, KmbDrop dy_drop, KmbDrop out2_drop,
+                                                     float* __restrict__ partials, int M, int D, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [4][2][D]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nch = D >> 3;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(M, r_begin + rows_per_block);
+  float dg[NCH][8], db[NCH][8], gm[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[i][e] = 0.f; db[i][e] = 0.f;
+      gm[i][e] = (c < nch) ? gamma[c * 8 + e] : 0.f;
+    }
+  }
+  for (int row = r_begin + wave; row < r_end; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[NCH][8], xh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float d8[8], z8[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dy + (size_t)row * D + c * 8), d8);
+        unpack8(*reinterpret_cast<const u32x4*>(z + (size_t)row * D + c * 8), z8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float d = d8[e];
+          if (dy_drop.thr16 != 0u)
+            d = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 8 + e), dy_drop.thr16) ? d * dy_drop.scale : 0.f;
+          const float x = (z8[e] - mu) * rs;
+          xh[i][e] = x;
+          dg[i][e] += d * x;
+          db[i][e] += d;
+          const float gg = d * gm[i][e];
+          g[i][e] = gg;
+          s1 += gg;
+          s2 += gg * x;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[i][e] = 0.f; xh[i][e] = 0.f; }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)D;
+    const float c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        *reinterpret_cast<u32x4*>(dz + (size_t)row * D + c * 8) = pack8(o);
+        if (out2 != nullptr) {
+          if (out2_drop.thr16 != 0u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              o[e] = drop_keep(out2_drop.seed, (uint32_t)row, (uint32_t)(c * 8 + e), out2_drop.thr16)
+                         ? o[e] * out2_drop.scale : 0.f;
+          }
+          *reinterpret_cast<u32x4*>(out2 + (size_t)row * D + c * 8) = pack8(o);
+        }
+      }
+    }
+  }
+  // reduce the 4 waves' partial dgamma / dbeta through LDS, one partial row per block
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * D + c * 8 + e] = dg[i][e];
+        red[(wave * 2 + 1) * D + c * 8 + e] = db[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
+    const int which = idx / D, col = idx - which * D;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * D + col];
+    partials[((size_t)blockIdx.x * 2 + which) * D + col] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ partials, int nparts, int stride,
+                                                           float* __restrict__ out, int n) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partials[(size_t)p * stride + c];
+  out[c] = s;
+}
+
+// grid (ceil(N/64), nparts); block 256 = 8 column chunks x 32 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
+                                                     float* __restrict__ partials, int rows_per_part) {
+  __shared__ float red[32][65];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int col = blockIdx.x * 64 + tx * 8;
+  const int r0 = blockIdx.y * rows_per_part;
+  const int r1 = min(M, r0 + rows_per_part);
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+  if (col < N) {
+    const int nvalid = min(8, N - col);
+    for (int r = r0 + ty; r < r1; r += 32) {
+      float v[8];
+      if (nvalid == 8) {
+        unpack8(*reinterpret_cast<const u32x4*>(X + (size_t)r * ld + col), v);
+      } else {
+        for (int e = 0; e < 8; ++e) v[e] = e < nvalid ? bf2f(X[(size_t)r * ld + col + e]) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int y = 0; y < 32; ++y) s += red[y][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) partials[(size_t)blockIdx.y * N + c] = s;
+  }
+}
+
+}  // namespace
+
+hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* beta, bf16_t* y, float* mean,
+                             float* rstd, int M, int D, float eps, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if ((D & 7) || D > 2048) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+  if (D <= 512) hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
+  else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
+  else hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
+  return hipGetLastError();
+}
+
+static int ln_bwd_rows_per_block(int M) {
+  int rpb = (M + 511) / 512;  // <= 512 blocks
+  if (rpb < 4) rpb = 4;
+  return rpb;
+}
+int kmb_ln_bwd_parts(int M) {
+  const int rpb = ln_bwd_rows_per_block(M);
+  return (M + rpb - 1) / rpb;
+}
+
+hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd,
+                             const float* gamma, bf16_t* dz, bf16_t* out2, KmbDrop dy_drop, KmbDrop out2_drop,
+                             float* partials, int M, int D, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if ((D & 7) || D > 2048) return hipErrorInvalidValue;
+  const int rpb = ln_bwd_rows_per_block(M);
+  dim3 grid((M + rpb - 1) / rpb), block(256);
+  const size_t lds = (size_t)4 * 2 * D * sizeof(float);
+  if (D <= 512)
+    hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb);
+  else if (D <= 1024)
+    hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb);
+  return hipGetLastError();
+}
+
+hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride, float* out, int n,
+                                   hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partials, nparts, stride, out, n);
+  return hipGetLastError();
+}
+
+static int colsum_rows_per_part(int M) {
+  int rpp = (M + 63) / 64;  // <= 64 parts
+  if (rpp < 32) rpp = 32;
+  return rpp;
+}
+int kmb_colsum_parts(int M) {
+  const int rpp = colsum_rows_per_part(M);
+  return (M + rpp - 1) / rpp;
+}
+hipError_t kmb_colsum_launch(const bf16_t* X, int ld, int M, int N, float* partials, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int rpp = colsum_rows_per_part(M);
+  dim3 grid((N + 63) / 64, (M + rpp - 1) / rpp), block(256);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, stream, X, ld, M, N, partials, rpp);
+  return hipGetLastError();
+}

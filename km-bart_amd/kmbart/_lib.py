@@ -1,0 +1,140 @@
+"""ctypes binding of libkmbart_hip.so (include/kmbart.h).  Fails loudly when the library is missing:
+there is no CPU fallback for the hot path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libkmbart_hip.so")
+
+c_p = C.c_void_p
+i32, i64, u32, f32, f64 = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
+
+
+class KmbConfig(C.Structure):
+    _fields_ = [(n, i32) for n in (
+        "vocab_size", "d_model", "encoder_layers", "decoder_layers", "encoder_attention_heads",
+        "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_position_embeddings",
+        "extra_pos_embeddings", "image_feature_size", "pad_token_id", "bos_token_id", "eos_token_id",
+        "img_feat_id", "cls_token_id", "scale_embedding")] + [
+        ("dropout", f32), ("attention_dropout", f32), ("activation_dropout", f32), ("layer_norm_eps", f32)]
+
+
+class KmbBatch(C.Structure):
+    _fields_ = [("B", i32), ("S", i32), ("T", i32),
+                ("input_ids", c_p), ("attention_mask", c_p), ("image_features", c_p), ("feat_offsets", c_p),
+                ("n_features", i32), ("decoder_input_ids", c_p), ("decoder_attention_mask", c_p), ("labels", c_p)]
+
+
+class KmbGemm(C.Structure):
+    _fields_ = [("A", c_p), ("B", c_p), ("lda", i32), ("ldb", i32), ("a_kc", i32), ("b_kc", i32),
+                ("M", i32), ("N", i32), ("K", i32), ("bias", c_p), ("col_scale", f32), ("col_scale_n", i32),
+                ("act", i32), ("preact", c_p), ("ld_preact", i32), ("aux", c_p), ("ld_aux", i32),
+                ("drop_thr16", u32), ("drop_seed", u32), ("drop_scale", f32), ("residual", c_p), ("ld_res", i32),
+                ("out_bf16", c_p), ("ld_out_bf16", i32), ("out_f32", c_p), ("ld_out_f32", i32), ("beta", f32)]
+
+
+class KmbAttn(C.Structure):
+    _fields_ = [("Q", c_p), ("K", c_p), ("V", c_p), ("ldq", i32), ("ldk", i32), ("ldv", i32),
+                ("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("key_mask", c_p), ("causal", i32),
+                ("O", c_p), ("ldo", i32), ("lse", c_p), ("dO", c_p), ("lddo", i32),
+                ("dQ", c_p), ("dK", c_p), ("dV", c_p), ("lddq", i32), ("lddk", i32), ("lddv", i32),
+                ("dq_scale", f32)]
+
+
+class KmbAttnDecode(C.Structure):
+    _fields_ = [("Q", c_p), ("ldq", i32), ("Kc", c_p), ("Vc", c_p), ("Tmax", i32), ("ldc", i32), ("kv_row", c_p),
+                ("key_mask", c_p), ("mask_ld", i32), ("mask_row", c_p), ("R", i32), ("H", i32), ("Tk", i32),
+                ("O", c_p), ("ldo", i32)]
+
+
+class KmbDrop(C.Structure):
+    _fields_ = [("thr16", u32), ("seed", u32), ("scale", f32)]
+
+
+class KmbAdamW(C.Structure):
+    _fields_ = [("lr", f64), ("beta1", f64), ("beta2", f64), ("eps", f64), ("weight_decay", f64),
+                ("step", i32), ("correct_bias", i32), ("grad_scale", f32)]
+
+
+# name -> (restype, argtypes); must list every function include/kmbart.h declares
+PROTOTYPES = {
+    "kmb_last_error": (C.c_char_p, []),
+    "kmb_version": (C.c_int, []),
+    "kmb_create": (C.c_int, [C.POINTER(KmbConfig), C.POINTER(c_p)]),
+    "kmb_destroy": (None, [c_p]),
+    "kmb_param_count": (C.c_int, [c_p]),
+    "kmb_param_info": (C.c_int, [c_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
+    "kmb_arena_elems": (i64, [c_p]),
+    "kmb_bf16_arena_elems": (i64, [c_p]),
+    "kmb_bind_arenas": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "kmb_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "kmb_bind_workspace": (C.c_int, [c_p, c_p, i64]),
+    "kmb_sync_params": (C.c_int, [c_p, c_p]),
+    "kmb_set_seed": (C.c_int, [c_p, C.c_uint64]),
+    "kmb_bucket_count": (C.c_int, [c_p]),
+    "kmb_bucket_range": (C.c_int, [c_p, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
+    "kmb_stream_wait_bucket": (C.c_int, [c_p, C.c_int, c_p]),
+    "kmb_logits_ld": (C.c_int, [c_p]),
+    "kmb_forward": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p, c_p, c_p, c_p]),
+    "kmb_backward": (C.c_int, [c_p, f32, c_p]),
+    "kmb_adamw_step": (C.c_int, [c_p, C.POINTER(KmbAdamW), i64, i64, c_p]),
+    "kmb_read_status": (C.c_int, [c_p, C.POINTER(i32), c_p]),
+    "kmb_gen_begin": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p]),
+    "kmb_gen_step": (C.c_int, [c_p, c_p, C.c_int, c_p, c_p]),
+    "kmb_gen_reorder": (C.c_int, [c_p, c_p, C.c_int, c_p]),
+    "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p]),
+    "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "kmb_op_gemm": (C.c_int, [C.POINTER(KmbGemm), c_p]),
+    "kmb_op_attn_fwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
+    "kmb_op_attn_bwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
+    "kmb_op_attn_decode": (C.c_int, [C.POINTER(KmbAttnDecode), c_p]),
+    "kmb_op_ln_fwd": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int, C.c_int, f32, c_p]),
+    "kmb_op_ln_bwd_scratch": (i64, [C.c_int, C.c_int]),
+    "kmb_op_ln_bwd": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(KmbDrop), C.POINTER(KmbDrop), c_p, c_p,
+                                c_p, C.c_int, C.c_int, c_p]),
+    "kmb_op_colsum_scratch": (i64, [C.c_int, C.c_int]),
+    "kmb_op_colsum": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p]),
+    "kmb_op_img_rowmap": (C.c_int, [c_p, c_p, C.c_int, C.c_int, i64, i64, c_p, c_p, c_p]),
+    "kmb_op_cast_pad": (C.c_int, [c_p, C.c_int, C.c_int, c_p, C.c_int, c_p]),
+    "kmb_op_embed_ln_fwd": (C.c_int, [c_p, c_p, c_p, c_p, c_p, C.c_int, C.c_int, f32, c_p, c_p, c_p, c_p, c_p, c_p,
+                                      C.c_int, C.c_int, f32, C.POINTER(KmbDrop), c_p]),
+    "kmb_op_embed_bwd": (C.c_int, [c_p, c_p, c_p, f32, c_p, c_p, i64, C.c_int, C.c_int, c_p]),
+    "kmb_op_pos_bwd": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, c_p]),
+    "kmb_op_ce": (C.c_int, [c_p, C.c_int, C.c_int, c_p, C.c_int, f32, c_p, c_p, c_p, c_p, c_p]),
+    "kmb_op_adamw": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, C.POINTER(KmbAdamW), c_p]),
+    "kmb_op_cast_bf16": (C.c_int, [c_p, c_p, i64, c_p]),
+    "kmb_op_dropout_mask": (C.c_int, [u32, f32, C.c_int, C.c_int, c_p, c_p]),
+}
+
+_lib = None
+
+
+class KmbError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KmbError(
+            "libkmbart_hip.so is missing (%s). Build it with `python km-bart_amd/build.py`; "
+            "the KM-BART hot path has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise KmbError(load().kmb_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, or NULL."""
+    return None if t is None else C.c_void_p(t.data_ptr())

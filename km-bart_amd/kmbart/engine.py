@@ -1,0 +1,222 @@
+"""Python host of libkmbart_hip.so: owns the device arenas (torch tensors) and forwards calls
+through the C-ABI.  torch is used for memory, streams and torch.distributed only."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import KmbAdamW, KmbBatch, KmbConfig, check, ptr
+
+_CFG_INT_FIELDS = ("vocab_size", "d_model", "encoder_layers", "decoder_layers", "encoder_attention_heads",
+                   "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_position_embeddings",
+                   "extra_pos_embeddings", "image_feature_size", "pad_token_id", "bos_token_id", "eos_token_id",
+                   "img_feat_id", "cls_token_id")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_features(image_features, feat_dim, device):
+    """list[B] of [R_i, F] fp32 (R_i may be 0 -> torch.empty(0), collation.py:73-76)
+    -> (packed [Ntot, F] fp32 on device, offsets int32 [B+1] on device, Ntot)."""
+    lens = [int(x.shape[0]) if x.dim() == 2 else 0 for x in image_features]
+    offs = [0]
+    for n in lens:
+        offs.append(offs[-1] + n)
+    non_empty = [x.to(device=device, dtype=torch.float32) for x, n in zip(image_features, lens) if n > 0]
+    for x in non_empty:
+        if x.shape[1] != feat_dim:
+            raise ValueError("image feature width %d != config.image_feature_size %d" % (x.shape[1], feat_dim))
+    packed = torch.cat(non_empty, 0).contiguous() if non_empty else torch.zeros((1, feat_dim), device=device)
+    offsets = torch.tensor(offs, dtype=torch.int32).to(device)
+    return packed, offsets, offs[-1]
+
+
+class Engine:
+    """One model replica on one GPU."""
+
+    def __init__(self, config, device):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.KmbError("the KM-BART hot path needs an MI355X (HIP) device; there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.KmbError("Engine device must be a HIP device ('cuda:N'), got %s" % device)
+        self.config = config
+        c = KmbConfig()
+        for f in _CFG_INT_FIELDS:
+            setattr(c, f, int(getattr(config, f)))
+        c.scale_embedding = 1 if getattr(config, "scale_embedding", False) else 0
+        c.dropout = float(config.dropout)
+        c.attention_dropout = float(config.attention_dropout)
+        c.activation_dropout = float(config.activation_dropout)
+        c.layer_norm_eps = 1e-5
+        self._ccfg = c
+        h = C.c_void_p()
+        check(self.lib.kmb_create(C.byref(c), C.byref(h)))
+        self.h = h
+        with torch.cuda.device(self.device):
+            n = self.lib.kmb_arena_elems(h)
+            nb = self.lib.kmb_bf16_arena_elems(h)
+            self.n = n
+            self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.params_bf16 = torch.zeros(nb, dtype=torch.bfloat16, device=self.device)
+            self.final_logits_bias = torch.zeros(int(config.vocab_size), dtype=torch.float32, device=self.device)
+            check(self.lib.kmb_bind_arenas(h, ptr(self.params), ptr(self.grads), ptr(self.exp_avg),
+                                           ptr(self.exp_avg_sq), ptr(self.params_bf16), ptr(self.final_logits_bias)))
+        self.index = {}  # name -> (offset, rows, cols)
+        name, off, rows, cols = C.c_char_p(), C.c_int64(), C.c_int32(), C.c_int32()
+        for i in range(self.lib.kmb_param_count(h)):
+            check(self.lib.kmb_param_info(h, i, C.byref(name), C.byref(off), C.byref(rows), C.byref(cols)))
+            self.index[name.value.decode()] = (off.value, rows.value, cols.value)
+        self.logits_ld = self.lib.kmb_logits_ld(h)
+        self.workspace = None
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._keep = []  # tensors the in-flight kernels read
+        self.step_count = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.kmb_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------
+    def view(self, arena, name):
+        off, rows, cols = self.index[name]
+        t = arena[off: off + rows * cols]
+        return t.view(cols) if rows == 1 else t.view(rows, cols)
+
+    def sync_params(self):
+        """fp32 master -> bf16 mirror (after init / load_state_dict / manual edits)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_sync_params(self.h, _stream()))
+
+    def set_seed(self, seed):
+        check(self.lib.kmb_set_seed(self.h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+
+    # ---- workspace --------------------------------------------------------------------------
+    def _ensure_ws(self, nbytes):
+        if self.workspace is None or self.workspace.numel() < nbytes:
+            torch.cuda.synchronize(self.device)
+            self.workspace = None
+            self.workspace = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+            check(self.lib.kmb_bind_workspace(self.h, ptr(self.workspace), self.workspace.numel()))
+
+    def _batch(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask, labels):
+        dev = self.device
+
+        def i64(t):
+            return None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
+
+        input_ids = i64(input_ids)
+        B, S = input_ids.shape
+        packed, offsets, ntot = pack_features(image_features, int(self.config.image_feature_size), dev)
+        attention_mask = i64(attention_mask)
+        decoder_input_ids = i64(decoder_input_ids)
+        decoder_attention_mask = i64(decoder_attention_mask)
+        labels = i64(labels)
+        T = decoder_input_ids.shape[1] if decoder_input_ids is not None else 1
+        b = KmbBatch(B=B, S=S, T=T, input_ids=ptr(input_ids), attention_mask=ptr(attention_mask),
+                     image_features=ptr(packed), feat_offsets=ptr(offsets), n_features=ntot,
+                     decoder_input_ids=ptr(decoder_input_ids), decoder_attention_mask=ptr(decoder_attention_mask),
+                     labels=ptr(labels))
+        keep = [input_ids, packed, offsets, attention_mask, decoder_input_ids, decoder_attention_mask, labels]
+        return b, keep, (B, S, T, ntot)
+
+    # ---- training step ----------------------------------------------------------------------
+    def forward(self, input_ids, image_features, attention_mask=None, decoder_input_ids=None,
+                decoder_attention_mask=None, labels=None, train=False, need_grad=False, want_logits=False,
+                want_encoder=True):
+        """Returns (loss [1] or None, logits [B,T,V] fp32 or None, encoder_out [B,S,D] bf16 or None)."""
+        with torch.cuda.device(self.device):
+            b, keep, (B, S, T, ntot) = self._batch(input_ids, image_features, attention_mask, decoder_input_ids,
+                                                   decoder_attention_mask, labels)
+            self._ensure_ws(self.lib.kmb_workspace_bytes(self.h, B, S, T, ntot))
+            logits = None
+            if want_logits:
+                logits = torch.empty((B * T, self.logits_ld), dtype=torch.float32, device=self.device)
+            enc = None
+            if want_encoder:
+                enc = torch.empty((B, S, int(self.config.d_model)), dtype=torch.bfloat16, device=self.device)
+            loss = torch.empty(1, dtype=torch.float32, device=self.device) if labels is not None else None
+            check(self.lib.kmb_forward(self.h, C.byref(b), 1 if train else 0, 1 if need_grad else 0, ptr(loss),
+                                       ptr(logits), ptr(enc), _stream()))
+            self._keep = keep
+            if logits is not None:
+                logits = logits.view(B, T, self.logits_ld)[:, :, : int(self.config.vocab_size)]
+            return loss, logits, enc
+
+    def check_inputs(self):
+        """Raises if the device-side validation of the last forward flagged the batch (syncs)."""
+        st = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_read_status(self.h, C.byref(st), _stream()))
+        if st.value & 1:
+            raise RuntimeError("number of <img_feat>/<cls> ids differs from the number of region features "
+                               "(reference src/model/modules.py:98-100 would raise a shape mismatch)")
+
+    def backward(self, loss_scale=1.0):
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_backward(self.h, C.c_float(loss_scale), _stream()))
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0,
+                   offset=0, count=None, bump=True):
+        if bump:
+            self.step_count += 1
+        hp = KmbAdamW(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay,
+                      step=self.step_count, correct_bias=1 if correct_bias else 0, grad_scale=grad_scale)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_adamw_step(self.h, C.byref(hp), offset, self.n - offset if count is None else count,
+                                          _stream()))
+
+    # ---- data-parallel buckets --------------------------------------------------------------
+    def buckets(self):
+        out = []
+        off, cnt = C.c_int64(), C.c_int64()
+        for i in range(self.lib.kmb_bucket_count(self.h)):
+            check(self.lib.kmb_bucket_range(self.h, i, C.byref(off), C.byref(cnt)))
+            out.append((off.value, cnt.value))
+        return out
+
+    def stream_wait_bucket(self, i, stream):
+        check(self.lib.kmb_stream_wait_bucket(self.h, i, C.c_void_p(stream.cuda_stream)))
+
+    # ---- generation -------------------------------------------------------------------------
+    def gen_begin(self, input_ids, image_features, attention_mask, num_beams, max_length):
+        with torch.cuda.device(self.device):
+            b, keep, (B, S, _, ntot) = self._batch(input_ids, image_features, attention_mask, None, None, None)
+            self._ensure_ws(self.lib.kmb_gen_workspace_bytes(self.h, B, S, num_beams, max_length, ntot))
+            check(self.lib.kmb_gen_begin(self.h, C.byref(b), num_beams, max_length, _stream()))
+            self._keep = keep
+            self._gen_rows = B * num_beams
+            self._gen_logits = torch.empty((self._gen_rows, self.logits_ld), dtype=torch.float32, device=self.device)
+
+    def gen_step(self, tokens, step):
+        """tokens int64 [B*num_beams] (device) at 0-based position `step` -> fp32 logits [R, V] (padded view)."""
+        with torch.cuda.device(self.device):
+            tokens = tokens.to(device=self.device, dtype=torch.int64).contiguous()
+            check(self.lib.kmb_gen_step(self.h, ptr(tokens), int(step), ptr(self._gen_logits), _stream()))
+            self._keep_tok = tokens
+        return self._gen_logits
+
+    def gen_reorder(self, beam_idx, step):
+        with torch.cuda.device(self.device):
+            beam_idx = beam_idx.to(device=self.device, dtype=torch.int32).contiguous()
+            check(self.lib.kmb_gen_reorder(self.h, ptr(beam_idx), int(step), _stream()))
+            self._keep_idx = beam_idx
+
+    def logsoftmax_topk(self, logits, k, add=None, force_token=-1):
+        R = logits.shape[0]
+        val = torch.empty((R, k), dtype=torch.float32, device=self.device)
+        idx = torch.empty((R, k), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_logsoftmax_topk(ptr(logits), logits.stride(0), int(self.config.vocab_size), R,
+                                               ptr(add), int(force_token), int(k), ptr(val), ptr(idx), _stream()))
+        return val, idx

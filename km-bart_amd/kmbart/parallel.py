@@ -1,0 +1,130 @@
+"""Single-node data parallelism: one process per GPU, gradient all-reduce over RCCL/xGMI overlapped
+with backward.  Replaces torch DistributedDataParallel as used by the reference
+(vcg_train.py:98: DDP(model, device_ids=[rank], find_unused_parameters=True); src/utils.py:13).
+
+Semantics kept: parameters are broadcast from rank 0 at wrap time; after `loss.backward()` every
+rank holds the arithmetic MEAN over ranks of the per-rank gradients (each rank's loss is the mean over
+its own non-ignored tokens); `.module` reaches the wrapped model.
+
+Mechanics: the engine's gradients are one flat fp32 arena cut into buckets in backward completion
+order (decoder layers last->first, decoder embedding, encoder layers, encoder embedding + image
+projection, tied matrix).  kmb_backward records an event per bucket on the compute stream; the
+reducer makes the communication stream wait on that event and issues the bucket's all-reduce, so
+the collectives run while the rest of backward is still computing.  `find_unused_parameters` is
+not needed: every gradient is written every step (no per-step bitmap collective).
+"""
+import torch
+import torch.distributed as dist
+
+
+class BucketedAllReducer:
+    """All-reduce (mean) of slices of one flat tensor, in a given bucket order.
+
+    wait_ready(i, stream): optional hook that makes `stream` wait until bucket i is complete
+    (HIP event on the GPU path; None on the CPU/gloo test path where backward has already finished).
+    """
+
+    def __init__(self, flat, buckets, process_group=None, wait_ready=None, comm_stream=None, max_bucket_elems=None):
+        self.flat = flat
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.wait_ready = wait_ready
+        self.comm_stream = comm_stream
+        self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        # split very large buckets (the tied matrix is 154 MB) so that the tail latency is one piece, not the whole
+        self.pieces = []
+        for i, (off, cnt) in enumerate(buckets):
+            if max_bucket_elems and cnt > max_bucket_elems:
+                n = (cnt + max_bucket_elems - 1) // max_bucket_elems
+                step = (cnt + n - 1) // n
+                for s in range(0, cnt, step):
+                    self.pieces.append((i, off + s, min(step, cnt - s)))
+            else:
+                self.pieces.append((i, off, cnt))
+        self._works = []
+
+    def launch(self):
+        if self.world == 1:
+            return
+        use_avg = self.backend == "nccl"
+        op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+        on_gpu = self.flat.is_cuda
+        ctx = torch.cuda.stream(self.comm_stream) if (on_gpu and self.comm_stream is not None) else _Null()
+        waited = set()
+        with ctx:
+            for i, off, cnt in self.pieces:
+                if self.wait_ready is not None and i not in waited:
+                    self.wait_ready(i, self.comm_stream if self.comm_stream is not None else torch.cuda.current_stream())
+                    waited.add(i)
+                piece = self.flat[off: off + cnt]
+                w = dist.all_reduce(piece, op=op, group=self.group, async_op=True)
+                self._works.append((w, piece, use_avg))
+
+    def finish(self):
+        """Makes the current stream (GPU) or the host (CPU) wait for every outstanding all-reduce."""
+        for w, piece, use_avg in self._works:
+            w.wait()
+            if not use_avg:
+                piece.div_(self.world)
+        self._works = []
+        if self.flat.is_cuda and self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class DistributedDataParallel(torch.nn.Module):
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None,
+                 max_bucket_mb=64):
+        super().__init__()
+        self.__dict__["module"] = module  # not a registered child: parameters() must not be re-wrapped
+        eng = module._need_engine()
+        self.engine = eng
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.reducer = None
+        if self.world > 1:
+            # C2: parameters and the logits-bias buffer start identical on every rank
+            dist.broadcast(eng.params, src=0, group=process_group)
+            dist.broadcast(eng.final_logits_bias, src=0, group=process_group)
+            eng.sync_params()
+            comm = torch.cuda.Stream(device=eng.device)
+            self.reducer = BucketedAllReducer(
+                eng.grads, eng.buckets(), process_group,
+                wait_ready=lambda i, stream: eng.stream_wait_bucket(i, stream), comm_stream=comm,
+                max_bucket_elems=max_bucket_mb * (1 << 20) // 4)
+            module._post_backward = self._reduce
+
+    def _reduce(self):
+        self.reducer.launch()
+        self.reducer.finish()
+
+    def forward(self, *args, **kwargs):
+        return self.module.forward(*args, **kwargs)
+
+    def generate(self, *args, **kwargs):
+        return self.module.generate(*args, **kwargs)
+
+    def parameters(self, recurse=True):
+        return self.module.parameters()
+
+    def named_parameters(self, prefix="", recurse=True, remove_duplicate=True):
+        return self.module.named_parameters(prefix="module")
+
+    def train(self, mode=True):
+        self.module.train(mode)
+        return super().train(mode)
+
+    def eval(self):
+        return self.train(False)
+
+    def state_dict(self, *a, **k):
+        return {"module." + n: v for n, v in self.module.state_dict().items()}
+
+    def train_step_fwd_bwd(self, batch, loss_scale=1.0):
+        return self.module.train_step_fwd_bwd(batch, loss_scale)

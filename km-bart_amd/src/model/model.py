@@ -1,0 +1,561 @@
+"""MultiModalBartForConditionalGeneration on the MI355X engine.
+
+Same call surface as the reference class (reference src/model/model.py:317-405, generation
+src/model/mixins.py:33-434, checkpoint glue src/model/mixins.py:458-883), but the arithmetic runs in
+libkmbart_hip.so: this module only marshals tensors, keeps the reference's return conventions and
+does the beam bookkeeping on the host.  There is no CPU forward: calling the model before it has
+been moved to a HIP device raises.
+"""
+import math
+import os
+
+import torch
+from torch import nn
+
+from kmbart.engine import Engine
+from src.model.config import MultiModalBartConfig
+
+WEIGHTS_NAME = "pytorch_model.bin"
+_TIED = ("model.encoder.embed_tokens.weight", "model.decoder.embed_tokens.weight")
+
+
+def _param_names(cfg):
+    names = ["model.encoder.embed_images.linear.weight", "model.encoder.embed_images.linear.bias",
+             "model.encoder.embed_positions.weight", "model.encoder.layernorm_embedding.weight",
+             "model.encoder.layernorm_embedding.bias"]
+
+    def attn(p, blk):
+        out = []
+        for a in ("q_proj", "k_proj", "v_proj"):
+            out.append(p + f"{blk}.{a}.weight")
+        for a in ("q_proj", "k_proj", "v_proj"):
+            out.append(p + f"{blk}.{a}.bias")
+        out += [p + f"{blk}.out_proj.weight", p + f"{blk}.out_proj.bias",
+                p + f"{blk}_layer_norm.weight", p + f"{blk}_layer_norm.bias"]
+        return out
+
+    def ffn(p):
+        return [p + "fc1.weight", p + "fc1.bias", p + "fc2.weight", p + "fc2.bias",
+                p + "final_layer_norm.weight", p + "final_layer_norm.bias"]
+
+    for i in range(cfg.encoder_layers):
+        p = f"model.encoder.layers.{i}."
+        names += attn(p, "self_attn") + ffn(p)
+    names += ["model.decoder.embed_positions.weight", "model.decoder.layernorm_embedding.weight",
+              "model.decoder.layernorm_embedding.bias"]
+    for i in range(cfg.decoder_layers):
+        p = f"model.decoder.layers.{i}."
+        names += attn(p, "self_attn") + attn(p, "encoder_attn") + ffn(p)
+    names.append("model.shared.weight")
+    return names
+
+
+def _param_shape(cfg, name):
+    d = cfg.d_model
+    if name == "model.shared.weight":
+        return (cfg.vocab_size, d)
+    if name.endswith("embed_images.linear.weight"):
+        return (d, cfg.image_feature_size)
+    if name.endswith("embed_positions.weight"):
+        return (cfg.max_position_embeddings + cfg.extra_pos_embeddings, d)
+    ffn = cfg.encoder_ffn_dim if ".encoder." in name else cfg.decoder_ffn_dim
+    if name.endswith("fc1.weight"):
+        return (ffn, d)
+    if name.endswith("fc1.bias"):
+        return (ffn,)
+    if name.endswith("fc2.weight"):
+        return (d, ffn)
+    if name.endswith("proj.weight"):
+        return (d, d)
+    return (d,)
+
+
+class _LossFn(torch.autograd.Function):
+    """Connects the engine's loss scalar to autograd so `loss.backward()` / `scaler.scale(loss).backward()`
+    (reference src/training.py:137-142) run kmb_backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss):
+        ctx.model = model
+        return loss.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._backward(float(grad_out))
+        return None, None, None
+
+
+class LazyLogits:
+    """outputs[1] of a training forward: the fp32 logits are produced on first use (one extra head GEMM on
+    the saved decoder states) instead of 1.6 GB per step that the training loop never reads."""
+
+    def __init__(self, fn):
+        self._fn, self._t = fn, None
+
+    def tensor(self):
+        if self._t is None:
+            self._t = self._fn()
+        return self._t
+
+    def __getattr__(self, name):
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+
+class BeamHypotheses:
+    """transformers 3.0.2 BeamHypotheses (n-best list, score = sum_logprobs / len ** length_penalty)."""
+
+    def __init__(self, num_beams, max_length, length_penalty, early_stopping):
+        self.max_length = max_length - 1
+        self.length_penalty = length_penalty
+        self.early_stopping = early_stopping
+        self.num_beams = num_beams
+        self.beams = []
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / len(hyp) ** self.length_penalty
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self) > self.num_beams:
+                sorted_scores = sorted([(s, idx) for idx, (s, _) in enumerate(self.beams)])
+                del self.beams[sorted_scores[0][1]]
+                self.worst_score = sorted_scores[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+class MultiModalBartForConditionalGeneration(nn.Module):
+    base_model_prefix = "model"
+    config_class = MultiModalBartConfig
+
+    def __init__(self, config: MultiModalBartConfig):
+        super().__init__()
+        config.check_supported()
+        self.config = config
+        self._engine = None
+        self._names = _param_names(config)
+        g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        self._p = {}
+        # transformers `init_weights` (model.py:37): N(0, init_std), zero biases / pad rows, LayerNorm (1, 0)
+        for n in self._names:
+            shp = _param_shape(config, n)
+            if "layer_norm" in n or "layernorm" in n:
+                t = torch.ones(shp) if n.endswith("weight") else torch.zeros(shp)
+            elif n.endswith("bias"):
+                t = torch.zeros(shp)
+            else:
+                t = torch.randn(shp, generator=g) * config.init_std
+                if n == "model.shared.weight" or n.endswith("embed_positions.weight"):
+                    t[config.pad_token_id].zero_()
+            self._p[n] = nn.Parameter(t)
+        self._flb = torch.zeros((1, config.vocab_size))  # buffer final_logits_bias (model.py:323)
+        self._anchor = None
+        self._post_backward = None  # set by the data-parallel wrapper
+        self._dec_hidden_for_logits = None
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def named_parameters(self, prefix="", recurse=True, remove_duplicate=True):
+        for n in self._names:
+            yield (prefix + ("." if prefix else "") + n, self._p[n])
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    @property
+    def final_logits_bias(self):
+        return self._engine.final_logits_bias.view(1, -1) if self._engine is not None else self._flb
+
+    def state_dict(self, *args, **kwargs):
+        sd = {"final_logits_bias": self.final_logits_bias.detach().clone().cpu()}
+        for n in self._names:
+            sd[n] = self._p[n].detach().clone().cpu()
+        for t in _TIED:
+            sd[t] = sd["model.shared.weight"]
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing, unexpected = [], []
+        with torch.no_grad():
+            for n in self._names:
+                if n in state_dict:
+                    self._p[n].copy_(state_dict[n].to(self._p[n].dtype))
+                else:
+                    missing.append(n)
+            if "final_logits_bias" in state_dict:
+                self.final_logits_bias.copy_(state_dict["final_logits_bias"].view(1, -1))
+            for k in state_dict:
+                if k not in self._p and k not in _TIED and k != "final_logits_bias":
+                    unexpected.append(k)
+        if strict and (missing or unexpected):
+            raise RuntimeError("load_state_dict: missing %s unexpected %s" % (missing, unexpected))
+        if self._engine is not None:
+            self._engine.sync_params()
+        return missing, unexpected
+
+    def to(self, *args, **kwargs):
+        device = None
+        for a in args:
+            if isinstance(a, (str, torch.device)):
+                device = torch.device(a)
+            elif isinstance(a, int):
+                device = torch.device("cuda", a)
+        device = torch.device(kwargs["device"]) if "device" in kwargs else device
+        if device is None:
+            return self
+        if device.type != "cuda":
+            if self._engine is not None:
+                raise RuntimeError("moving a device model back to CPU is not supported; use state_dict()")
+            return self
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._engine is not None:
+            if self._engine.device != device:
+                raise RuntimeError("model already lives on %s" % self._engine.device)
+            return self
+        eng = Engine(self.config, device)
+        with torch.no_grad():
+            for n in self._names:
+                eng.view(eng.params, n).copy_(self._p[n].detach().to(device))
+            eng.final_logits_bias.copy_(self._flb.view(-1).to(device))
+        for n in self._names:
+            p = nn.Parameter(eng.view(eng.params, n))
+            p.grad = eng.view(eng.grads, n)
+            p._kmb_engine = eng
+            off, rows, cols = eng.index[n]
+            p._kmb_range = (off, rows * cols)
+            self._p[n] = p
+        self._engine = eng
+        self._anchor = torch.zeros((), device=device, requires_grad=True)
+        eng.sync_params()
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def zero_grad(self, set_to_none=False):
+        pass  # every gradient is overwritten by the next backward (reference zeroes after forward, training.py:136)
+
+    @property
+    def device(self):
+        return self._engine.device if self._engine is not None else torch.device("cpu")
+
+    def _need_engine(self):
+        if self._engine is None:
+            raise RuntimeError("MultiModalBartForConditionalGeneration runs on an MI355X only: call .to('cuda:N') "
+                               "first (there is no CPU forward path)")
+        return self._engine
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, input_ids, image_features, attention_mask=None, encoder_outputs=None, decoder_input_ids=None,
+                decoder_attention_mask=None, decoder_cached_states=None, labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_logits=None, **unused):
+        """Reference src/model/model.py:325-405.  Returns (loss, logits, encoder_last_hidden) with labels,
+        (logits, encoder_last_hidden) without.  The cached-decode branch is served by generate()."""
+        eng = self._need_engine()
+        if encoder_outputs is not None or decoder_cached_states is not None:
+            raise NotImplementedError("encoder_outputs / decoder_cached_states are internal to generate() here")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
+        if decoder_input_ids is None:
+            # transformers shift_tokens_right(input_ids, pad) (HF3.0.2 _prepare_bart_decoder_inputs)
+            pad = self.config.pad_token_id
+            prev = input_ids.clone()
+            idx_eos = (input_ids.ne(pad).sum(dim=1) - 1).unsqueeze(-1)
+            prev[:, 0] = input_ids.gather(1, idx_eos).squeeze()
+            prev[:, 1:] = input_ids[:, :-1]
+            decoder_input_ids = prev
+        if decoder_attention_mask is None and bool((decoder_input_ids == self.config.pad_token_id).any()):
+            decoder_attention_mask = decoder_input_ids.ne(self.config.pad_token_id).long()
+        need_grad = labels is not None and torch.is_grad_enabled()
+        want_logits = (labels is None) if return_logits is None else bool(return_logits)
+        loss, logits, enc = eng.forward(input_ids, image_features, attention_mask, decoder_input_ids,
+                                        decoder_attention_mask, labels, train=self.training, need_grad=need_grad,
+                                        want_logits=want_logits)
+        if labels is None:
+            return (logits, enc)
+        if need_grad:
+            loss = _LossFn.apply(self._anchor, self, loss)
+        else:
+            loss = loss.view(())
+        if logits is None:
+            args = (input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask)
+            logits = LazyLogits(lambda: self._logits_only(*args))
+        return (loss, logits, enc)
+
+    def _logits_only(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask):
+        was = self.training
+        self.training = False
+        try:
+            _, logits, _ = self._engine.forward(input_ids, image_features, attention_mask, decoder_input_ids,
+                                                decoder_attention_mask, None, train=False, need_grad=False,
+                                                want_logits=True, want_encoder=False)
+        finally:
+            self.training = was
+        return logits
+
+    def _backward(self, loss_scale=1.0):
+        self._engine.backward(loss_scale)
+        if self._post_backward is not None:
+            self._post_backward()
+
+    def train_step_fwd_bwd(self, batch, loss_scale=1.0):
+        """forward + backward without any host synchronisation; returns the device loss tensor [1]."""
+        eng = self._need_engine()
+        loss, _, _ = eng.forward(batch["input_ids"], batch["image_features"], batch.get("attention_mask"),
+                                 batch.get("decoder_input_ids"), batch.get("decoder_attention_mask"), batch["labels"],
+                                 train=self.training, need_grad=True, want_logits=False, want_encoder=False)
+        self._backward(loss_scale)
+        return loss
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def generate(self, input_ids=None, image_features=None, max_length=None, min_length=None, do_sample=None,
+                 early_stopping=None, num_beams=None, temperature=None, top_k=None, top_p=None,
+                 repetition_penalty=None, bad_words_ids=None, bos_token_id=None, pad_token_id=None,
+                 eos_token_id=None, length_penalty=None, no_repeat_ngram_size=None, num_return_sequences=None,
+                 attention_mask=None, decoder_start_token_id=None, use_cache=None, return_scores=False,
+                 **model_specific_kwargs):
+        """Reference src/model/mixins.py:33-384 (+ transformers 3.0.2 _generate_beam_search /
+        _generate_no_beam_search).  Encoder once, KV-cached decoder steps on the device, beam
+        bookkeeping on the host exactly as the reference does it."""
+        eng = self._need_engine()
+        cfg = self.config
+
+        def dflt(v, name):
+            return v if v is not None else getattr(cfg, name)
+
+        max_length = dflt(max_length, "max_length")
+        min_length = dflt(min_length, "min_length")
+        do_sample = dflt(do_sample, "do_sample")
+        early_stopping = dflt(early_stopping, "early_stopping")
+        num_beams = dflt(num_beams, "num_beams")
+        temperature = dflt(temperature, "temperature")
+        top_k = dflt(top_k, "top_k")
+        top_p = dflt(top_p, "top_p")
+        repetition_penalty = dflt(repetition_penalty, "repetition_penalty")
+        pad_token_id = dflt(pad_token_id, "pad_token_id")
+        eos_token_id = dflt(eos_token_id, "eos_token_id")
+        length_penalty = dflt(length_penalty, "length_penalty")
+        no_repeat_ngram_size = dflt(no_repeat_ngram_size, "no_repeat_ngram_size")
+        bad_words_ids = dflt(bad_words_ids, "bad_words_ids")
+        num_return_sequences = dflt(num_return_sequences, "num_return_sequences")
+        decoder_start_token_id = dflt(decoder_start_token_id, "decoder_start_token_id")
+        # argument validation of mixins.py:176-208
+        assert input_ids is not None and input_ids.dim() == 2, "Input prompt should be of shape (batch_size, sequence length)."
+        assert isinstance(max_length, int) and max_length > 0, "`max_length` should be a strictly positive integer."
+        assert isinstance(min_length, int) and min_length >= 0, "`min_length` should be a positive integer."
+        assert isinstance(do_sample, bool), "`do_sample` should be a boolean."
+        assert isinstance(early_stopping, bool), "`early_stopping` should be a boolean."
+        assert isinstance(num_beams, int) and num_beams > 0, "`num_beams` should be a strictly positive integer."
+        assert temperature > 0, "`temperature` should be strictly positive."
+        assert isinstance(top_k, int) and top_k >= 0, "`top_k` should be a positive integer."
+        assert 0 <= top_p <= 1, "`top_p` should be between 0 and 1."
+        assert length_penalty > 0, "`length_penalty` should be strictly positive."
+        assert isinstance(num_return_sequences, int) and num_return_sequences > 0
+        if repetition_penalty != 1.0 or no_repeat_ngram_size != 0 or bad_words_ids is not None:
+            raise NotImplementedError("repetition_penalty / no_repeat_ngram_size / bad_words_ids are not used by the "
+                                      "reference's generate_text (src/generation.py:22-32) and are not implemented")
+        if not do_sample:
+            if num_beams == 1:
+                assert num_return_sequences == 1, "Greedy decoding will always produce the same output"
+            else:
+                assert num_beams >= num_return_sequences
+        elif num_beams > 1:
+            raise NotImplementedError("beam-search multinomial sampling is not implemented")
+        B = input_ids.shape[0]
+        dev = eng.device
+        if attention_mask is None:
+            if pad_token_id is not None and bool((input_ids == pad_token_id).any()):
+                attention_mask = input_ids.ne(pad_token_id).long()
+            else:
+                attention_mask = torch.ones_like(input_ids)
+        eff_mult = num_return_sequences if do_sample else 1
+        assert 1 < max_length, "The context has 1 number of tokens, but `max_length` is only %d" % max_length
+        if do_sample and eff_mult > 1:  # sampling replicates the batch (mixins.py:259-262)
+            rep = torch.arange(B).repeat_interleave(eff_mult)
+            input_ids = input_ids[rep]
+            attention_mask = attention_mask[rep]
+            image_features = [image_features[i] for i in rep.tolist()]
+            B = B * eff_mult
+        V = cfg.vocab_size
+        R = B * num_beams
+        eng.gen_begin(input_ids, image_features, attention_mask, num_beams, max_length)
+        eng.check_inputs()
+        ids = torch.full((R, 1), decoder_start_token_id, dtype=torch.long)  # host copy of the decoder inputs
+        cur_len = 1
+
+        if num_beams == 1:
+            unfinished = torch.ones(B, dtype=torch.long)
+            while cur_len < max_length:
+                logits = eng.gen_step(ids[:, -1].to(dev), cur_len - 1)[:, :V]
+                if eos_token_id is not None and cur_len < min_length:
+                    logits[:, eos_token_id] = -float("inf")
+                if do_sample:
+                    lg = logits / temperature if temperature != 1.0 else logits
+                    lg = _top_k_top_p_filtering(lg.clone(), top_k=top_k, top_p=top_p)
+                    nxt = torch.multinomial(torch.softmax(lg, dim=-1), num_samples=1).squeeze(1).cpu()
+                else:
+                    nxt = torch.argmax(logits, dim=-1).cpu()
+                tok = nxt * unfinished + pad_token_id * (1 - unfinished) if eos_token_id is not None else nxt
+                ids = torch.cat([ids, tok.unsqueeze(-1)], dim=-1)
+                cur_len += 1
+                if eos_token_id is not None:
+                    unfinished = unfinished * (tok != eos_token_id).long()
+                    if int(unfinished.max()) == 0:
+                        break
+            return ids.to(dev)
+
+        hyps = [BeamHypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
+        beam_scores = torch.zeros((B, num_beams), dtype=torch.float32)
+        beam_scores[:, 1:] = -1e9
+        beam_scores = beam_scores.view(-1)
+        done = [False] * B
+        k = 2 * num_beams
+        while cur_len < max_length:
+            logits = eng.gen_step(ids[:, -1].to(dev), cur_len - 1)
+            force = -1
+            if cur_len == 1:
+                force = cfg.bos_token_id          # adjust_logits_during_generation, mixins.py:400-405
+            if cur_len == max_length - 1 and eos_token_id is not None:
+                force = eos_token_id
+            if eos_token_id is not None and cur_len < min_length:
+                logits[:, eos_token_id] = -float("inf")
+            val, idx = eng.logsoftmax_topk(logits, k, add=beam_scores.to(dev), force_token=force)
+            val = val.view(B, num_beams * k).cpu()
+            idx = (idx.view(B, num_beams, k).long() + (torch.arange(num_beams, device=dev) * V).view(1, -1, 1)) \
+                .view(B, num_beams * k).cpu()
+            # top 2*num_beams of the union == top 2*num_beams over num_beams * V (each row contributed its best 2*num_beams)
+            order = torch.sort(val, dim=1, descending=True, stable=True)[1][:, :k]
+            next_scores = torch.gather(val, 1, order)
+            next_tokens = torch.gather(idx, 1, order)
+            next_batch_beam = []
+            for b in range(B):
+                if done[b]:
+                    next_batch_beam.extend([(0, pad_token_id, 0)] * num_beams)
+                    continue
+                sent = []
+                for rank, (tid, tscore) in enumerate(zip(next_tokens[b].tolist(), next_scores[b].tolist())):
+                    beam_id, token_id = tid // V, tid % V
+                    eff = b * num_beams + beam_id
+                    if eos_token_id is not None and token_id == eos_token_id:
+                        if rank >= num_beams:
+                            continue
+                        hyps[b].add(ids[eff].clone(), tscore)
+                    else:
+                        sent.append((tscore, token_id, eff))
+                    if len(sent) == num_beams:
+                        break
+                done[b] = done[b] or hyps[b].is_done(float(next_scores[b].max()), cur_len)
+                assert len(sent) == num_beams, "Beam should always be full"
+                next_batch_beam.extend(sent)
+            if all(done):
+                break
+            beam_scores = torch.tensor([x[0] for x in next_batch_beam], dtype=torch.float32)
+            beam_tokens = torch.tensor([x[1] for x in next_batch_beam], dtype=torch.long)
+            beam_idx = torch.tensor([x[2] for x in next_batch_beam], dtype=torch.long)
+            ids = torch.cat([ids[beam_idx, :], beam_tokens.unsqueeze(1)], dim=-1)
+            eng.gen_reorder(beam_idx.to(dev), cur_len - 1)   # _reorder_cache, mixins.py:419-434
+            cur_len += 1
+        for b in range(B):
+            if done[b]:
+                continue
+            for beam_id in range(num_beams):
+                eff = b * num_beams + beam_id
+                hyps[b].add(ids[eff], float(beam_scores[eff]))
+        best, best_scores, lens = [], [], []
+        for h in hyps:
+            sh = sorted(h.beams, key=lambda x: x[0])
+            for _ in range(num_return_sequences):
+                s, hyp = sh.pop()
+                best.append(hyp)
+                best_scores.append(s)
+                lens.append(len(hyp))
+        if min(lens) != max(lens):
+            L = min(max(lens) + 1, max_length)
+            out = torch.full((len(best), L), pad_token_id, dtype=torch.long)
+            for i, hyp in enumerate(best):
+                out[i, : lens[i]] = hyp
+                if lens[i] < max_length:
+                    out[i, lens[i]] = eos_token_id
+        else:
+            out = torch.stack(best).long()
+        out = out.to(dev)
+        return (out, torch.tensor(best_scores)) if return_scores else out
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_pretrained(self, save_directory):
+        """transformers `save_pretrained`: config.json + pytorch_model.bin with the reference's key names
+        (vcg_train.py:249-254)."""
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        torch.save(self.state_dict(), os.path.join(save_directory, WEIGHTS_NAME))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, state_dict=None,
+                        error_on_mismatch=False, **kwargs):
+        """Reference src/model/mixins.py:551-883 for local paths: directory with pytorch_model.bin or a file.
+        Keys listed in `config.partial_load` are copied into the top-left slice of a larger parameter
+        (mixins.py:511-530); other shape mismatches are skipped silently like the reference (mixins.py:856-863,
+        the RuntimeError there is built but never raised).  The model is returned in eval mode (:867)."""
+        path = pretrained_model_name_or_path
+        if config is None:
+            config = MultiModalBartConfig.from_pretrained(path)
+        model = cls(config, *model_args)
+        if state_dict is None:
+            f = os.path.join(path, WEIGHTS_NAME) if os.path.isdir(path) else path
+            if not os.path.isfile(f):
+                raise EnvironmentError("no %s under %s (hub download is not available offline)" % (WEIGHTS_NAME, path))
+            state_dict = torch.load(f, map_location="cpu")
+        partial = set(getattr(config, "partial_load", ()) or ())
+        own = {n: model._p[n] for n in model._names}
+        with torch.no_grad():
+            for key, val in state_dict.items():
+                tgt_name = "model.shared.weight" if key in _TIED else key
+                if key == "final_logits_bias":
+                    tgt = model._flb
+                elif tgt_name in own:
+                    tgt = own[tgt_name]
+                else:
+                    continue
+                if tuple(tgt.shape) == tuple(val.shape):
+                    tgt.copy_(val)
+                elif key in partial and val.dim() == tgt.dim() and all(a <= b for a, b in zip(val.shape, tgt.shape)):
+                    tgt[tuple(slice(0, s) for s in val.shape)] = val
+        model.eval()
+        return model
+
+
+def _top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("inf"), min_tokens_to_keep=1):
+    """transformers 3.0.2 `top_k_top_p_filtering` (sampling path of generate)."""
+    if top_k > 0:
+        top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
+        remove = logits < torch.topk(logits, top_k)[0][..., -1, None]
+        logits[remove] = filter_value
+    if top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        cum = torch.cumsum(torch.softmax(sorted_logits, dim=-1), dim=-1)
+        rm = cum > top_p
+        if min_tokens_to_keep > 1:
+            rm[..., :min_tokens_to_keep] = 0
+        rm[..., 1:] = rm[..., :-1].clone()
+        rm[..., 0] = 0
+        remove = rm.scatter(1, sorted_indices, rm)
+        logits[remove] = filter_value
+    return logits
+
+
+MultiModalBartModel = MultiModalBartForConditionalGeneration  # the bare model shares the engine

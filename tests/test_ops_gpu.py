@@ -1,0 +1,398 @@
+"""GPU: every HIP kernel, called through the C-ABI, against a plain PyTorch fp32 computation of the same
+op on the same (bf16-rounded) inputs.  Tolerances: fp32 outputs differ from the reference only by
+accumulation order (<= 1e-4 relative); bf16 outputs carry one bf16 rounding (2^-9 = 2e-3)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from kmbart import _lib  # noqa: E402
+from kmbart._lib import KmbAdamW, KmbAttnDecode, KmbDrop, check, ptr  # noqa: E402
+from gpu_util import DEV, attn_struct, bf, dropout_mask, gemm, rel_err, stream  # noqa: E402
+
+BF_TOL = 4e-3
+F32_TOL = 1e-4
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+# --------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (64, 768, 768), (1024, 2304, 768), (37, 50320, 128)])
+def test_gemm_forward_layout(M, N, K):
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))
+    bias = rnd(N, seed=3)
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    outb = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    gemm(A, B, bias=bias, out_f32=out, out_bf16=outb)
+    ref = A.float() @ B.float().t() + bias
+    assert rel_err(out, ref) < F32_TOL
+    assert rel_err(outb, ref) < BF_TOL
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric B catches transposed / permuted fragment maps exactly."""
+    n = 128
+    A = bf(torch.eye(n, device=DEV))
+    B = bf((torch.arange(n * n, device=DEV).view(n, n) % 251).float() - 125.0)  # exact in bf16
+    out = torch.empty((n, n), dtype=torch.float32, device=DEV)
+    gemm(A, B, out_f32=out)
+    assert torch.equal(out, B.float().t().contiguous())
+    gemm(A, B, b_kc=False, out_f32=out)          # B stored [K, N]
+    assert torch.equal(out, B.float())
+    gemm(A, B, a_kc=False, b_kc=False, out_f32=out)  # A stored [K, M] (identity either way)
+    assert torch.equal(out, B.float())
+    gemm(B, A, a_kc=False, b_kc=False, out_f32=out)  # A = B stored [K, M] -> logical A = B^T
+    assert torch.equal(out, B.float().t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (100, 264, 200), (64, 2056, 768)])
+def test_gemm_dgrad_layout(M, N, K):
+    """dX[M,N] = dY[M,K] W[K,N]: B operand is N-contiguous (a torch Linear weight read along its rows)."""
+    dY, W = bf(rnd(M, K, seed=4)), bf(rnd(K, N, seed=5, scale=0.1))
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    gemm(dY, W, a_kc=True, b_kc=False, out_f32=out)
+    assert rel_err(out, dY.float() @ W.float()) < F32_TOL
+
+
+@pytest.mark.parametrize("T,N,K", [(512, 768, 768), (72, 128, 2056), (1000, 264, 136), (9, 128, 64)])
+def test_gemm_wgrad_layout(T, N, K):
+    """dW[N,K] = dY[T,N]^T X[T,K]: both operands are read against their contiguous dimension."""
+    dY, X = bf(rnd(T, N, seed=6)), bf(rnd(T, K, seed=7))
+    out = torch.full((N, K), 7.0, dtype=torch.float32, device=DEV)
+    gemm(dY, X, a_kc=False, b_kc=False, out_f32=out)
+    ref = dY.float().t() @ X.float()
+    assert rel_err(out, ref) < F32_TOL
+    gemm(dY, X, a_kc=False, b_kc=False, out_f32=out, beta=1.0)  # accumulate
+    assert rel_err(out, 2 * ref) < F32_TOL
+
+
+def test_gemm_wgrad_unpadded_output():
+    """image-projection weight gradient: logical N = 2052 columns out of a 2056-wide padded operand."""
+    T, N, Kp, Kv = 72, 128, 2056, 2052
+    dY, X = bf(rnd(T, N, seed=8)), bf(rnd(T, Kp, seed=9))
+    out = torch.zeros((N, Kv), dtype=torch.float32, device=DEV)
+    gemm(dY, X, a_kc=False, b_kc=False, N=Kv, out_f32=out)
+    assert rel_err(out, (dY.float().t() @ X.float())[:, :Kv]) < F32_TOL
+
+
+def test_gemm_epilogues():
+    M, N, K = 192, 256, 128
+    A, B = bf(rnd(M, K, seed=10)), bf(rnd(N, K, seed=11, scale=0.2))
+    bias = rnd(N, seed=12)
+    base = A.float() @ B.float().t() + bias
+    # q pre-scale on the first columns
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    gemm(A, B, bias=bias, col_scale=0.125, col_scale_n=64, out_f32=out)
+    ref = base.clone()
+    ref[:, :64] *= 0.125
+    assert rel_err(out, ref) < F32_TOL
+    # exact GeLU + stored pre-activation
+    pre = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    gemm(A, B, bias=bias, act=1, preact=pre, out_f32=out)
+    assert rel_err(out, F.gelu(base)) < F32_TOL
+    assert rel_err(pre, base) < BF_TOL
+    # multiply by GeLU'(aux)
+    u = bf(rnd(M, N, seed=13))
+    gemm(A, B, act=2, aux=u, out_f32=out)
+    uu = u.float().requires_grad_(True)
+    F.gelu(uu).sum().backward()
+    assert rel_err(out, (A.float() @ B.float().t()) * uu.grad) < F32_TOL
+    # residual
+    res = bf(rnd(M, N, seed=14))
+    gemm(A, B, bias=bias, residual=res, out_f32=out)
+    assert rel_err(out, base + res.float()) < F32_TOL
+    # dropout before the residual; mask must be the generator's mask for that seed
+    gemm(A, B, bias=bias, drop_p=0.25, drop_seed=1234, residual=res, out_f32=out)
+    keep = dropout_mask(1234, 0.25, M, N)
+    scale = 1.0 / (1.0 - round(0.25 * 65536) / 65536.0)
+    assert rel_err(out, torch.where(keep, base * scale, torch.zeros_like(base)) + res.float()) < F32_TOL
+    assert abs(float(keep.float().mean()) - 0.75) < 0.01
+
+
+# ------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, key_mask, causal):
+    """q [B,H,Tq,64] (already scaled), fp32; HF3.0.2 SelfAttention arithmetic."""
+    w = q @ k.transpose(-1, -2)
+    Tq, Tk = w.shape[-2:]
+    if causal:
+        w = w + torch.triu(torch.full((Tq, Tk), float("-inf"), device=w.device), 1)
+    if key_mask is not None:
+        w = w.masked_fill(key_mask[:, None, None, :] == 0, float("-inf"))
+    p = torch.softmax(w, dim=-1)
+    return p @ v
+
+
+ATTN_CASES = [
+    dict(B=2, H=2, Tq=64, Tk=64, causal=False, mask=False, fused=True),
+    dict(B=3, H=2, Tq=32, Tk=32, causal=True, mask=True, fused=True),
+    dict(B=2, H=3, Tq=32, Tk=64, causal=False, mask=True, fused=False),
+    dict(B=2, H=1, Tq=40, Tk=100, causal=False, mask=True, fused=False),
+    dict(B=1, H=2, Tq=130, Tk=130, causal=True, mask=False, fused=True),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(case):
+    B, H, Tq, Tk = case["B"], case["H"], case["Tq"], case["Tk"]
+    d = H * 64
+    lib = _lib.load()
+    if case["fused"]:  # self-attention: q|k|v interleaved rows of width 3d
+        qkv = bf(rnd(B * Tq, 3 * d, seed=20, scale=0.7))
+        Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    else:
+        Q = bf(rnd(B * Tq, d, seed=21, scale=0.7))
+        kv = bf(rnd(B * Tk, 2 * d, seed=22, scale=0.7))
+        K, V = kv[:, :d], kv[:, d:]
+    key_mask = None
+    if case["mask"]:
+        key_mask = torch.ones((B, Tk), dtype=torch.int64, device=DEV)
+        for b in range(B):
+            key_mask[b, Tk - 1 - 3 * b:] = 0  # right padding, different per sample; key 0 always kept
+    O = torch.zeros((B * Tq, d), dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros((B, H, Tq), dtype=torch.float32, device=DEV)
+    a = attn_struct(Q, K, V, B, H, Tq, Tk, key_mask, case["causal"], O, lse)
+    check(lib.kmb_op_attn_fwd(C.byref(a), stream()))
+
+    def heads(x, T):
+        return x.float().reshape(B, T, H, 64).transpose(1, 2)
+
+    qf = heads(Q, Tq).requires_grad_(True)
+    kf = heads(K, Tk).requires_grad_(True)
+    vf = heads(V, Tk).requires_grad_(True)
+    ref = ref_attention(qf, kf, vf, key_mask, case["causal"])
+    ref_rows = ref.transpose(1, 2).reshape(B * Tq, d)
+    assert rel_err(O, ref_rows) < 1e-2  # P is rounded to bf16 before P.V
+    w = qf @ kf.transpose(-1, -2)
+    if case["causal"]:
+        w = w + torch.triu(torch.full((Tq, Tk), float("-inf"), device=DEV), 1)
+    if key_mask is not None:
+        w = w.masked_fill(key_mask[:, None, None, :] == 0, float("-inf"))
+    assert torch.allclose(lse, torch.logsumexp(w, dim=-1).detach(), atol=2e-3)
+
+    # backward
+    dO = bf(rnd(B * Tq, d, seed=23))
+    ref.backward(heads(dO, Tq))
+    dQ = torch.zeros((B * Tq, d), dtype=torch.bfloat16, device=DEV)
+    dKV = torch.zeros((B * Tk, 2 * d), dtype=torch.bfloat16, device=DEV)
+    a.dO, a.lddo = ptr(dO), d
+    a.dQ, a.lddq = ptr(dQ), d
+    a.dK, a.dV, a.lddk, a.lddv = ptr(dKV), ptr(dKV[:, d:]), 2 * d, 2 * d
+    a.dq_scale = 0.125
+    check(lib.kmb_op_attn_bwd(C.byref(a), stream()))
+
+    def rows(x, T):
+        return x.transpose(1, 2).reshape(B * T, d)
+
+    assert rel_err(dQ, rows(qf.grad, Tq) * 0.125) < 2e-2
+    assert rel_err(dKV[:, :d], rows(kf.grad, Tk)) < 2e-2
+    assert rel_err(dKV[:, d:], rows(vf.grad, Tk)) < 2e-2
+
+
+def test_attention_decode():
+    lib = _lib.load()
+    R, H, Tk, Tmax = 6, 2, 37, 48
+    d = H * 64
+    q = bf(rnd(R, d, seed=30, scale=0.5))
+    Kc = bf(rnd(3, Tmax, d, seed=31, scale=0.5))
+    Vc = bf(rnd(3, Tmax, d, seed=32))
+    kv_row = torch.tensor([0, 0, 1, 1, 2, 2], dtype=torch.int32, device=DEV)
+    mask = torch.ones((3, Tmax), dtype=torch.int64, device=DEV)
+    mask[1, 30:] = 0
+    O = torch.zeros((R, d), dtype=torch.bfloat16, device=DEV)
+    a = KmbAttnDecode(Q=ptr(q), ldq=d, Kc=ptr(Kc), Vc=ptr(Vc), Tmax=Tmax, ldc=d, kv_row=ptr(kv_row),
+                      key_mask=ptr(mask), mask_ld=Tmax, mask_row=ptr(kv_row), R=R, H=H, Tk=Tk, O=ptr(O), ldo=d)
+    check(lib.kmb_op_attn_decode(C.byref(a), stream()))
+    for r in range(R):
+        c = int(kv_row[r])
+        for h in range(H):
+            s = Kc[c, :Tk, h * 64:(h + 1) * 64].float() @ q[r, h * 64:(h + 1) * 64].float()
+            s = s.masked_fill(mask[c, :Tk] == 0, float("-inf"))
+            ref = torch.softmax(s, 0) @ Vc[c, :Tk, h * 64:(h + 1) * 64].float()
+            assert rel_err(O[r, h * 64:(h + 1) * 64], ref) < BF_TOL
+
+
+# ----------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("M,D", [(70, 768), (33, 128), (16, 1024)])
+def test_layernorm_fwd_bwd(M, D):
+    lib = _lib.load()
+    z = bf(rnd(M, D, seed=40) * 2 + 0.3)
+    gamma, beta = rnd(D, seed=41) * 0.1 + 1.0, rnd(D, seed=42) * 0.1
+    y = torch.empty_like(z)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    check(lib.kmb_op_ln_fwd(ptr(z), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, D, 1e-5, stream()))
+    zf = z.float().requires_grad_(True)
+    gf, bfp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(zf, (D,), gf, bfp, 1e-5)
+    assert rel_err(y, ref) < BF_TOL
+    assert torch.allclose(mean, zf.mean(-1).detach(), atol=1e-5)
+    dy = bf(rnd(M, D, seed=43))
+    ref.backward(dy.float())
+    dz = torch.empty_like(z)
+    dg, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    scratch = torch.empty(int(lib.kmb_op_ln_bwd_scratch(M, D)), device=DEV)
+    check(lib.kmb_op_ln_bwd(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), None, None, None, ptr(dg),
+                            ptr(db), ptr(scratch), M, D, stream()))
+    assert rel_err(dz, zf.grad) < BF_TOL
+    assert rel_err(dg, gf.grad) < 1e-4
+    assert rel_err(db, bfp.grad) < 1e-4
+
+
+def test_layernorm_bwd_dropout_paths():
+    """dy_drop masks the incoming gradient (embedding LN output dropout); out2 is dz under a second mask."""
+    lib = _lib.load()
+    M, D = 48, 256
+    z = bf(rnd(M, D, seed=44))
+    gamma = torch.ones(D, device=DEV)
+    mean, rstd = z.float().mean(-1), (z.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+    dy = bf(rnd(M, D, seed=45))
+    dz, out2 = torch.empty_like(z), torch.empty_like(z)
+    dg, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    scratch = torch.empty(int(lib.kmb_op_ln_bwd_scratch(M, D)), device=DEV)
+    thr = round(0.1 * 65536)
+    sc = 1.0 / (1.0 - thr / 65536.0)
+    d1, d2 = KmbDrop(thr, 77, sc), KmbDrop(thr, 99, sc)
+    check(lib.kmb_op_ln_bwd(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), ptr(out2), C.byref(d1),
+                            C.byref(d2), ptr(dg), ptr(db), ptr(scratch), M, D, stream()))
+    k1, k2 = dropout_mask(77, 0.1, M, D), dropout_mask(99, 0.1, M, D)
+    zf = z.float().requires_grad_(True)
+    F.layer_norm(zf, (D,), gamma, None, 1e-5).backward(torch.where(k1, dy.float() * sc, torch.zeros(1, device=DEV)))
+    assert rel_err(dz, zf.grad) < BF_TOL
+    assert rel_err(out2, torch.where(k2, dz.float() * sc, torch.zeros(1, device=DEV))) < BF_TOL
+
+
+def test_colsum():
+    lib = _lib.load()
+    for M, N in [(1000, 768), (37, 72), (5000, 2304)]:
+        X = bf(rnd(M, N, seed=46))
+        out = torch.empty(N, device=DEV)
+        scratch = torch.empty(int(lib.kmb_op_colsum_scratch(M, N)), device=DEV)
+        check(lib.kmb_op_colsum(ptr(X), N, M, N, ptr(out), ptr(scratch), stream()))
+        assert rel_err(out, X.float().sum(0)) < 1e-4
+
+
+# ----------------------------------------------------------------------------------- embedding
+def test_embedding_forward_backward():
+    lib = _lib.load()
+    B, S, D, V, Fin, Fpad = 3, 20, 128, 300, 2052, 2056
+    IMG, CLS, PAD = 290, 293, 1
+    ids = torch.randint(3, 280, (B, S), device=DEV)
+    ids[0, 2:7] = IMG
+    ids[0, 4] = CLS
+    ids[1, 1:3] = IMG
+    ids[2, 5:9] = IMG      # sample 2 has placeholders but an EMPTY feature list -> stays token rows
+    ids[2, -1] = PAD
+    feat_off = torch.tensor([0, 5, 7, 7], dtype=torch.int32, device=DEV)
+    img_src = torch.empty(B * S, dtype=torch.int32, device=DEV)
+    status = torch.zeros(4, dtype=torch.int32, device=DEV)
+    check(lib.kmb_op_img_rowmap(ptr(ids), ptr(feat_off), B, S, IMG, CLS, ptr(img_src), ptr(status), stream()))
+    src = img_src.view(B, S).cpu()
+    assert src[0, 2:7].tolist() == [0, 1, 2, 3, 4] and src[1, 1:3].tolist() == [5, 6]
+    assert int((src[2] >= 0).sum()) == 0 and int(status[0]) == 0
+    bad_off = torch.tensor([0, 4, 6, 6], dtype=torch.int32, device=DEV)  # 4 features for 5 placeholders
+    check(lib.kmb_op_img_rowmap(ptr(ids), ptr(bad_off), B, S, IMG, CLS, ptr(img_src), ptr(status), stream()))
+    assert int(status[0]) & 1
+    check(lib.kmb_op_img_rowmap(ptr(ids), ptr(feat_off), B, S, IMG, CLS, ptr(img_src), ptr(status), stream()))
+
+    feats = rnd(7, Fin, seed=50).abs()
+    fb = torch.empty((7, Fpad), dtype=torch.bfloat16, device=DEV)
+    check(lib.kmb_op_cast_pad(ptr(feats), 7, Fin, ptr(fb), Fpad, stream()))
+    assert torch.equal(fb[:, :Fin], feats.to(torch.bfloat16)) and float(fb[:, Fin:].abs().sum()) == 0.0
+
+    E, P = rnd(V, D, seed=51, scale=0.05), rnd(S + 2, D, seed=52, scale=0.05)
+    img_emb = rnd(7, D, seed=53)
+    gamma, beta = rnd(D, seed=54) * 0.1 + 1, rnd(D, seed=55) * 0.1
+    M = B * S
+    z, y = torch.empty((M, D), dtype=torch.bfloat16, device=DEV), torch.empty((M, D), dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    check(lib.kmb_op_embed_ln_fwd(ptr(ids), ptr(img_src), ptr(E), ptr(img_emb), ptr(P), 2, S, 1.0, ptr(gamma),
+                                  ptr(beta), ptr(z), ptr(y), ptr(mean), ptr(rstd), M, D, 1e-5, None, stream()))
+    emb = E[ids.view(-1)].clone()
+    sel = img_src >= 0
+    emb[sel] = img_emb[img_src[sel].long()]
+    zr = emb + P[2:2 + S].repeat(B, 1)
+    assert rel_err(z, zr) < BF_TOL
+    assert rel_err(y, F.layer_norm(zr, (D,), gamma, beta, 1e-5)) < BF_TOL
+
+    dz = bf(rnd(M, D, seed=56))
+    dE = torch.zeros((V, D), device=DEV)
+    dimg = torch.zeros((7, D), dtype=torch.bfloat16, device=DEV)
+    check(lib.kmb_op_embed_bwd(ptr(dz), ptr(ids), ptr(img_src), 1.0, ptr(dE), ptr(dimg), PAD, M, D, stream()))
+    ref_dE = torch.zeros((V, D), device=DEV)
+    tok = (~sel) & (ids.view(-1) != PAD)
+    ref_dE.index_add_(0, ids.view(-1)[tok], dz.float()[tok])
+    assert rel_err(dE, ref_dE) < 1e-5
+    assert torch.equal(dimg[img_src[sel].long()], dz[sel])
+    dP = torch.full((S + 6, D), 3.0, device=DEV)
+    check(lib.kmb_op_pos_bwd(ptr(dz), B, S, D, ptr(dP), 2, S + 6, stream()))
+    assert rel_err(dP[2:2 + S], dz.float().view(B, S, D).sum(0)) < 1e-5
+    assert float(dP[:2].abs().sum()) == 0.0 and float(dP[2 + S:].abs().sum()) == 0.0
+
+
+# --------------------------------------------------------------------------------- loss / topk
+def test_cross_entropy_and_grad():
+    lib = _lib.load()
+    rows, V, ld = 50, 50320, 50432
+    logits = torch.zeros((rows, ld), device=DEV)
+    logits[:, :V] = rnd(rows, V, seed=60) * 3
+    logits[:, V:] = 1e30  # padding must be ignored
+    labels = torch.randint(0, V, (rows,), device=DEV)
+    labels[::7] = -100
+    loss_rows = torch.empty(rows, device=DEV)
+    dl = torch.empty((rows, ld), dtype=torch.bfloat16, device=DEV)
+    count = torch.zeros(4, dtype=torch.int32, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    check(lib.kmb_op_ce(ptr(logits), ld, V, ptr(labels), rows, 1.0, ptr(loss_rows), ptr(dl), ptr(count), ptr(loss), stream()))
+    lf = logits[:, :V].clone().requires_grad_(True)
+    ref = F.cross_entropy(lf, labels)
+    ref.backward()
+    assert int(count[0]) == int((labels != -100).sum())
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    assert rel_err(dl[:, :V], lf.grad) < BF_TOL
+    assert float(dl[:, V:].float().abs().sum()) == 0.0
+
+
+def test_logsoftmax_topk():
+    lib = _lib.load()
+    rows, V, ld, k = 10, 50320, 50432, 10
+    logits = torch.zeros((rows, ld), device=DEV)
+    logits[:, :V] = rnd(rows, V, seed=61) * 4
+    add = rnd(rows, seed=62)
+    val = torch.empty((rows, k), device=DEV)
+    idx = torch.empty((rows, k), dtype=torch.int32, device=DEV)
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, k, ptr(val), ptr(idx), stream()))
+    lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
+    rv, ri = torch.topk(lp, k, dim=1)
+    assert torch.equal(idx.long(), ri)
+    assert torch.allclose(val, rv, atol=1e-4)
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), 2, k, ptr(val), ptr(idx), stream()))
+    assert torch.all(idx[:, 0] == 2) and torch.allclose(val[:, 0], add, atol=1e-6)
+    assert torch.all(torch.isinf(val[:, 1:]))
+
+
+# ---------------------------------------------------------------------------------------- AdamW
+def test_adamw_matches_hf_form():
+    from oracle.kmbart_oracle import HFAdamW
+    lib = _lib.load()
+    n = 100003
+    p0 = rnd(n, seed=70)
+    p = p0.clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    ref_p = torch.nn.Parameter(p0.clone().cpu())
+    opt = HFAdamW([ref_p], lr=1e-3, eps=1e-6, weight_decay=0.01)
+    for step in range(1, 4):
+        g = rnd(n, seed=70 + step) * 0.1
+        hp = KmbAdamW(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.01, step=step, correct_bias=1, grad_scale=1.0)
+        check(lib.kmb_op_adamw(ptr(p), ptr(g), ptr(m), ptr(v), ptr(pb), n, C.byref(hp), stream()))
+        ref_p.grad = g.cpu()
+        opt.step()
+    assert torch.allclose(p.cpu(), ref_p.detach(), atol=2e-7, rtol=1e-6)
+    assert torch.equal(pb, p.to(torch.bfloat16))
