@@ -1,0 +1,214 @@
+"""KM-BART vcg_base training throughput on MI355X (BASELINE.json metric: training tokens/sec, whole node).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_PER_GPU]
+
+A step = forward (dropout 0.1 as config/vcg_base.json) + backward + gradient all-reduce (N > 1) + fused
+AdamW on one synthetic VCG batch per GPU (36 regions x 2052-d, 64 encoder tokens, 32 decoder tokens;
+SURVEY.md section 8d), inputs resident in HBM.  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; RCCL ("nccl") carries the all-reduce.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "km-bart_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+VCG_BASE = dict(  # reference config/vcg_base.json
+    activation_dropout=0.0, activation_function="gelu", attention_dropout=0.0, d_model=768,
+    decoder_attention_heads=12, decoder_ffn_dim=3072, decoder_layers=6, dropout=0.1, encoder_attention_heads=12,
+    encoder_ffn_dim=3072, encoder_layers=6, init_std=0.02, max_position_embeddings=1024, vocab_size=50320,
+    cls_token_id=50276, img_feat_id=50273, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+S_ENC, T_DEC, REGIONS = 64, 32, 36
+GFLOP_PER_TOKEN = 0.3822          # 36.69 GFLOP per training sample / 96 tokens
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n_steps=8, warmup=2):
+    """The oracle (CPU restatement of the reference path, --cpu semantics of vcg_train.py:62-64) timed on
+    this box's host cores: b=2, fp32, dropout 0.1, HF-AdamW.  Bounded sample of the same workload."""
+    from oracle import kmbart_oracle as O
+    from src.data.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig.from_dict(VCG_BASE)
+    model = O.OracleModel(cfg, seed=0).train()
+    opt = O.HFAdamW(model.parameters(), lr=1e-5)
+    b = make_batch(2, seed=1234)
+    times = []
+    for i in range(warmup + n_steps):
+        t0 = time.perf_counter()
+        loss = model(b["input_ids"], b["image_features"], b["attention_mask"],
+                     decoder_input_ids=b["decoder_input_ids"], decoder_attention_mask=b["decoder_attention_mask"],
+                     labels=b["labels"])[0]
+        loss.item()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(2 * (S_ENC + T_DEC) / med, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": "oracle (pure PyTorch fp32) b=2, S=64, T=32, 36 regions, %d timed steps, median %.3f s/step"
+                      % (n_steps, med)}
+
+
+def loss_parity(model, dev):
+    """CE-loss delta vs the fp32 oracle on BASELINE config 1 (b=2, dropout off, identical weights)."""
+    from oracle import kmbart_oracle as O
+    from src.data.synthetic import make_batch
+    cfg = O.OracleConfig.from_dict(dict(VCG_BASE, dropout=0.0))
+    sd = model.state_dict()
+    b = make_batch(2, seed=1234)
+    with torch.no_grad():
+        ref, _, _ = O.forward(sd, cfg, b["input_ids"], b["image_features"], b["attention_mask"],
+                              b["decoder_input_ids"], b["decoder_attention_mask"], b["labels"])
+        was = model.training
+        model.eval()
+        got = model(input_ids=b["input_ids"].to(dev), image_features=[f.to(dev) for f in b["image_features"]],
+                    attention_mask=b["attention_mask"].to(dev), decoder_input_ids=b["decoder_input_ids"].to(dev),
+                    decoder_attention_mask=b["decoder_attention_mask"].to(dev), labels=b["labels"].to(dev))[0]
+        model.train(was)
+    return abs(float(got) - float(ref)) / abs(float(ref)), float(got), float(ref)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--lr", type=float, default=1e-5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from kmbart import _lib
+    from kmbart.optim import AdamW
+    from kmbart.parallel import DistributedDataParallel
+    from src.data.synthetic import make_batch
+    from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration
+
+    torch.manual_seed(0)  # identical random-init weights on every rank (no checkpoints offline)
+    model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(VCG_BASE))
+    model.to(dev)
+    model._engine.set_seed(1234 + rank)
+    ddp = DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    ddp.train()
+    opt = AdamW(model.parameters(), lr=args.lr)
+
+    parity = None
+    if rank == 0 and args.gpus == 1:
+        parity = loss_parity(model, dev)
+
+    b = make_batch(args.batch, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=1234 + rank)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    batch["image_features"] = [f.to(dev) for f in b["image_features"]]
+    # packed once: the timed region starts with inputs resident in HBM (the list-of-tensors H2D + cat is row (f))
+    batch["image_features"] = list(torch.cat(batch["image_features"], 0).split(REGIONS))
+
+    def step():
+        loss = ddp.train_step_fwd_bwd(batch)
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    last_loss = float(loss)
+
+    tokens_per_step = world * args.batch * (S_ENC + T_DEC)
+    value = tokens_per_step * args.steps / dt
+    out = {
+        "metric": "train_tokens_per_sec", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "vcg_base train step (fwd+bwd+allreduce+AdamW), dropout 0.1, %d regions x 2052-d, "
+                               "%d enc tokens, %d dec tokens, random-init weights" % (REGIONS, S_ENC, T_DEC),
+                   "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                   "target_tokens_per_sec": round(world * args.batch * T_DEC * args.steps / dt, 1)},
+        "final_loss": round(last_loss, 4),
+        "model_tflops_per_gpu": round(value / world * GFLOP_PER_TOKEN / 1e3, 1),
+        "mfma_frac_whole_step": round(value / world * GFLOP_PER_TOKEN / 1e3 / PEAK_BF16_TFLOPS, 4),
+    }
+    if parity is not None:
+        out["ce_loss_rel_delta_vs_oracle_b2"] = float("%.3e" % parity[0])
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = the bf16 MFMA GEMM: time every launch of a few steps with HIP events on its stream
+        lib = _lib.load()
+        agg = {}
+        n_prof = 3
+        for _ in range(n_prof):
+            lib.kmb_profile_gemm(1)
+            step()
+            torch.cuda.synchronize()
+            for variant, name in ((3, "fwd"), (2, "dgrad"), (0, "wgrad")):
+                n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+                _lib.check(lib.kmb_profile_read(variant, C.byref(n), C.byref(ms), C.byref(fl)))
+                a = agg.setdefault(name, [0, 0.0, 0.0])
+                a[0] += n.value
+                a[1] += ms.value
+                a[2] += fl.value
+            lib.kmb_profile_gemm(0)
+        tot_ms = sum(a[1] for a in agg.values())
+        tot_fl = sum(a[2] for a in agg.values())
+        launches = sum(a[0] for a in agg.values())
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_kernel<A_KC,B_KC> (all GEMM launches of a step)",
+            "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
+            "gemm_ms_per_step": round(tot_ms / n_prof, 3),
+            "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),
+                               "tflops": round(a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None}
+                           for k, a in agg.items()},
+        }
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

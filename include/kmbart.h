@@ -157,6 +157,12 @@ int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const floa
                         float* out_val, int32_t* out_idx, void* stream);
 int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
 
+/* ================= measurement ================= */
+/* time every GEMM launch of the following calls with HIP events on its own stream (bench.py roofline leg);
+ * variant = a_kc*2 + b_kc: 3 forward (X W^T), 2 dgrad (dY W), 0 wgrad (dY^T X) */
+int kmb_profile_gemm(int enable);
+int kmb_profile_read(int variant, int64_t* launches, double* total_ms, double* total_flops);
+
 /* ================= single operators (unit tests / profiling) ================= */
 int kmb_op_gemm(const KmbGemm* p, void* stream);
 int kmb_op_attn_fwd(const KmbAttn* p, void* stream);

@@ -162,11 +162,33 @@ void add_ffn(kmb_handle* h, const std::string& p, int F, LayerP& L) {
   L.ln_b = add_param(h, p + "final_layer_norm.bias", 1, d);
 }
 
+// ---- optional per-launch timing of the GEMM kernels with HIP events (bench.py roofline leg) ----
+struct GemmProfiler {
+  bool on = false;
+  std::vector<hipEvent_t> ev;        // pairs
+  struct Rec { int variant; double flops; };
+  std::vector<Rec> recs;
+  size_t used = 0;
+} g_prof;
+
 KmbGemm gemm0() { KmbGemm g; memset(&g, 0, sizeof(g)); g.col_scale = 1.f; g.drop_scale = 1.f; return g; }
 
 int run_gemm(const KmbGemm& g, hipStream_t s) {
   const char* why = kmb_gemm_check(g);
   if (why) return fail("%s (M=%d N=%d K=%d lda=%d ldb=%d akc=%d bkc=%d)", why, g.M, g.N, g.K, g.lda, g.ldb, g.a_kc, g.b_kc);
+  if (g_prof.on) {
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+      const size_t old = g_prof.ev.size();
+      g_prof.ev.resize(old + 512);
+      for (size_t i = old; i < g_prof.ev.size(); ++i) HIPCHK(hipEventCreate(&g_prof.ev[i]));
+    }
+    HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], s));
+    HIPCHK(kmb_gemm_launch(g, s));
+    HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
+    g_prof.used += 2;
+    g_prof.recs.push_back({g.a_kc * 2 + g.b_kc, 2.0 * g.M * g.N * (double)g.K});
+    return 0;
+  }
   HIPCHK(kmb_gemm_launch(g, s));
   return 0;
 }
@@ -760,6 +782,26 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   }
   HIPCHK(hipEventRecord(h->events[ev++], s));
   HIPCHK(hipEventRecord(h->events[ev++], s));  // tied matrix: complete once the encoder-side scatter-add is in
+  return 0;
+}
+
+int kmb_profile_gemm(int enable) {
+  g_prof.on = enable != 0;
+  if (enable) { g_prof.used = 0; g_prof.recs.clear(); }
+  return 0;
+}
+
+// variant index = a_kc*2 + b_kc (3: forward, 2: dgrad, 0: wgrad).  Synchronises the events.
+int kmb_profile_read(int variant, int64_t* launches, double* total_ms, double* total_flops) {
+  int64_t n = 0; double ms = 0, fl = 0;
+  for (size_t i = 0; i < g_prof.recs.size(); ++i) {
+    if (g_prof.recs[i].variant != variant) continue;
+    float t = 0.f;
+    HIPCHK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    ms += t; fl += g_prof.recs[i].flops; ++n;
+  }
+  *launches = n; *total_ms = ms; *total_flops = fl;
   return 0;
 }
 

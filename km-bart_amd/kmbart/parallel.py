@@ -54,7 +54,10 @@ class BucketedAllReducer:
         with ctx:
             for i, off, cnt in self.pieces:
                 if self.wait_ready is not None and i not in waited:
-                    self.wait_ready(i, self.comm_stream if self.comm_stream is not None else torch.cuda.current_stream())
+                    stream = self.comm_stream
+                    if stream is None and on_gpu:
+                        stream = torch.cuda.current_stream()
+                    self.wait_ready(i, stream)
                     waited.add(i)
                 piece = self.flat[off: off + cnt]
                 w = dist.all_reduce(piece, op=op, group=self.group, async_op=True)

@@ -1,0 +1,122 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/kmbart.h declares; the
+parameter census behind it matches the reference's state-dict names and sizes."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+from kmbart import _lib
+from kmbart._lib import KmbConfig, check
+from oracle import kmbart_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VCG_BASE = dict(vocab_size=50320, d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12,
+                decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072, max_position_embeddings=1024,
+                extra_pos_embeddings=2, image_feature_size=2052, pad_token_id=1, bos_token_id=0, eos_token_id=2,
+                img_feat_id=50273, cls_token_id=50276, scale_embedding=0, dropout=0.1, attention_dropout=0.0,
+                activation_dropout=0.0, layer_norm_eps=1e-5)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, "include", "kmbart.h")).read()
+    declared = set(re.findall(r"\b(kmb_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 40
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libkmbart_hip.so does not export %s" % name
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert lib.kmb_version() >= 1
+
+
+def test_parameter_census_matches_reference_names(lib):
+    h = C.c_void_p()
+    cfg = KmbConfig(**VCG_BASE)
+    check(lib.kmb_create(C.byref(cfg), C.byref(h)))
+    try:
+        assert lib.kmb_arena_elems(h) == 141039360  # SURVEY.md section 2.4 census
+        ocfg = O.OracleConfig.from_dict({k: v for k, v in VCG_BASE.items()})
+        want = {n: O.param_shape(ocfg, n) for n in O.param_names(ocfg)}
+        name, off, rows, cols = C.c_char_p(), C.c_int64(), C.c_int32(), C.c_int32()
+        got, spans = {}, []
+        for i in range(lib.kmb_param_count(h)):
+            check(lib.kmb_param_info(h, i, C.byref(name), C.byref(off), C.byref(rows), C.byref(cols)))
+            got[name.value.decode()] = (rows.value, cols.value)
+            spans.append((off.value, rows.value * cols.value))
+        assert set(got) == set(want)
+        for n, shp in want.items():
+            r, c = got[n]
+            assert (r * c) == int(__import__("numpy").prod(shp)), n
+            assert (c,) == tuple(shp) if len(shp) == 1 else (r, c) == tuple(shp), n
+        spans.sort()
+        for (o1, n1), (o2, _) in zip(spans, spans[1:]):
+            assert o1 + n1 <= o2 and o1 % 64 == 0
+        # q|k|v are adjacent so that one GEMM serves the fused projection
+        idx = {n: i for i, n in enumerate(sorted(got, key=lambda n: dict(zip(got, range(len(got))))[n]))}
+        assert idx  # names iterate in arena order
+        total = 0
+        o, n = C.c_int64(), C.c_int64()
+        for i in range(lib.kmb_bucket_count(h)):
+            check(lib.kmb_bucket_range(h, i, C.byref(o), C.byref(n)))
+            total += n.value
+        assert total == 141039360 and lib.kmb_bucket_count(h) == 6 + 6 + 3
+        assert lib.kmb_logits_ld(h) == 50432
+        ws = lib.kmb_workspace_bytes(h, 2, 64, 32, 72)
+        assert 10 << 20 < ws < 200 << 20
+    finally:
+        lib.kmb_destroy(h)
+
+
+def test_unsupported_configs_fail_loudly(lib):
+    h = C.c_void_p()
+    bad = dict(VCG_BASE, d_model=1024)  # head_dim != 64
+    assert lib.kmb_create(C.byref(KmbConfig(**bad)), C.byref(h)) != 0
+    assert b"head_dim" in lib.kmb_last_error()
+    bad = dict(VCG_BASE, attention_dropout=0.1)
+    assert lib.kmb_create(C.byref(KmbConfig(**bad)), C.byref(h)) != 0
+
+
+def test_unbound_handle_refuses_to_run(lib):
+    h = C.c_void_p()
+    check(lib.kmb_create(C.byref(KmbConfig(**VCG_BASE)), C.byref(h)))
+    try:
+        b = _lib.KmbBatch(B=1, S=8, T=4)
+        assert lib.kmb_forward(h, C.byref(b), 0, 0, None, None, None, None) != 0
+        assert b"not bound" in lib.kmb_last_error()
+        assert lib.kmb_backward(h, 1.0, None) != 0
+    finally:
+        lib.kmb_destroy(h)
+
+
+def test_no_cpu_fallback():
+    import torch
+    from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = MultiModalBartConfig.from_dict(dict(vocab_size=512, d_model=128, encoder_layers=1, decoder_layers=1,
+                                              encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=128,
+                                              decoder_ffn_dim=128, max_position_embeddings=32, img_feat_id=488,
+                                              cls_token_id=491))
+    model = MultiModalBartForConditionalGeneration(cfg)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model(input_ids=torch.zeros((1, 4), dtype=torch.long), image_features=[torch.empty(0)])
+    with pytest.raises(RuntimeError):
+        model.to("cuda:0")
+    src_files = []
+    for base, _, files in os.walk(os.path.join(ROOT, "km-bart_amd")):
+        src_files += [os.path.join(base, f) for f in files if f.endswith(".py")]
+    for f in src_files + [os.path.join(ROOT, "bench.py")]:
+        if not os.path.exists(f):
+            continue
+        text = open(f).read()
+        if f.endswith("bench.py"):
+            continue  # bench.py may use the oracle for its cpu_baseline leg only
+        assert "oracle" not in text.replace("# oracle", ""), "product file %s mentions the oracle" % f

