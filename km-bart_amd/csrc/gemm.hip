@@ -14,6 +14,7 @@
 //                             f(r) = (r&3) | ((r>>3)&1)<<2                           (ds_read_b64_tr_b16)
 // The epilogue round-trips the fp32 accumulators through LDS so that bias / GeLU / dropout /
 // residual math and the stores run row-major with 16-byte accesses.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -88,62 +89,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
   }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 15, g = lane >> 4;
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-  const int row0 = tm * BM, col0 = tn * BN;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nt = (p.K + BK - 1) / BK;
-  u32x4 ra[4], rb[4];
-  load_tile<A_KC>(p.A, p.lda, row0, p.M, 0, p.K, tid, ra);
-  load_tile<B_KC>(p.B, p.ldb, col0, p.N, 0, p.K, tid, rb);
-  store_tile<A_KC>(smem, tid, ra);
-  store_tile<B_KC>(smem + BM * BK * 2, tid, rb);
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * STAGE_BYTES;
-    char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-    const bool more = (t + 1) < nt;
-    if (more) {
-      load_tile<A_KC>(p.A, p.lda, row0, p.M, (t + 1) * BK, p.K, tid, ra);
-      load_tile<B_KC>(p.B, p.ldb, col0, p.N, (t + 1) * BK, p.K, tid, rb);
-    }
-    const char* la = cur;
-    const char* lb = cur + BM * BK * 2;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(la, wm * 4 + i, kk, r, g);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(lb, wn * 4 + j, kk, r, g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      store_tile<A_KC>(nxt, tid, ra);
-      store_tile<B_KC>(nxt + BM * BK * 2, tid, rb);
-    }
-    __syncthreads();
-  }
-
+__device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x4 (&acc)[4][4], int tid, int wm, int wn,
+                                              int r, int g, int row0, int col0) {
   // ---- epilogue phase 1: accumulators -> LDS fp32 [128][EPI_LD] ----
   float* ef = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -239,6 +186,149 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
   }
 }
 
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (p.K + BK - 1) / BK;
+  u32x4 ra[4], rb[4];
+  load_tile<A_KC>(p.A, p.lda, row0, p.M, 0, p.K, tid, ra);
+  load_tile<B_KC>(p.B, p.ldb, col0, p.N, 0, p.K, tid, rb);
+  store_tile<A_KC>(smem, tid, ra);
+  store_tile<B_KC>(smem + BM * BK * 2, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * STAGE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+    const bool more = (t + 1) < nt;
+    if (more) {
+      load_tile<A_KC>(p.A, p.lda, row0, p.M, (t + 1) * BK, p.K, tid, ra);
+      load_tile<B_KC>(p.B, p.ldb, col0, p.N, (t + 1) * BK, p.K, tid, rb);
+    }
+    const char* la = cur;
+    const char* lb = cur + BM * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(la, wm * 4 + i, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(lb, wn * 4 + j, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<A_KC>(nxt, tid, ra);
+      store_tile<B_KC>(nxt + BM * BK * 2, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0);
+}
+
+// ------------------------------------------------------------------------------------------
+// v2: same tile / fragment maps, but the global->LDS staging is LDS-DMA (global_load_lds, 16 B per
+// lane): no staging VGPRs and no ds_write pass.  A wave instruction writes 1 KiB of LDS linearly
+// (base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE address instead: lane i of
+// piece p lands on physical chunk (i % 8 or i % 16) of its row and therefore fetches the LOGICAL
+// chunk that the swizzle maps there.  Requires K % 64 == 0 (no zero-fill on this path).
+template <bool KC>
+__device__ __forceinline__ void glds_tile(char* lds_tile, const bf16_t* __restrict__ X, int ld, int r0, int R, int k0,
+                                          int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;  // 16 pieces of 1 KiB per 16 KiB tile
+    const bf16_t* src;
+    if (KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      int grow = r0 + row;
+      grow = grow < R ? grow : R - 1;
+      src = X + (size_t)grow * ld + k0 + c * 8;
+    } else {
+      const int krow = piece * 4 + (lane >> 4);
+      const int ps = lane & 15;
+      const int c32 = (ps >> 1) ^ swz_nkc(krow);
+      int m = r0 + c32 * 16 + (ps & 1) * 8;
+      const int mlast = ((R - 1) >> 3) << 3;
+      m = m < R ? m : mlast;
+      src = X + (size_t)(k0 + krow) * ld + m;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / BK;
+  glds_tile<A_KC>(smem, p.A, p.lda, row0, p.M, 0, wave, lane);
+  glds_tile<B_KC>(smem + BM * BK * 2, p.B, p.ldb, col0, p.N, 0, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * STAGE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+    if (t + 1 < nt) {
+      glds_tile<A_KC>(nxt, p.A, p.lda, row0, p.M, (t + 1) * BK, wave, lane);
+      glds_tile<B_KC>(nxt + BM * BK * 2, p.B, p.ldb, col0, p.N, (t + 1) * BK, wave, lane);
+    }
+    const char* la = cur;
+    const char* lb = cur + BM * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(la, wm * 4 + i, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(lb, wn * 4 + j, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0);
+}
+
 }  // namespace
 
 const char* kmb_gemm_check(const KmbGemm& p) {
@@ -268,6 +358,20 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
+  }
+  static int use_v2 = -1;
+  if (use_v2 < 0) {
+    const char* e = getenv("KMB_GEMM_V1");
+    use_v2 = (e && e[0] == '1') ? 0 : 1;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  }
+  if (use_v2 && (p.K % BK) == 0) {
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, true>), grid, block, LDS_BYTES, stream, p);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, false>), grid, block, LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel_v2<false, false>), grid, block, LDS_BYTES, stream, p);
+    return hipGetLastError();
   }
   if (p.a_kc && p.b_kc) {
     hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, LDS_BYTES, stream, p);

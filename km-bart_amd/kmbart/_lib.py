@@ -3,6 +3,9 @@ there is no CPU fallback for the hot path."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: torch bundles its own HIP runtime (libamdhip64.so.7); loading ours
+#                              before it would map a second runtime from /opt/rocm and break stream sharing
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libkmbart_hip.so")
 

@@ -126,7 +126,6 @@ def test_vcg_base_loss_parity_b2():
     ocfg = O.OracleConfig.from_dict(base)
     sd = O.init_state_dict(ocfg, seed=0)
     b = make_batch(2, seed=1234)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     with torch.no_grad():
         ref_loss, ref_logits, ref_enc = O.forward(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"],
                                                   b["decoder_input_ids"], b["decoder_attention_mask"], b["labels"])
