@@ -67,6 +67,7 @@ typedef struct KmbGemm {
   const kmb_bf16* residual; int32_t ld_res;
   kmb_bf16* out_bf16; int32_t ld_out_bf16;
   float* out_f32; int32_t ld_out_f32; float beta;
+  int32_t split_k; float* slab;   /* split_k > 1: slice s writes raw fp32 accumulators to slab[s][M][N]; no epilogue */
 } KmbGemm;
 
 /* ---- fused attention (csrc/attention.hip) -------------------------------------------------- */

@@ -42,7 +42,7 @@ int kmb_op_ln_fwd(const kmb_bf16* z, const float* gamma, const float* beta, kmb_
                   int M, int D, float eps, void* stream) {
   return hipfail(kmb_ln_fwd_launch(z, gamma, beta, y, mean, rstd, M, D, eps, (hipStream_t)stream), "ln_fwd");
 }
-int64_t kmb_op_ln_bwd_scratch(int M, int D) { return (int64_t)kmb_ln_bwd_parts(M) * 2 * D; }
+int64_t kmb_op_ln_bwd_scratch(int M, int D) { return (int64_t)kmb_ln_bwd_parts(M) * 3 * D; }
 int kmb_op_ln_bwd(const kmb_bf16* dy, const kmb_bf16* z, const float* mean, const float* rstd, const float* gamma,
                   kmb_bf16* dz, kmb_bf16* out2, const KmbDrop* dy_drop, const KmbDrop* out2_drop, float* dgamma,
                   float* dbeta, float* scratch, int M, int D, void* stream) {
@@ -52,9 +52,9 @@ int kmb_op_ln_bwd(const kmb_bf16* dy, const kmb_bf16* z, const float* mean, cons
                                      out2_drop ? *out2_drop : none, scratch, M, D, s), "ln_bwd");
   if (rc) return rc;
   const int np = kmb_ln_bwd_parts(M);
-  rc = hipfail(kmb_reduce_parts_launch(scratch, np, 2 * D, dgamma, D, s), "ln_bwd reduce");
+  rc = hipfail(kmb_reduce_parts_launch(scratch, np, 3 * D, dgamma, D, s), "ln_bwd reduce");
   if (rc) return rc;
-  return hipfail(kmb_reduce_parts_launch(scratch + D, np, 2 * D, dbeta, D, s), "ln_bwd reduce");
+  return hipfail(kmb_reduce_parts_launch(scratch + D, np, 3 * D, dbeta, D, s), "ln_bwd reduce");
 }
 int64_t kmb_op_colsum_scratch(int M, int N) { return (int64_t)kmb_colsum_parts(M) * N; }
 int kmb_op_colsum(const kmb_bf16* X, int ld, int M, int N, float* out, float* scratch, void* stream) {

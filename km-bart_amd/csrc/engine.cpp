@@ -102,6 +102,7 @@ struct kmb_handle {
   int32_t* status = nullptr; float* loss_dev = nullptr;
   bf16_t *dhdec, *dyA, *dyB, *dz, *dsub, *du, *dqkv, *dcq, *dckv, *dob, *denc;
   float* parts = nullptr;
+  float* slab = nullptr; size_t slab_floats = 0;
   // ---- generation state
   struct Gen {
     bool active = false; int B = 0, S = 0, nb = 0, R = 0, Tmax = 0;
@@ -213,20 +214,42 @@ KmbGemm lin_wgrad(const bf16_t* dy, int lddy, const bf16_t* x, int ldx, float* d
   return g;
 }
 
+// Weight-gradient GEMMs have few output tiles (768x768 -> 36) and a very long reduction (all tokens):
+// split K over workgroups so that the grid fills the chip; partial slabs are summed by one pass.
+int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
+  const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const int nt = (g.K + 63) / 64;
+  int S = (384 + tiles - 1) / tiles;
+  if (S > 16) S = 16;
+  if (S > nt / 2) S = nt / 2;
+  while (S > 1 && (size_t)S * g.M * g.N > h->slab_floats) --S;
+  if (S <= 1 || g.ld_out_f32 != g.N || ((size_t)g.M * g.N & 3)) return run_gemm(g, s);
+  float* out = g.out_f32;
+  const float beta = g.beta;
+  g.split_k = S; g.slab = h->slab; g.out_f32 = nullptr; g.beta = 0.f;
+  KCHK(run_gemm(g, s));
+  HIPCHK(kmb_reduce_slabs_launch(h->slab, S, (size_t)g.M * g.N, out, (size_t)g.M * g.N, beta, s));
+  return 0;
+}
+
 int bias_grad(kmb_handle* h, const bf16_t* dy, int ld, int M, int N, float* out, hipStream_t s) {
   HIPCHK(kmb_colsum_launch(dy, ld, M, N, h->parts, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, kmb_colsum_parts(M), N, out, N, s));
   return 0;
 }
 
+constexpr size_t NO_BIAS = (size_t)-1;
+// bias_off: gradient slot of the bias of the linear that produced the (dropped) sub-layer output, or NO_BIAS
 int ln_backward(kmb_handle* h, const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, size_t g_off,
-                size_t b_off, bf16_t* dz, bf16_t* out2, KmbDrop dy_drop, KmbDrop out2_drop, int M, hipStream_t s) {
+                size_t b_off, bf16_t* dz, bf16_t* out2, KmbDrop dy_drop, KmbDrop out2_drop, int M, hipStream_t s,
+                size_t bias_off = NO_BIAS) {
   const int d = h->d;
+  if (b_off != g_off + (size_t)d) return fail("LayerNorm weight/bias are not adjacent in the arena");
   HIPCHK(kmb_ln_bwd_launch(dy, z, mean, rstd, h->pf(g_off), dz, out2, dy_drop, out2_drop, h->parts, M, d, s));
   const int np = kmb_ln_bwd_parts(M);
-  // partials are [np][2][d]: dgamma rows at stride 2d offset 0, dbeta at offset d
-  HIPCHK(kmb_reduce_parts_launch(h->parts, np, 2 * d, h->gf(g_off), d, s));
-  HIPCHK(kmb_reduce_parts_launch(h->parts + d, np, 2 * d, h->gf(b_off), d, s));
+  // partials are [np][3][d]: dgamma | dbeta (adjacent in the arena too: one reduce) | column sums of the sub-layer gradient
+  HIPCHK(kmb_reduce_parts_launch(h->parts, np, 3 * d, h->gf(g_off), 2 * d, s));
+  if (bias_off != NO_BIAS) HIPCHK(kmb_reduce_parts_launch(h->parts + 2 * d, np, 3 * d, h->gf(bias_off), d, s));
   return 0;
 }
 
@@ -235,11 +258,11 @@ size_t parts_floats(const kmb_handle* h, int Mmax) {
   int maxN = 3 * d;
   if (h->Fe > maxN) maxN = h->Fe;
   if (h->Fd > maxN) maxN = h->Fd;
-  size_t a = (size_t)kmb_ln_bwd_parts(Mmax) * 2 * d;
+  size_t a = (size_t)kmb_ln_bwd_parts(Mmax) * 3 * d;
   size_t b = (size_t)kmb_colsum_parts(Mmax) * maxN;
   // colsum parts grows for small M (rows_per_part floor): bound it
   if (b < (size_t)64 * maxN) b = (size_t)64 * maxN;
-  if (a < (size_t)512 * 2 * d) a = (size_t)512 * 2 * d;
+  if (a < (size_t)256 * 3 * d) a = (size_t)256 * 3 * d;
   return a > b ? a : b;
 }
 
@@ -288,7 +311,9 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   }
   const size_t CH = Md < (size_t)h->lm_chunk ? Md : (size_t)h->lm_chunk;
   float* logits_c = bp.take<float>(CH * h->Vpad);
-  bf16_t* dlogits_c = bp.take<bf16_t>(CH * h->Vpad);
+  bf16_t* dlogits_c = bp.take<bf16_t>(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
+  const size_t slab_floats = (size_t)8 << 20;           // split-K partial slabs of the weight-gradient GEMMs
+  float* slab = bp.take<float>(slab_floats);
   float* loss_rows = bp.take<float>(Md);
   bf16_t* dhdec = bp.take<bf16_t>(Md * d);
   bf16_t* dyA = bp.take<bf16_t>(Mmax * d); bf16_t* dyB = bp.take<bf16_t>(Mmax * d);
@@ -305,6 +330,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     H->xe = xe; H->xd = xd; H->ea = ea; H->da = da; H->logits_c = logits_c; H->dlogits_c = dlogits_c;
     H->loss_rows = loss_rows; H->dhdec = dhdec; H->dyA = dyA; H->dyB = dyB; H->dz = dz; H->dsub = dsub; H->du = du;
     H->dqkv = dqkv; H->dcq = dcq; H->dckv = dckv; H->dob = dob; H->denc = denc; H->parts = parts;
+    H->slab = slab; H->slab_floats = slab_floats;
   }
   return bp.used();
 }
@@ -363,14 +389,14 @@ int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const b
                  KmbDrop dr, hipStream_t s) {
   const int d = h->d;
   bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
-  KCHK(ln_backward(h, dy, z, mean, rstd, L.ln_g, L.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s));
-  KCHK(bias_grad(h, dsub, d, M, d, h->gf(L.fc2_b), s));
-  KCHK(run_gemm(lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
+  KCHK(ln_backward(h, dy, z, mean, rstd, L.ln_g, L.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
+                   L.fc2_b));
+  KCHK(run_wgrad(h, lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(L.fc2_w), M, d, F);
   g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = h->du; g.ld_out_bf16 = F;
   KCHK(run_gemm(g, s));
   KCHK(bias_grad(h, h->du, F, M, F, h->gf(L.fc1_b), s));
-  KCHK(run_gemm(lin_wgrad(h->du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
+  KCHK(run_wgrad(h, lin_wgrad(h->du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
   g = lin_dgrad(h->du, F, h->wb(L.fc1_w), M, F, d);
   g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
@@ -400,16 +426,16 @@ int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf
                        int T, const int64_t* mask, int causal, KmbDrop dr, hipStream_t s) {
   const int d = h->d, M = B * T;
   bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
-  KCHK(ln_backward(h, dy, z, mean, rstd, A.ln_g, A.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s));
-  KCHK(bias_grad(h, dsub, d, M, d, h->gf(A.o_b), s));
-  KCHK(run_gemm(lin_wgrad(dsub, d, o, d, h->gf(A.o_w), M, d, d, 0.f), s));
+  KCHK(ln_backward(h, dy, z, mean, rstd, A.ln_g, A.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
+                   A.o_b));
+  KCHK(run_wgrad(h, lin_wgrad(dsub, d, o, d, h->gf(A.o_w), M, d, d, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(A.o_w), M, d, d);
   g.out_bf16 = h->dob; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
   AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
   KCHK(attn_backward(h, io, B, H, o, lse, h->dob, h->dqkv, 3 * d, h->dqkv + d, h->dqkv + 2 * d, 3 * d, s));
   KCHK(bias_grad(h, h->dqkv, 3 * d, M, 3 * d, h->gf(A.qkv_b), s));
-  KCHK(run_gemm(lin_wgrad(h->dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
+  KCHK(run_wgrad(h, lin_wgrad(h->dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
   g = lin_dgrad(h->dqkv, 3 * d, h->wb(A.qkv_w), M, 3 * d, d);
   g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
@@ -665,16 +691,15 @@ int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad,
       KCHK(run_gemm(g, s));
       if (!bt.labels) continue;
       HIPCHK(kmb_ce_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, 1.f, h->loss_rows + r0,
-                           need_grad ? h->dlogits_c : nullptr, s));
-      if (need_grad) {
-        // dH = dlogits E  (reduction over the padded vocabulary; pad columns / rows are zero)
-        KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, rows, h->Vpad, d);
-        gd.out_bf16 = h->dhdec + (size_t)r0 * d; gd.ld_out_bf16 = d;
-        KCHK(run_gemm(gd, s));
-        // dE[V,d] (+)= dlogits^T H
-        KCHK(run_gemm(lin_wgrad(h->dlogits_c, h->Vpad, hdec + (size_t)r0 * d, d, h->gf(h->shared), rows, h->V, d,
-                                c == 0 ? 0.f : 1.f), s));
-      }
+                           need_grad ? h->dlogits_c + (size_t)r0 * h->Vpad : nullptr, s));
+    }
+    if (bt.labels && need_grad) {
+      // dH = dlogits E  (reduction over the padded vocabulary; pad columns / rows are zero)
+      KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, Md, h->Vpad, d);
+      gd.out_bf16 = h->dhdec; gd.ld_out_bf16 = d;
+      KCHK(run_gemm(gd, s));
+      // dE[V,d] = dlogits^T H  (overwrites: the embedding scatter-adds of backward come on top)
+      KCHK(run_wgrad(h, lin_wgrad(h->dlogits_c, h->Vpad, hdec, d, h->gf(h->shared), Md, h->V, d, 0.f), s));
     }
     if (bt.labels) {
       HIPCHK(kmb_loss_finish_launch(h->loss_rows, Md, h->count, h->loss_dev, s));
@@ -718,9 +743,8 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
       const KmbDrop dr = h->drop_site(101 + 3 * l, tr);
       bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
       KCHK(ln_backward(h, t0, a.z2, a.m2, a.r2, L.ca.ln_g, L.ca.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr,
-                       KmbDrop{0u, 0u, 1.f}, dr, Md, s));
-      KCHK(bias_grad(h, dsub, d, Md, d, h->gf(L.ca.o_b), s));
-      KCHK(run_gemm(lin_wgrad(dsub, d, a.o2, d, h->gf(L.ca.o_w), Md, d, d, 0.f), s));
+                       KmbDrop{0u, 0u, 1.f}, dr, Md, s, L.ca.o_b));
+      KCHK(run_wgrad(h, lin_wgrad(dsub, d, a.o2, d, h->gf(L.ca.o_w), Md, d, d, 0.f), s));
       KmbGemm g = lin_dgrad(dsub, d, h->wb(L.ca.o_w), Md, d, d);
       g.out_bf16 = h->dob; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
@@ -728,12 +752,12 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
       KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, h->dcq, d, h->dckv, h->dckv + d, 2 * d, s));
       // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn
       KCHK(bias_grad(h, h->dcq, d, Md, d, h->gf(L.ca.qkv_b), s));
-      KCHK(run_gemm(lin_wgrad(h->dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
+      KCHK(run_wgrad(h, lin_wgrad(h->dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
       g = lin_dgrad(h->dcq, d, h->wb(L.ca.qkv_w), Md, d, d);
       g.residual = h->dz; g.ld_res = d; g.out_bf16 = t1; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
       KCHK(bias_grad(h, h->dckv, 2 * d, Me, 2 * d, h->gf(L.ca.qkv_b) + d, s));
-      KCHK(run_gemm(lin_wgrad(h->dckv, 2 * d, enc, d, h->gf(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d, 0.f), s));
+      KCHK(run_wgrad(h, lin_wgrad(h->dckv, 2 * d, enc, d, h->gf(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d, 0.f), s));
       g = lin_dgrad(h->dckv, 2 * d, h->wb(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d);
       if (denc_init) { g.residual = h->denc; g.ld_res = d; }
       g.out_bf16 = h->denc; g.ld_out_bf16 = d;
@@ -775,7 +799,7 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   HIPCHK(kmb_pos_bwd_launch(h->dz, B, S, d, h->gf(h->enc_pos), h->cfg.extra_pos_embeddings, h->Prows, s));
   if (h->Ntot > 0) {
     KCHK(bias_grad(h, h->dimg, d, h->Ntot, d, h->gf(h->img_b), s));
-    KCHK(run_gemm(lin_wgrad(h->dimg, d, h->xf, h->Fpad, h->gf(h->img_w), h->Ntot, d, h->Fin, 0.f), s));
+    KCHK(run_wgrad(h, lin_wgrad(h->dimg, d, h->xf, h->Fpad, h->gf(h->img_w), h->Ntot, d, h->Fin, 0.f), s));
   } else {
     HIPCHK(hipMemsetAsync(h->gf(h->img_w), 0, ((size_t)d * h->Fin) * sizeof(float), s));
     HIPCHK(hipMemsetAsync(h->gf(h->img_b), 0, (size_t)d * sizeof(float), s));

@@ -90,7 +90,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
 }
 
 __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x4 (&acc)[4][4], int tid, int wm, int wn,
-                                              int r, int g, int row0, int col0) {
+                                              int r, int g, int row0, int col0, int slice) {
   // ---- epilogue phase 1: accumulators -> LDS fp32 [128][EPI_LD] ----
   float* ef = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -107,6 +107,22 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
   const int gcol = col0 + c8;
   if (gcol >= p.N) return;
   const int nvalid = (p.N - gcol) < 8 ? (p.N - gcol) : 8;
+  if (p.split_k > 1) {  // raw partial sums of this K slice -> slab[slice][M][N]
+    float* slab = p.slab + (size_t)slice * p.M * p.N;
+    for (int it = 0; it < 8; ++it) {
+      const int lrow = (tid >> 4) + 16 * it;
+      const int grow = row0 + lrow;
+      if (grow >= p.M) break;
+      float* o = slab + (size_t)grow * p.N + gcol;
+      if (nvalid == 8 && (p.N & 3) == 0) {
+        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8);
+        *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8 + 4);
+      } else {
+        for (int e = 0; e < nvalid; ++e) o[e] = ef[lrow * EPI_LD + c8 + e];
+      }
+    }
+    return;
+  }
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = (p.bias != nullptr && e < nvalid) ? p.bias[gcol + e] : 0.f;
@@ -195,7 +211,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int nsl = p.split_k > 1 ? p.split_k : 1;
+  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
   f32x4 acc[4][4];
@@ -204,10 +222,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = (p.K + BK - 1) / BK;
+  const int nt_all = (p.K + BK - 1) / BK;
+  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
+  const int nt = t_end - t_begin;
   u32x4 ra[4], rb[4];
-  load_tile<A_KC>(p.A, p.lda, row0, p.M, 0, p.K, tid, ra);
-  load_tile<B_KC>(p.B, p.ldb, col0, p.N, 0, p.K, tid, rb);
+  load_tile<A_KC>(p.A, p.lda, row0, p.M, t_begin * BK, p.K, tid, ra);
+  load_tile<B_KC>(p.B, p.ldb, col0, p.N, t_begin * BK, p.K, tid, rb);
   store_tile<A_KC>(smem, tid, ra);
   store_tile<B_KC>(smem + BM * BK * 2, tid, rb);
   __syncthreads();
@@ -217,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
     char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
     const bool more = (t + 1) < nt;
     if (more) {
-      load_tile<A_KC>(p.A, p.lda, row0, p.M, (t + 1) * BK, p.K, tid, ra);
-      load_tile<B_KC>(p.B, p.ldb, col0, p.N, (t + 1) * BK, p.K, tid, rb);
+      load_tile<A_KC>(p.A, p.lda, row0, p.M, (t_begin + t + 1) * BK, p.K, tid, ra);
+      load_tile<B_KC>(p.B, p.ldb, col0, p.N, (t_begin + t + 1) * BK, p.K, tid, rb);
     }
     const char* la = cur;
     const char* lb = cur + BM * BK * 2;
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
     __syncthreads();
   }
 
-  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0);
+  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -286,7 +306,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int nsl = p.split_k > 1 ? p.split_k : 1;
+  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
   f32x4 acc[4][4];
@@ -295,9 +317,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.K / BK;
-  glds_tile<A_KC>(smem, p.A, p.lda, row0, p.M, 0, wave, lane);
-  glds_tile<B_KC>(smem + BM * BK * 2, p.B, p.ldb, col0, p.N, 0, wave, lane);
+  const int nt_all = p.K / BK;
+  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
+  const int nt = t_end - t_begin;
+  glds_tile<A_KC>(smem, p.A, p.lda, row0, p.M, t_begin * BK, wave, lane);
+  glds_tile<B_KC>(smem + BM * BK * 2, p.B, p.ldb, col0, p.N, t_begin * BK, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -305,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
     char* cur = smem + (t & 1) * STAGE_BYTES;
     char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
     if (t + 1 < nt) {
-      glds_tile<A_KC>(nxt, p.A, p.lda, row0, p.M, (t + 1) * BK, wave, lane);
-      glds_tile<B_KC>(nxt + BM * BK * 2, p.B, p.ldb, col0, p.N, (t + 1) * BK, wave, lane);
+      glds_tile<A_KC>(nxt, p.A, p.lda, row0, p.M, (t_begin + t + 1) * BK, wave, lane);
+      glds_tile<B_KC>(nxt + BM * BK * 2, p.B, p.ldb, col0, p.N, (t_begin + t + 1) * BK, wave, lane);
     }
     const char* la = cur;
     const char* lb = cur + BM * BK * 2;
@@ -326,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0);
+  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
 }
 
 }  // namespace
@@ -346,12 +370,16 @@ const char* kmb_gemm_check(const KmbGemm& p) {
   if (p.out_f32 && ((uintptr_t)p.out_f32 & 15)) return "gemm: f32 output alignment";
   if (p.act == 2 && !p.aux) return "gemm: gelu-backward epilogue needs aux";
   if (!p.a_kc && p.b_kc) return "gemm: (M-contiguous A, K-contiguous B) is not instantiated";
+  if (p.split_k > 1) {
+    if (!p.slab || ((uintptr_t)p.slab & 15)) return "gemm: split-K needs a 16-byte aligned slab";
+    if (p.split_k > (p.K + BK - 1) / BK) return "gemm: more K slices than K steps";
+  }
   return nullptr;
 }
 
 hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles), block(256);
+  dim3 grid(tiles * (p.split_k > 1 ? p.split_k : 1)), block(256);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -24,7 +24,8 @@ hipError_t kmb_attn_decode_launch(const KmbAttnDecode& p, hipStream_t stream);
 // y = LN(z) * gamma + beta ; saves mean / rstd.  z, y bf16 [M, D]
 hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* beta, bf16_t* y,
                              float* mean, float* rstd, int M, int D, float eps, hipStream_t stream);
-// dz = LN backward; partial dgamma/dbeta go to `partials` [nparts][2][D] (nparts returned by kmb_ln_bwd_parts)
+// dz = LN backward; partial dgamma / dbeta / column-sums-of-(out2 or dz) go to `partials` [nparts][3][D]
+// (nparts returned by kmb_ln_bwd_parts)
 // dy_drop: dropout that was applied to the LN OUTPUT in forward (embedding LN), thr16 == 0 if none.
 // dz_drop: if out2 != null, out2 = dz * keep(out2 site) * scale (gradient of a dropped sub-layer output).
 int kmb_ln_bwd_parts(int M);
@@ -33,6 +34,8 @@ hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mea
                              float* partials, int M, int D, hipStream_t stream);
 // out[c] = sum_p partials[p*stride + c]  for c < n   (overwrites)
 hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride, float* out, int n,
+                                   hipStream_t stream);
+hipError_t kmb_reduce_slabs_launch(const float* slabs, int nslabs, size_t stride, float* out, size_t n, float beta,
                                    hipStream_t stream);
 // column sums of a bf16 matrix -> partials [nparts][N]; nparts = kmb_colsum_parts(M)
 int kmb_colsum_parts(int M);

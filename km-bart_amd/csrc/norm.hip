@@ -60,18 +60,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      bf16_t* __restrict__ out2, KmbDrop dy_drop, KmbDrop out2_drop,
                                                      float* __restrict__ partials, int M, int D, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [4][2][D]
+  float* red = reinterpret_cast<float*>(smem);  // [4][3][D]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nch = D >> 3;
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(M, r_begin + rows_per_block);
-  float dg[NCH][8], db[NCH][8], gm[NCH][8];
+  float dg[NCH][8], db[NCH][8], ds[NCH][8], gm[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      dg[i][e] = 0.f; db[i][e] = 0.f;
+      dg[i][e] = 0.f; db[i][e] = 0.f; ds[i][e] = 0.f;
       gm[i][e] = (c < nch) ? gamma[c * 8 + e] : 0.f;
     }
   }
@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
           }
           *reinterpret_cast<u32x4*>(out2 + (size_t)row * D + c * 8) = pack8(o);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ds[i][e] += o[e];  // column sums of the sub-layer gradient
       }
     }
   }
@@ -134,28 +136,58 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     if (c < nch) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(wave * 2 + 0) * D + c * 8 + e] = dg[i][e];
-        red[(wave * 2 + 1) * D + c * 8 + e] = db[i][e];
+        red[(wave * 3 + 0) * D + c * 8 + e] = dg[i][e];
+        red[(wave * 3 + 1) * D + c * 8 + e] = db[i][e];
+        red[(wave * 3 + 2) * D + c * 8 + e] = ds[i][e];
       }
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
+  for (int idx = threadIdx.x; idx < 3 * D; idx += 256) {
     const int which = idx / D, col = idx - which * D;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * D + col];
-    partials[((size_t)blockIdx.x * 2 + which) * D + col] = s;
+    for (int w = 0; w < 4; ++w) s += red[(w * 3 + which) * D + col];
+    partials[((size_t)blockIdx.x * 3 + which) * D + col] = s;
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ partials, int nparts, int stride,
+// out[c] = beta*out[c] + sum_p partials[p*stride + c].  Two shapes of the same reduction:
+//  (a) many partial rows, few columns (LayerNorm / bias gradients): 32 columns x 8 part-lanes per block
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ partials, int nparts, size_t stride,
                                                            float* __restrict__ out, int n) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= n) return;
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partials[(size_t)p * stride + c];
-  out[c] = s;
+  if (c < n) {
+#pragma unroll 8
+    for (int p = pl; p < nparts; p += 8) s += partials[(size_t)p * stride + c];
+  }
+  red[pl][cl] = s;
+  __syncthreads();
+  if (pl == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    out[c] = t;
+  }
+}
+//  (b) few slabs, many elements (split-K weight gradients): float4 per thread
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, size_t stride,
+                                                           float* __restrict__ out, size_t n4, float beta) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 a = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int s = 1; s < nslabs; ++s) {
+      const f32x4 b = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride)[i];
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    if (beta != 0.f) {
+      const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+      a[0] += beta * o[0]; a[1] += beta * o[1]; a[2] += beta * o[2]; a[3] += beta * o[3];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = a;
+  }
 }
 
 // grid (ceil(N/64), nparts); block 256 = 8 column chunks x 32 row lanes
@@ -208,7 +240,7 @@ hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* b
 }
 
 static int ln_bwd_rows_per_block(int M) {
-  int rpb = (M + 511) / 512;  // <= 512 blocks
+  int rpb = (M + 255) / 256;  // <= 256 blocks (one per CU): fewer partial rows to reduce
   if (rpb < 4) rpb = 4;
   return rpb;
 }
@@ -224,7 +256,7 @@ hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mea
   if ((D & 7) || D > 2048) return hipErrorInvalidValue;
   const int rpb = ln_bwd_rows_per_block(M);
   dim3 grid((M + rpb - 1) / rpb), block(256);
-  const size_t lds = (size_t)4 * 2 * D * sizeof(float);
+  const size_t lds = (size_t)4 * 3 * D * sizeof(float);
   if (D <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb);
   else if (D <= 1024)
@@ -237,7 +269,18 @@ hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mea
 hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride, float* out, int n,
                                    hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partials, nparts, stride, out, n);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, partials, nparts, (size_t)stride, out, n);
+  return hipGetLastError();
+}
+
+// out[i] = beta*out[i] + sum_s slabs[s*stride + i], n % 4 == 0, 16-byte aligned
+hipError_t kmb_reduce_slabs_launch(const float* slabs, int nslabs, size_t stride, float* out, size_t n, float beta,
+                                   hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if ((n & 3) || (stride & 3)) return hipErrorInvalidValue;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, nslabs, stride, out, n / 4, beta);
   return hipGetLastError();
 }
 

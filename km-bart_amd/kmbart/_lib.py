@@ -33,7 +33,8 @@ class KmbGemm(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("bias", c_p), ("col_scale", f32), ("col_scale_n", i32),
                 ("act", i32), ("preact", c_p), ("ld_preact", i32), ("aux", c_p), ("ld_aux", i32),
                 ("drop_thr16", u32), ("drop_seed", u32), ("drop_scale", f32), ("residual", c_p), ("ld_res", i32),
-                ("out_bf16", c_p), ("ld_out_bf16", i32), ("out_f32", c_p), ("ld_out_f32", i32), ("beta", f32)]
+                ("out_bf16", c_p), ("ld_out_bf16", i32), ("out_f32", c_p), ("ld_out_f32", i32), ("beta", f32),
+                ("split_k", i32), ("slab", c_p)]
 
 
 class KmbAttn(C.Structure):

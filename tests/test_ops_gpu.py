@@ -73,6 +73,15 @@ def test_gemm_wgrad_layout(T, N, K):
     assert rel_err(out, 2 * ref) < F32_TOL
 
 
+@pytest.mark.parametrize("T,N,K,S", [(1024, 256, 128, 4), (4096, 768, 768, 8), (640, 128, 136, 3)])
+def test_gemm_split_k_slabs(T, N, K, S):
+    """split-K: slice s writes its partial sums to slab[s]; the slabs add up to the full product."""
+    dY, X = bf(rnd(T, N, seed=15)), bf(rnd(T, K, seed=16))
+    slab = torch.full((S, N, K), 9.0, dtype=torch.float32, device=DEV)
+    gemm(dY, X, a_kc=False, b_kc=False, split_k=S, slab=slab)
+    assert rel_err(slab.sum(0), dY.float().t() @ X.float()) < F32_TOL
+
+
 def test_gemm_wgrad_unpadded_output():
     """image-projection weight gradient: logical N = 2052 columns out of a 2056-wide padded operand."""
     T, N, Kp, Kv = 72, 128, 2056, 2052
