@@ -89,8 +89,10 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
   }
 }
 
+template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x4 (&acc)[4][4], int tid, int wm, int wn,
                                               int r, int g, int row0, int col0, int slice) {
+  constexpr int RPP = NT / 16;  // rows per pass
   // ---- epilogue phase 1: accumulators -> LDS fp32 [128][EPI_LD] ----
   float* ef = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -110,7 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
   if (p.split_k > 1) {  // raw partial sums of this K slice -> slab[slice][M][N]
     float* slab = p.slab + (size_t)slice * p.M * p.N;
     for (int it = 0; it < 8; ++it) {
-      const int lrow = (tid >> 4) + 16 * it;
+      const int lrow = (tid >> 4) + RPP * it;
       const int grow = row0 + lrow;
       if (grow >= p.M) break;
       float* o = slab + (size_t)grow * p.N + gcol;
@@ -129,7 +131,7 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
 
 #pragma unroll 2
   for (int it = 0; it < 8; ++it) {
-    const int lrow = (tid >> 4) + 16 * it;
+    const int lrow = (tid >> 4) + RPP * it;
     const int grow = row0 + lrow;
     if (grow >= p.M) break;
     float v[8];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
     __syncthreads();
   }
 
-  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
+  gemm_epilogue<256>(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -350,7 +352,129 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  gemm_epilogue(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
+  gemm_epilogue<256>(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// v3: 256x128x64 tile, 512 threads = 8 waves (4x2, 64x64 each), THREE LDS stages filled by LDS-DMA two
+// K-steps ahead.  One raw s_barrier per K-step; the wait that precedes it is a COUNTED vmcnt (the six
+// newest LDS-DMA of the wave -- the tile after next -- stay in flight across the barrier), so HBM
+// latency is covered by two full compute phases instead of one.
+constexpr int BM3 = 256;
+constexpr int ST3 = (BM3 + BN) * BK * 2;          // 48 KB per stage
+constexpr int LDS3 = 3 * ST3;                     // 144 KB (>= 256 x EPI_LD fp32 epilogue staging)
+static_assert(LDS3 >= BM3 * EPI_LD * 4, "epilogue staging must fit the stage ring");
+
+template <bool KC, int ROWS>
+__device__ __forceinline__ void glds_tile3(char* lds_tile, const bf16_t* __restrict__ X, int ld, int r0, int R, int k0,
+                                           int wave, int lane) {
+  constexpr int PIECES = ROWS / 8;   // 1 KiB pieces per tile
+  constexpr int PER_WAVE = PIECES / 8;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int piece = wave * PER_WAVE + i;
+    const bf16_t* src;
+    if (KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      int grow = r0 + row;
+      grow = grow < R ? grow : R - 1;
+      src = X + (size_t)grow * ld + k0 + c * 8;
+    } else {
+      constexpr int LPR = ROWS / 8;            // lanes (16-byte slots) per k-row
+      const int krow = piece * (64 / LPR) + lane / LPR;
+      const int ps = lane % LPR;
+      const int c32 = (ps >> 1) ^ swz_nkc(krow);
+      int m = r0 + c32 * 16 + (ps & 1) * 8;
+      const int mlast = ((R - 1) >> 3) << 3;
+      m = m < R ? m : mlast;
+      src = X + (size_t)(k0 + krow) * ld + m;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <bool KC, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag3(const char* lds, int rowtile16, int kk, int r, int g) {
+  if (KC) {
+    const int row = rowtile16 * 16 + r;
+    const int c = kk * 4 + g;
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  } else {
+    bf16x8 out;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int krow = kk * 32 + g * 8 + hh * 4 + (r >> 2);
+      const int off = krow * (ROWS * 2) + ((rowtile16 ^ swz_nkc(krow)) << 5) + ((r & 3) << 3);
+      const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(lds + off));
+      out[hh * 4 + 0] = t[0]; out[hh * 4 + 1] = t[1]; out[hh * 4 + 2] = t[2]; out[hh * 4 + 3] = t[3];
+    }
+    return out;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nsl = p.split_k > 1 ? p.split_k : 1;
+  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm * BM3, col0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt_all = p.K / BK;
+  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
+  const int nt = t_end - t_begin;
+  constexpr int A_BYTES = BM3 * BK * 2;
+
+  glds_tile3<A_KC, BM3>(smem, p.A, p.lda, row0, p.M, t_begin * BK, wave, lane);
+  glds_tile3<B_KC, BN>(smem + A_BYTES, p.B, p.ldb, col0, p.N, t_begin * BK, wave, lane);
+  if (nt > 1) {
+    glds_tile3<A_KC, BM3>(smem + ST3, p.A, p.lda, row0, p.M, (t_begin + 1) * BK, wave, lane);
+    glds_tile3<B_KC, BN>(smem + ST3 + A_BYTES, p.B, p.ldb, col0, p.N, (t_begin + 1) * BK, wave, lane);
+  }
+  int st = 0;  // stage of tile t
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) {
+      const int s2 = st >= 1 ? st - 1 : 2;  // (st + 2) % 3: the stage read during the previous K-step
+      glds_tile3<A_KC, BM3>(smem + s2 * ST3, p.A, p.lda, row0, p.M, (t_begin + t + 2) * BK, wave, lane);
+      glds_tile3<B_KC, BN>(smem + s2 * ST3 + A_BYTES, p.B, p.ldb, col0, p.N, (t_begin + t + 2) * BK, wave, lane);
+    }
+    const char* la = smem + st * ST3;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag3<A_KC, BM3>(la, wm * 4 + i, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag3<B_KC, BN>(lb, wn * 4 + j, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    st = st == 2 ? 0 : st + 1;
+  }
+  __syncthreads();
+  gemm_epilogue<512>(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
 }
 
 }  // namespace
@@ -394,6 +518,22 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  }
+  static int use_v3 = -1;
+  if (use_v3 < 0) {
+    const char* e = getenv("KMB_GEMM_NO_V3");
+    use_v3 = (e && e[0] == '1') ? 0 : 1;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+  }
+  if (use_v2 && use_v3 && (p.K % BK) == 0 && p.M > 128) {
+    const int tiles3 = ((p.M + BM3 - 1) / BM3) * ((p.N + BN - 1) / BN);
+    dim3 grid3(tiles3 * (p.split_k > 1 ? p.split_k : 1)), block3(512);
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, true>), grid3, block3, LDS3, stream, p);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, false>), grid3, block3, LDS3, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel_v3<false, false>), grid3, block3, LDS3, stream, p);
+    return hipGetLastError();
   }
   if (use_v2 && (p.K % BK) == 0) {
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, true>), grid, block, LDS_BYTES, stream, p);
