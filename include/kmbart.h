@@ -163,6 +163,7 @@ int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams
  * variant = a_kc*2 + b_kc: 3 forward (X W^T), 2 dgrad (dY W), 0 wgrad (dY^T X) */
 int kmb_profile_gemm(int enable);
 int kmb_profile_read(int variant, int64_t* launches, double* total_ms, double* total_flops);
+int kmb_profile_dump(const char* path);   /* one text line per profiled GEMM launch */
 
 /* ================= single operators (unit tests / profiling) ================= */
 int kmb_op_gemm(const KmbGemm* p, void* stream);

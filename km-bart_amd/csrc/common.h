@@ -51,12 +51,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact (erf) GeLU, the reference's "activation_function": "gelu" (config/vcg_base.json:3)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-form GeLU, the reference's "activation_function": "gelu" (config/vcg_base.json:3).
+// erf via Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off level): one v_rcp + one v_exp
+// instead of libm's branchy erff -- the GeLU epilogue of a K=768 GEMM costs as much as its main loop otherwise.
+// Returns cdf = Phi(x) and e = exp(-x^2 / 2) (shared with the derivative).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  e = __expf(-z * z);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erf_abs = 1.0f - poly * t * e;      // erf(|x| / sqrt 2)
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return cdf + x * 0.39894228040143268f * e;
 }
 
 // ---- dropout: counter-based keep decision, identical in forward epilogues and backward ----

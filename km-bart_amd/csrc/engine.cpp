@@ -167,7 +167,7 @@ void add_ffn(kmb_handle* h, const std::string& p, int F, LayerP& L) {
 struct GemmProfiler {
   bool on = false;
   std::vector<hipEvent_t> ev;        // pairs
-  struct Rec { int variant; double flops; };
+  struct Rec { int variant; double flops; int M, N, K, split, act; };
   std::vector<Rec> recs;
   size_t used = 0;
 } g_prof;
@@ -187,7 +187,7 @@ int run_gemm(const KmbGemm& g, hipStream_t s) {
     HIPCHK(kmb_gemm_launch(g, s));
     HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
     g_prof.used += 2;
-    g_prof.recs.push_back({g.a_kc * 2 + g.b_kc, 2.0 * g.M * g.N * (double)g.K});
+    g_prof.recs.push_back({g.a_kc * 2 + g.b_kc, 2.0 * g.M * g.N * (double)g.K, g.M, g.N, g.K, g.split_k, g.act});
     return 0;
   }
   HIPCHK(kmb_gemm_launch(g, s));
@@ -826,6 +826,21 @@ int kmb_profile_read(int variant, int64_t* launches, double* total_ms, double* t
     ms += t; fl += g_prof.recs[i].flops; ++n;
   }
   *launches = n; *total_ms = ms; *total_flops = fl;
+  return 0;
+}
+
+// one line per GEMM launch of the profiled calls: variant M N K split act microseconds
+int kmb_profile_dump(const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return fail("kmb_profile_dump: cannot open %s", path);
+  for (size_t i = 0; i < g_prof.recs.size(); ++i) {
+    float t = 0.f;
+    HIPCHK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    const auto& r = g_prof.recs[i];
+    fprintf(f, "%d %d %d %d %d %d %.3f\n", r.variant, r.M, r.N, r.K, r.split, r.act, t * 1e3);
+  }
+  fclose(f);
   return 0;
 }
 

@@ -14,7 +14,10 @@
 //                             f(r) = (r&3) | ((r>>3)&1)<<2                           (ds_read_b64_tr_b16)
 // The epilogue round-trips the fp32 accumulators through LDS so that bias / GeLU / dropout /
 // residual math and the stores run row-major with 16-byte accesses.
+#include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <tuple>
 #include "common.h"
 #include "kernels.h"
 
@@ -90,10 +93,12 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
 }
 
 template <int NT>
+__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, int tid, int row0, int col0, int slice);
+
+template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x4 (&acc)[4][4], int tid, int wm, int wn,
                                               int r, int g, int row0, int col0, int slice) {
-  constexpr int RPP = NT / 16;  // rows per pass
-  // ---- epilogue phase 1: accumulators -> LDS fp32 [128][EPI_LD] ----
+  // ---- epilogue phase 1: accumulators -> LDS fp32 [rows][EPI_LD] ----
   float* ef = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -103,7 +108,12 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
       for (int q = 0; q < 4; ++q)
         ef[(wm * 64 + i * 16 + g * 4 + q) * EPI_LD + wn * 64 + j * 16 + r] = acc[i][j][q];
   __syncthreads();
+  gemm_epilogue_phase2<NT>(p, ef, tid, row0, col0, slice);
+}
 
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, int tid, int row0, int col0, int slice) {
+  constexpr int RPP = NT / 16;  // rows per pass
   // ---- phase 2: row-major math + 16-byte stores ----
   const int c8 = (tid & 15) * 8;
   const int gcol = col0 + c8;
@@ -477,6 +487,86 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const KmbGemm p) {
   gemm_epilogue<512>(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// v4: 256x256x64 tile, 512 threads = 8 waves (2x4), each wave 128x64 (8x4 MFMA tiles): 12 fragment reads per
+// 32 MFMAs instead of 8 per 16 -- the LDS read traffic per MFMA is what bounds the 64x64-per-wave kernels.
+// Two 64 KB stages filled by LDS-DMA; epilogue in two column halves (fp32 staging does not fit otherwise).
+constexpr int BM4 = 256, BN4 = 256;
+constexpr int ST4 = (BM4 + BN4) * BK * 2;   // 64 KB
+constexpr int LDS4 = (2 * ST4 > BM4 * EPI_LD * 4) ? 2 * ST4 : BM4 * EPI_LD * 4;
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, g = lane >> 4;
+  const int tiles_n = (p.N + BN4 - 1) / BN4;
+  const int nsl = p.split_k > 1 ? p.split_k : 1;
+  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm * BM4, col0 = tn * BN4;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt_all = p.K / BK;
+  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
+  const int nt = t_end - t_begin;
+  constexpr int A_BYTES = BM4 * BK * 2;
+
+  glds_tile3<A_KC, BM4>(smem, p.A, p.lda, row0, p.M, t_begin * BK, wave, lane);
+  glds_tile3<B_KC, BN4>(smem + A_BYTES, p.B, p.ldb, col0, p.N, t_begin * BK, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * ST4;
+    char* nxt = smem + ((t + 1) & 1) * ST4;
+    if (t + 1 < nt) {
+      glds_tile3<A_KC, BM4>(nxt, p.A, p.lda, row0, p.M, (t_begin + t + 1) * BK, wave, lane);
+      glds_tile3<B_KC, BN4>(nxt + A_BYTES, p.B, p.ldb, col0, p.N, (t_begin + t + 1) * BK, wave, lane);
+    }
+    const char* la = cur;
+    const char* lb = cur + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[8], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag3<B_KC, BN4>(lb, wn * 4 + j, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = read_frag3<A_KC, BM4>(la, wm * 8 + i, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // epilogue: two passes over the column halves; in pass h the waves with (wn >> 1) == h stage their accumulators
+  float* ef = reinterpret_cast<float*>(smem);
+  for (int h = 0; h < 2; ++h) {
+    if ((wn >> 1) == h) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            ef[(wm * 128 + i * 16 + g * 4 + q) * EPI_LD + (wn & 1) * 64 + j * 16 + r] = acc[i][j][q];
+    }
+    __syncthreads();
+    gemm_epilogue_phase2<512>(p, ef, tid, row0, col0 + h * 128, slice);
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 const char* kmb_gemm_check(const KmbGemm& p) {
@@ -501,52 +591,116 @@ const char* kmb_gemm_check(const KmbGemm& p) {
   return nullptr;
 }
 
+namespace {
+
+template <int V> struct Launch;
+hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
+  const int nsl = p.split_k > 1 ? p.split_k : 1;
+  if (variant == 4) {
+    const int tiles = ((p.M + BM4 - 1) / BM4) * ((p.N + BN4 - 1) / BN4);
+    dim3 grid(tiles * nsl), block(512);
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v4<true, true>), grid, block, LDS4, stream, p);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v4<true, false>), grid, block, LDS4, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel_v4<false, false>), grid, block, LDS4, stream, p);
+  } else if (variant == 3) {
+    const int tiles = ((p.M + BM3 - 1) / BM3) * ((p.N + BN - 1) / BN);
+    dim3 grid(tiles * nsl), block(512);
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, true>), grid, block, LDS3, stream, p);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, false>), grid, block, LDS3, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel_v3<false, false>), grid, block, LDS3, stream, p);
+  } else {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    dim3 grid(tiles * nsl), block(256);
+    if (variant == 2) {
+      if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, true>), grid, block, LDS_BYTES, stream, p);
+      else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, false>), grid, block, LDS_BYTES, stream, p);
+      else hipLaunchKernelGGL((gemm_kernel_v2<false, false>), grid, block, LDS_BYTES, stream, p);
+    } else {
+      if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
+      else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, LDS_BYTES, stream, p);
+      else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, LDS_BYTES, stream, p);
+    }
+  }
+  return hipGetLastError();
+}
+
+struct TuneKey {
+  int akc, bkc, M, N, K, split, act;
+  bool operator<(const TuneKey& o) const {
+    return std::tie(akc, bkc, M, N, K, split, act) < std::tie(o.akc, o.bkc, o.M, o.N, o.K, o.split, o.act);
+  }
+};
+std::map<TuneKey, int> g_best;
+
+bool writes_an_input(const KmbGemm& p) {
+  const void* outs[3] = {p.out_bf16, p.out_f32, p.preact};
+  const void* ins[4] = {p.A, p.B, p.residual, p.aux};
+  for (const void* o : outs)
+    if (o)
+      for (const void* i : ins)
+        if (i == o) return true;
+  return p.beta != 0.f;
+}
+
+}  // namespace
+
+// Every variant computes bit-identical results (same per-element accumulation order), so the choice is pure
+// speed: the first launch of a new shape times the eligible variants on the real operands (measure, don't guess).
 hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles * (p.split_k > 1 ? p.split_k : 1)), block(256);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int forced = -1, autotune = 1, verbose = 0;
+  if (forced < 0) {
+    const char* ev = getenv("KMB_GEMM_VARIANT");
+    forced = ev ? atoi(ev) : 0;
+    const char* ea = getenv("KMB_GEMM_AUTOTUNE");
+    if (ea && ea[0] == '0') autotune = 0;
+    verbose = getenv("KMB_GEMM_VERBOSE") != nullptr;
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
-  static int use_v2 = -1;
-  if (use_v2 < 0) {
-    const char* e = getenv("KMB_GEMM_V1");
-    use_v2 = (e && e[0] == '1') ? 0 : 1;
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  }
-  static int use_v3 = -1;
-  if (use_v3 < 0) {
-    const char* e = getenv("KMB_GEMM_NO_V3");
-    use_v3 = (e && e[0] == '1') ? 0 : 1;
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
   }
-  if (use_v2 && use_v3 && (p.K % BK) == 0 && p.M > 128) {
-    const int tiles3 = ((p.M + BM3 - 1) / BM3) * ((p.N + BN - 1) / BN);
-    dim3 grid3(tiles3 * (p.split_k > 1 ? p.split_k : 1)), block3(512);
-    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, true>), grid3, block3, LDS3, stream, p);
-    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, false>), grid3, block3, LDS3, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel_v3<false, false>), grid3, block3, LDS3, stream, p);
-    return hipGetLastError();
+  const bool dma_ok = (p.K % BK) == 0;           // LDS-DMA variants have no K-edge zero fill
+  const bool big = dma_ok && p.M > 128;
+  if (!dma_ok) return launch_variant(1, p, stream);
+  if (forced) {
+    int v = forced;
+    if ((v == 3 && !big) || (v == 4 && !(big && p.N > 128))) v = 2;
+    return launch_variant(v, p, stream);
   }
-  if (use_v2 && (p.K % BK) == 0) {
-    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, true>), grid, block, LDS_BYTES, stream, p);
-    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, false>), grid, block, LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel_v2<false, false>), grid, block, LDS_BYTES, stream, p);
-    return hipGetLastError();
+  if (!big || p.N <= 128) return launch_variant(2, p, stream);
+  const TuneKey key{p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act};
+  auto it = g_best.find(key);
+  if (it == g_best.end()) {
+    if (!autotune || writes_an_input(p)) return launch_variant(2, p, stream);
+    const int cands[2] = {2, 4};
+    float best_ms = 1e30f;
+    int best = 2;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_variant(2, p, stream);
+    for (int c : cands) {
+      hipError_t e = launch_variant(c, p, stream);  // warm
+      if (e != hipSuccess) return e;
+      (void)hipEventRecord(e0, stream);
+      for (int rep = 0; rep < 3; ++rep) (void)launch_variant(c, p, stream);
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess) return hipGetLastError();
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (verbose) fprintf(stderr, "[kmb gemm tune] akc=%d bkc=%d M=%d N=%d K=%d split=%d act=%d v%d %.1f us\n", p.a_kc,
+                           p.b_kc, p.M, p.N, p.K, p.split_k, p.act, c, ms / 3 * 1e3);
+      if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    it = g_best.emplace(key, best).first;
   }
-  if (p.a_kc && p.b_kc) {
-    hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
-  } else if (p.a_kc && !p.b_kc) {
-    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, LDS_BYTES, stream, p);
-  } else {
-    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, LDS_BYTES, stream, p);
-  }
-  return hipGetLastError();
+  return launch_variant(it->second, p, stream);
 }
