@@ -68,6 +68,7 @@ typedef struct KmbGemm {
   kmb_bf16* out_bf16; int32_t ld_out_bf16;
   float* out_f32; int32_t ld_out_f32; float beta;
   int32_t split_k; float* slab;   /* split_k > 1: slice s writes raw fp32 accumulators to slab[s][M][N]; no epilogue */
+  float* colsum;                  /* optional [ceil(M/128)][N]: per-128-row-block column sums of the stored values */
 } KmbGemm;
 
 /* ---- fused attention (csrc/attention.hip) -------------------------------------------------- */
@@ -82,6 +83,8 @@ typedef struct KmbAttn {
   const kmb_bf16* dO; int32_t lddo;
   kmb_bf16* dQ; kmb_bf16* dK; kmb_bf16* dV; int32_t lddq, lddk, lddv;
   float dq_scale;
+  /* optional bias-gradient partials (backward): per-batch-item column sums of dQ / dK / dV, row stride ld_colsum */
+  float* dq_colsum; float* dk_colsum; float* dv_colsum; int32_t ld_colsum;
 } KmbAttn;
 
 typedef struct KmbAttnDecode {

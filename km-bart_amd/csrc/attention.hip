@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
   char* dSs = smem + 5 * TILE_BYTES;
   float* lse_s = reinterpret_cast<float*>(smem + 6 * TILE_BYTES);
   float* del_s = lse_s + 64;
-  float* dQacc = del_s + 64;  // [nqt*64][64] fp32
+  float* colk = del_s + 64;   // [64] column sums of dK over all keys (bias-gradient partial)
+  float* colv = colk + 64;    // [64] same for dV
+  float* dQacc = colv + 64;   // [nqt*64][64] fp32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
   const bf16_t* dOh = p.dO + h * HD;
 
   const int nkt = (p.Tk + 63) / 64;
+  if (tid < 128) colk[tid] = 0.f;  // colk and colv are adjacent
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     stage_tile(Ks, Kh, (size_t)b * p.Tk, kt * 64, p.Tk, p.ldk, tid);
@@ -282,6 +285,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
         }
     }
     // this wave's 16 keys of dK / dV
+    if (p.dk_colsum != nullptr) {  // uniform branch
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sk = 0.f, sv = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool valid = (kt * 64 + wave * 16 + g * 4 + q) < p.Tk;
+          sk += valid ? dk[j][q] : 0.f;
+          sv += valid ? dv[j][q] : 0.f;
+        }
+        sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
+        sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+        if (g == 0) { atomicAdd(&colk[j * 16 + r], sk); atomicAdd(&colv[j * 16 + r], sv); }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int key = kt * 64 + wave * 16 + g * 4 + q;
@@ -303,6 +321,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = dQacc[(size_t)q * 64 + c * 8 + e] * p.dq_scale;
     *reinterpret_cast<u32x4*>(p.dQ + ((size_t)b * p.Tq + q) * p.lddq + h * HD + c * 8) = pack8(v);
+  }
+  if (p.dq_colsum != nullptr && tid < 64) {
+    float sq = 0.f;
+    for (int q = 0; q < p.Tq; ++q) sq += dQacc[(size_t)q * 64 + tid] * p.dq_scale;
+    p.dq_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = sq;
+  }
+  if (p.dk_colsum != nullptr && tid < 64) {
+    p.dk_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = colk[tid];
+    p.dv_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = colv[tid];
   }
 }
 
@@ -382,7 +409,7 @@ hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
 
 hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream) {
   const int nqt = (p.Tq + 63) / 64;
-  const size_t lds = 6 * TILE_BYTES + 128 * sizeof(float) + (size_t)nqt * 64 * 64 * sizeof(float);
+  const size_t lds = 6 * TILE_BYTES + 256 * sizeof(float) + (size_t)nqt * 64 * 64 * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

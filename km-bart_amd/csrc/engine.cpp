@@ -253,17 +253,21 @@ int ln_backward(kmb_handle* h, const bf16_t* dy, const bf16_t* z, const float* m
   return 0;
 }
 
-size_t parts_floats(const kmb_handle* h, int Mmax) {
-  const int d = h->d;
-  int maxN = 3 * d;
-  if (h->Fe > maxN) maxN = h->Fe;
-  if (h->Fd > maxN) maxN = h->Fd;
-  size_t a = (size_t)kmb_ln_bwd_parts(Mmax) * 3 * d;
-  size_t b = (size_t)kmb_colsum_parts(Mmax) * maxN;
-  // colsum parts grows for small M (rows_per_part floor): bound it
-  if (b < (size_t)64 * maxN) b = (size_t)64 * maxN;
-  if (a < (size_t)256 * 3 * d) a = (size_t)256 * 3 * d;
-  return a > b ? a : b;
+// scratch for partial reductions: LayerNorm [<=256][3][d], attention bias partials [B][3d],
+// GEMM column sums [ceil(M/128)][F], colsum kernel [<=64][maxN]
+size_t parts_floats(const kmb_handle* h, int Mmax, int B) {
+  const size_t d = h->d;
+  size_t maxN = 3 * d;
+  if ((size_t)h->Fe > maxN) maxN = h->Fe;
+  if ((size_t)h->Fd > maxN) maxN = h->Fd;
+  size_t need = (size_t)256 * 3 * d;
+  const size_t attn = (size_t)B * 3 * d;
+  const size_t gsum = ((size_t)Mmax + 127) / 128 * maxN;
+  const size_t csum = (size_t)64 * maxN;
+  if (attn > need) need = attn;
+  if (gsum > need) need = gsum;
+  if (csum > need) need = csum;
+  return need + 1024;
 }
 
 // ------------------------------------------------------------------ workspace layout (training)
@@ -323,7 +327,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   bf16_t* dqkv = bp.take<bf16_t>(Mmax * 3 * d);
   bf16_t* dcq = bp.take<bf16_t>(Md * d); bf16_t* dckv = bp.take<bf16_t>(Me * 2 * d);
   bf16_t* dob = bp.take<bf16_t>(Mmax * d); bf16_t* denc = bp.take<bf16_t>(Me * d);
-  float* parts = bp.take<float>(parts_floats(h, (int)Mmax));
+  float* parts = bp.take<float>(parts_floats(h, (int)Mmax, B));
   if (assign) {
     H->status = status; H->count = count; H->loss_dev = loss_dev; H->xf = xf; H->img_emb = img_emb; H->dimg = dimg;
     H->img_src = img_src; H->ze0 = ze0; H->me0 = me0; H->re0 = re0; H->zd0 = zd0; H->md0 = md0; H->rd0 = rd0;
@@ -356,12 +360,14 @@ int attn_forward(kmb_handle* h, const AttnIO& io, int B, int H, bf16_t* o, float
 }
 
 int attn_backward(kmb_handle* h, const AttnIO& io, int B, int H, bf16_t* o, float* lse, const bf16_t* dO, bf16_t* dq,
-                  int lddq, bf16_t* dk, bf16_t* dv, int lddkv, hipStream_t s) {
+                  int lddq, bf16_t* dk, bf16_t* dv, int lddkv, float* cs_q, float* cs_k, float* cs_v, int ld_cs,
+                  hipStream_t s) {
   KmbAttn a; memset(&a, 0, sizeof(a));
   a.Q = io.q; a.K = io.k; a.V = io.v; a.ldq = io.ldq; a.ldk = io.ldkv; a.ldv = io.ldkv;
   a.B = B; a.H = H; a.Tq = io.Tq; a.Tk = io.Tk; a.key_mask = io.mask; a.causal = io.causal;
   a.O = o; a.ldo = h->d; a.lse = lse; a.dO = dO; a.lddo = h->d;
   a.dQ = dq; a.lddq = lddq; a.dK = dk; a.dV = dv; a.lddk = lddkv; a.lddv = lddkv; a.dq_scale = 0.125f;
+  a.dq_colsum = cs_q; a.dk_colsum = cs_k; a.dv_colsum = cs_v; a.ld_colsum = ld_cs;
   const char* why = kmb_attn_check(a, 1);
   if (why) return fail("%s", why);
   HIPCHK(kmb_attn_bwd_launch(a, s));
@@ -394,8 +400,9 @@ int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const b
   KCHK(run_wgrad(h, lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(L.fc2_w), M, d, F);
   g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = h->du; g.ld_out_bf16 = F;
+  g.colsum = h->parts;  // per-128-row-block column sums of du = partials of the fc1 bias gradient
   KCHK(run_gemm(g, s));
-  KCHK(bias_grad(h, h->du, F, M, F, h->gf(L.fc1_b), s));
+  HIPCHK(kmb_reduce_parts_launch(h->parts, (M + 127) / 128, F, h->gf(L.fc1_b), F, s));
   KCHK(run_wgrad(h, lin_wgrad(h->du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
   g = lin_dgrad(h->du, F, h->wb(L.fc1_w), M, F, d);
   g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
@@ -433,8 +440,9 @@ int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf
   g.out_bf16 = h->dob; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
   AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
-  KCHK(attn_backward(h, io, B, H, o, lse, h->dob, h->dqkv, 3 * d, h->dqkv + d, h->dqkv + 2 * d, 3 * d, s));
-  KCHK(bias_grad(h, h->dqkv, 3 * d, M, 3 * d, h->gf(A.qkv_b), s));
+  KCHK(attn_backward(h, io, B, H, o, lse, h->dob, h->dqkv, 3 * d, h->dqkv + d, h->dqkv + 2 * d, 3 * d, h->parts,
+                     h->parts + d, h->parts + 2 * d, 3 * d, s));
+  HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(A.qkv_b), 3 * d, s));
   KCHK(run_wgrad(h, lin_wgrad(h->dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
   g = lin_dgrad(h->dqkv, 3 * d, h->wb(A.qkv_w), M, 3 * d, d);
   g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
@@ -749,14 +757,14 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
       g.out_bf16 = h->dob; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
       AttnIO io{a.cq, d, a.ckv, a.ckv + d, 2 * d, T, S, bt.attention_mask, 0};
-      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, h->dcq, d, h->dckv, h->dckv + d, 2 * d, s));
-      // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn
-      KCHK(bias_grad(h, h->dcq, d, Md, d, h->gf(L.ca.qkv_b), s));
+      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, h->dcq, d, h->dckv, h->dckv + d, 2 * d, h->parts,
+                         h->parts + d, h->parts + 2 * d, 3 * d, s));
+      // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn: q|k|v biases are adjacent
+      HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(L.ca.qkv_b), 3 * d, s));
       KCHK(run_wgrad(h, lin_wgrad(h->dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
       g = lin_dgrad(h->dcq, d, h->wb(L.ca.qkv_w), Md, d, d);
       g.residual = h->dz; g.ld_res = d; g.out_bf16 = t1; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
-      KCHK(bias_grad(h, h->dckv, 2 * d, Me, 2 * d, h->gf(L.ca.qkv_b) + d, s));
       KCHK(run_wgrad(h, lin_wgrad(h->dckv, 2 * d, enc, d, h->gf(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d, 0.f), s));
       g = lin_dgrad(h->dckv, 2 * d, h->wb(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d);
       if (denc_init) { g.residual = h->denc; g.ld_res = d; }

@@ -26,7 +26,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;  // 32 KB
 constexpr int EPI_LD = BN + 4;                        // fp32 staging row stride
-constexpr int LDS_BYTES = (BM * EPI_LD * 4 > 2 * STAGE_BYTES) ? BM * EPI_LD * 4 : 2 * STAGE_BYTES;
+constexpr int CS256 = 16 * 128 * 4, CS512 = 32 * 128 * 4;  // column-sum scratch behind the fp32 staging (bias gradients)
+constexpr int EPI_BYTES = BM * EPI_LD * 4;
+constexpr int LDS_BYTES = ((EPI_BYTES > 2 * STAGE_BYTES) ? EPI_BYTES : 2 * STAGE_BYTES) + CS256;  // 74 KB: two per CU
 
 __device__ __forceinline__ int swz_nkc(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
@@ -93,7 +95,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
 }
 
 template <int NT>
-__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, int tid, int row0, int col0, int slice);
+__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
+                                                     int col0, int slice);
 
 template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x4 (&acc)[4][4], int tid, int wm, int wn,
@@ -108,17 +111,22 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
       for (int q = 0; q < 4; ++q)
         ef[(wm * 64 + i * 16 + g * 4 + q) * EPI_LD + wn * 64 + j * 16 + r] = acc[i][j][q];
   __syncthreads();
-  gemm_epilogue_phase2<NT>(p, ef, tid, row0, col0, slice);
+  gemm_epilogue_phase2<NT>(p, ef, reinterpret_cast<float*>(smem + EPI_BYTES * (NT / 256)), tid, row0, col0, slice);
 }
 
+// cs: [NT/16][128] fp32 scratch (only touched when p.colsum != nullptr)
 template <int NT>
-__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, int tid, int row0, int col0, int slice) {
+__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
+                                                     int col0, int slice) {
   constexpr int RPP = NT / 16;  // rows per pass
   // ---- phase 2: row-major math + 16-byte stores ----
   const int c8 = (tid & 15) * 8;
   const int gcol = col0 + c8;
-  if (gcol >= p.N) return;
-  const int nvalid = (p.N - gcol) < 8 ? (p.N - gcol) : 8;
+  if (gcol >= p.N && p.colsum == nullptr) return;
+  const int nvalid = gcol >= p.N ? 0 : ((p.N - gcol) < 8 ? (p.N - gcol) : 8);
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   if (p.split_k > 1) {  // raw partial sums of this K slice -> slab[slice][M][N]
     float* slab = p.slab + (size_t)slice * p.M * p.N;
     for (int it = 0; it < 8; ++it) {
@@ -143,7 +151,7 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
   for (int it = 0; it < 8; ++it) {
     const int lrow = (tid >> 4) + RPP * it;
     const int grow = row0 + lrow;
-    if (grow >= p.M) break;
+    if (grow >= p.M || nvalid == 0) break;
     float v[8];
     {
       const f32x4 lo = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8);
@@ -191,6 +199,8 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rr[e];
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] += v[e];
     if (p.out_bf16 != nullptr) {
       if (nvalid == 8) {
         *reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol) = pack8(v);
@@ -210,6 +220,20 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
       } else {
         for (int e = 0; e < nvalid; ++e) o[e] = v[e];
       }
+    }
+  }
+  if (p.colsum != nullptr) {
+    // column sums of this tile's stored values: reduce the row-lanes through LDS, one partial row per 128 rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[(tid >> 4) * 128 + c8 + e] = csum[e];
+    __syncthreads();
+    if (tid < 128 && col0 + tid < p.N) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < RPP; ++k) t += cs[k * 128 + tid];
+      const int prow = row0 >> 7;
+      p.colsum[(size_t)prow * p.N + col0 + tid] = t;
+      if (NT == 512 && row0 + 128 < p.M) p.colsum[(size_t)(prow + 1) * p.N + col0 + tid] = 0.f;
     }
   }
 }
@@ -367,14 +391,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
 
 
 // ------------------------------------------------------------------------------------------
-// v3: 256x128x64 tile, 512 threads = 8 waves (4x2, 64x64 each), THREE LDS stages filled by LDS-DMA two
-// K-steps ahead.  One raw s_barrier per K-step; the wait that precedes it is a COUNTED vmcnt (the six
-// newest LDS-DMA of the wave -- the tile after next -- stay in flight across the barrier), so HBM
-// latency is covered by two full compute phases instead of one.
-constexpr int BM3 = 256;
-constexpr int ST3 = (BM3 + BN) * BK * 2;          // 48 KB per stage
-constexpr int LDS3 = 3 * ST3;                     // 144 KB (>= 256 x EPI_LD fp32 epilogue staging)
-static_assert(LDS3 >= BM3 * EPI_LD * 4, "epilogue staging must fit the stage ring");
+// LDS-DMA staging / fragment reads for tiles that are 128 or 256 rows (columns) tall; used by v4.
+// (A 256x128 three-stage variant with counted vmcnt was measured 10-25 % slower than v2 on every training
+//  shape -- one workgroup per CU loses the cross-workgroup overlap -- and was removed.)
 
 template <bool KC, int ROWS>
 __device__ __forceinline__ void glds_tile3(char* lds_tile, const bf16_t* __restrict__ X, int ld, int r0, int R, int k0,
@@ -426,75 +445,13 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* lds, int rowtile16, int
   }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const KmbGemm p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 15, g = lane >> 4;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int row0 = tm * BM3, col0 = tn * BN;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nt_all = p.K / BK;
-  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
-  const int nt = t_end - t_begin;
-  constexpr int A_BYTES = BM3 * BK * 2;
-
-  glds_tile3<A_KC, BM3>(smem, p.A, p.lda, row0, p.M, t_begin * BK, wave, lane);
-  glds_tile3<B_KC, BN>(smem + A_BYTES, p.B, p.ldb, col0, p.N, t_begin * BK, wave, lane);
-  if (nt > 1) {
-    glds_tile3<A_KC, BM3>(smem + ST3, p.A, p.lda, row0, p.M, (t_begin + 1) * BK, wave, lane);
-    glds_tile3<B_KC, BN>(smem + ST3 + A_BYTES, p.B, p.ldb, col0, p.N, (t_begin + 1) * BK, wave, lane);
-  }
-  int st = 0;  // stage of tile t
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 < nt) {
-      const int s2 = st >= 1 ? st - 1 : 2;  // (st + 2) % 3: the stage read during the previous K-step
-      glds_tile3<A_KC, BM3>(smem + s2 * ST3, p.A, p.lda, row0, p.M, (t_begin + t + 2) * BK, wave, lane);
-      glds_tile3<B_KC, BN>(smem + s2 * ST3 + A_BYTES, p.B, p.ldb, col0, p.N, (t_begin + t + 2) * BK, wave, lane);
-    }
-    const char* la = smem + st * ST3;
-    const char* lb = la + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag3<A_KC, BM3>(la, wm * 4 + i, kk, r, g);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag3<B_KC, BN>(lb, wn * 4 + j, kk, r, g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    st = st == 2 ? 0 : st + 1;
-  }
-  __syncthreads();
-  gemm_epilogue<512>(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
-}
-
-
 // ------------------------------------------------------------------------------------------
 // v4: 256x256x64 tile, 512 threads = 8 waves (2x4), each wave 128x64 (8x4 MFMA tiles): 12 fragment reads per
 // 32 MFMAs instead of 8 per 16 -- the LDS read traffic per MFMA is what bounds the 64x64-per-wave kernels.
 // Two 64 KB stages filled by LDS-DMA; epilogue in two column halves (fp32 staging does not fit otherwise).
 constexpr int BM4 = 256, BN4 = 256;
 constexpr int ST4 = (BM4 + BN4) * BK * 2;   // 64 KB
-constexpr int LDS4 = (2 * ST4 > BM4 * EPI_LD * 4) ? 2 * ST4 : BM4 * EPI_LD * 4;
+constexpr int LDS4 = ((2 * ST4 > 2 * EPI_BYTES) ? 2 * ST4 : 2 * EPI_BYTES) + CS512;
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
@@ -562,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
             ef[(wm * 128 + i * 16 + g * 4 + q) * EPI_LD + (wn & 1) * 64 + j * 16 + r] = acc[i][j][q];
     }
     __syncthreads();
-    gemm_epilogue_phase2<512>(p, ef, tid, row0, col0 + h * 128, slice);
+    gemm_epilogue_phase2<512>(p, ef, reinterpret_cast<float*>(smem + 2 * EPI_BYTES), tid, row0, col0 + h * 128, slice);
     __syncthreads();
   }
 }
@@ -584,6 +541,7 @@ const char* kmb_gemm_check(const KmbGemm& p) {
   if (p.out_f32 && ((uintptr_t)p.out_f32 & 15)) return "gemm: f32 output alignment";
   if (p.act == 2 && !p.aux) return "gemm: gelu-backward epilogue needs aux";
   if (!p.a_kc && p.b_kc) return "gemm: (M-contiguous A, K-contiguous B) is not instantiated";
+  if (p.colsum && p.split_k > 1) return "gemm: column sums are not available with split-K";
   if (p.split_k > 1) {
     if (!p.slab || ((uintptr_t)p.slab & 15)) return "gemm: split-K needs a 16-byte aligned slab";
     if (p.split_k > (p.K + BK - 1) / BK) return "gemm: more K slices than K steps";
@@ -593,7 +551,6 @@ const char* kmb_gemm_check(const KmbGemm& p) {
 
 namespace {
 
-template <int V> struct Launch;
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   if (variant == 4) {
@@ -602,12 +559,6 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v4<true, true>), grid, block, LDS4, stream, p);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v4<true, false>), grid, block, LDS4, stream, p);
     else hipLaunchKernelGGL((gemm_kernel_v4<false, false>), grid, block, LDS4, stream, p);
-  } else if (variant == 3) {
-    const int tiles = ((p.M + BM3 - 1) / BM3) * ((p.N + BN - 1) / BN);
-    dim3 grid(tiles * nsl), block(512);
-    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, true>), grid, block, LDS3, stream, p);
-    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v3<true, false>), grid, block, LDS3, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel_v3<false, false>), grid, block, LDS3, stream, p);
   } else {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles * nsl), block(256);
@@ -660,9 +611,6 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
@@ -672,7 +620,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   if (!dma_ok) return launch_variant(1, p, stream);
   if (forced) {
     int v = forced;
-    if ((v == 3 && !big) || (v == 4 && !(big && p.N > 128))) v = 2;
+    if (v == 3 || (v == 4 && !(big && p.N > 128))) v = 2;
     return launch_variant(v, p, stream);
   }
   if (!big || p.N <= 128) return launch_variant(2, p, stream);

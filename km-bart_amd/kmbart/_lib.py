@@ -34,7 +34,7 @@ class KmbGemm(C.Structure):
                 ("act", i32), ("preact", c_p), ("ld_preact", i32), ("aux", c_p), ("ld_aux", i32),
                 ("drop_thr16", u32), ("drop_seed", u32), ("drop_scale", f32), ("residual", c_p), ("ld_res", i32),
                 ("out_bf16", c_p), ("ld_out_bf16", i32), ("out_f32", c_p), ("ld_out_f32", i32), ("beta", f32),
-                ("split_k", i32), ("slab", c_p)]
+                ("split_k", i32), ("slab", c_p), ("colsum", c_p)]
 
 
 class KmbAttn(C.Structure):
@@ -42,7 +42,7 @@ class KmbAttn(C.Structure):
                 ("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("key_mask", c_p), ("causal", i32),
                 ("O", c_p), ("ldo", i32), ("lse", c_p), ("dO", c_p), ("lddo", i32),
                 ("dQ", c_p), ("dK", c_p), ("dV", c_p), ("lddq", i32), ("lddk", i32), ("lddv", i32),
-                ("dq_scale", f32)]
+                ("dq_scale", f32), ("dq_colsum", c_p), ("dk_colsum", c_p), ("dv_colsum", c_p), ("ld_colsum", i32)]
 
 
 class KmbAttnDecode(C.Structure):
