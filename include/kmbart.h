@@ -68,7 +68,7 @@ typedef struct KmbGemm {
   kmb_bf16* out_bf16; int32_t ld_out_bf16;
   float* out_f32; int32_t ld_out_f32; float beta;
   int32_t split_k; float* slab;   /* split_k > 1: slice s writes raw fp32 accumulators to slab[s][M][N]; no epilogue */
-  float* colsum;                  /* optional [ceil(M/128)][N]: per-128-row-block column sums of the stored values */
+  float* colsum;                  /* optional [ceil(M/64)][N]: per-64-row-block column sums of the stored values */
 } KmbGemm;
 
 /* ---- fused attention (csrc/attention.hip) -------------------------------------------------- */

@@ -262,7 +262,7 @@ size_t parts_floats(const kmb_handle* h, int Mmax, int B) {
   if ((size_t)h->Fd > maxN) maxN = h->Fd;
   size_t need = (size_t)256 * 3 * d;
   const size_t attn = (size_t)B * 3 * d;
-  const size_t gsum = ((size_t)Mmax + 127) / 128 * maxN;
+  const size_t gsum = ((size_t)Mmax + 63) / 64 * maxN;
   const size_t csum = (size_t)64 * maxN;
   if (attn > need) need = attn;
   if (gsum > need) need = gsum;
@@ -400,9 +400,9 @@ int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const b
   KCHK(run_wgrad(h, lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(L.fc2_w), M, d, F);
   g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = h->du; g.ld_out_bf16 = F;
-  g.colsum = h->parts;  // per-128-row-block column sums of du = partials of the fc1 bias gradient
+  g.colsum = h->parts;  // per-64-row-block column sums of du = partials of the fc1 bias gradient
   KCHK(run_gemm(g, s));
-  HIPCHK(kmb_reduce_parts_launch(h->parts, (M + 127) / 128, F, h->gf(L.fc1_b), F, s));
+  HIPCHK(kmb_reduce_parts_launch(h->parts, (M + 63) / 64, F, h->gf(L.fc1_b), F, s));
   KCHK(run_wgrad(h, lin_wgrad(h->du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
   g = lin_dgrad(h->du, F, h->wb(L.fc1_w), M, F, d);
   g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;

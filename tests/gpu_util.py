@@ -19,7 +19,7 @@ def bf(x):
 
 def gemm(A, B, a_kc=True, b_kc=True, M=None, N=None, K=None, bias=None, col_scale=1.0, col_scale_n=0, act=0,
          preact=None, aux=None, drop_p=0.0, drop_seed=0, residual=None, out_bf16=None, out_f32=None, beta=0.0,
-         split_k=0, slab=None):
+         split_k=0, slab=None, colsum=None):
     """A, B are bf16 2-D tensors in their STORAGE layout; M/N/K default from the shapes."""
     lib = _lib.load()
     if M is None:
@@ -52,6 +52,7 @@ def gemm(A, B, a_kc=True, b_kc=True, M=None, N=None, K=None, bias=None, col_scal
     g.beta = beta
     g.split_k = split_k
     g.slab = ptr(slab)
+    g.colsum = ptr(colsum)
     check(lib.kmb_op_gemm(C.byref(g), stream()))
 
 

@@ -82,6 +82,21 @@ def test_gemm_split_k_slabs(T, N, K, S):
     assert rel_err(slab.sum(0), dY.float().t() @ X.float()) < F32_TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1000, 3072, 768), (300, 264, 64)])
+def test_gemm_epilogue_column_sums(M, N, K):
+    """bias-gradient partials: one row of column sums per 64 rows of the stored (GeLU'-scaled) output."""
+    A, B = bf(rnd(M, K, seed=17)), bf(rnd(K, N, seed=18, scale=0.1))
+    u = bf(rnd(M, N, seed=19))
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    parts = torch.full(((M + 63) // 64, N), 5.0, dtype=torch.float32, device=DEV)
+    gemm(A, B, a_kc=True, b_kc=False, act=2, aux=u, out_bf16=out, colsum=parts)
+    uu = u.float().requires_grad_(True)
+    F.gelu(uu).sum().backward()
+    ref = (A.float() @ B.float()) * uu.grad
+    assert rel_err(out, ref) < BF_TOL
+    assert rel_err(parts.sum(0), ref.sum(0)) < 1e-3
+
+
 def test_gemm_wgrad_unpadded_output():
     """image-projection weight gradient: logical N = 2052 columns out of a 2056-wide padded operand."""
     T, N, Kp, Kv = 72, 128, 2056, 2052
