@@ -100,9 +100,17 @@ struct kmb_handle {
   bf16_t* xf = nullptr; float* img_emb = nullptr; int32_t* img_src = nullptr; bf16_t* dimg = nullptr;
   float* logits_c = nullptr; bf16_t* dlogits_c = nullptr; float* loss_rows = nullptr; int32_t* count = nullptr;
   int32_t* status = nullptr; float* loss_dev = nullptr;
-  bf16_t *dhdec, *dyA, *dyB, *dz, *dsub, *du, *dqkv, *dcq, *dckv, *dob, *denc;
+  bf16_t *dhdec, *dyA, *dyB, *dz, *dob, *denc;
+  // gradient buffers read by the weight-gradient GEMMs of the side stream: one per LayerNorm site
+  // (0 = FFN, 1 = self-attention, 2 = cross-attention) and per layer parity, so that the main stream can run
+  // up to one layer ahead of the side stream without overwriting what it still reads
+  struct BwdBufs { bf16_t *dz[3], *dsub[3], *du, *dqkv, *dcq, *dckv; } bb[2];
+  hipStream_t side = nullptr; bool side_on = true;
+  std::vector<hipEvent_t> ring; size_t ring_pos = 0;
+  std::vector<hipEvent_t> layer_done;   // recorded on the side stream
   float* parts = nullptr;
   float* slab = nullptr; size_t slab_floats = 0;
+  hipEvent_t next_event() { hipEvent_t e = ring[ring_pos]; ring_pos = (ring_pos + 1) % ring.size(); return e; }
   // ---- generation state
   struct Gen {
     bool active = false; int B = 0, S = 0, nb = 0, R = 0, Tmax = 0;
@@ -232,6 +240,17 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
   return 0;
 }
 
+// Weight gradients are off the critical path (nothing in backward reads them): enqueue them on the side stream
+// behind an event that marks "everything the main stream has produced so far".  Two different GEMMs in flight are
+// out of phase, so one's output-store burst overlaps the other's matrix work and partial waves get filled.
+int wgrad_side(kmb_handle* h, const KmbGemm& g, hipStream_t sA) {
+  if (!h->side_on || h->side == nullptr) return run_wgrad(h, g, sA);
+  hipEvent_t e = h->next_event();
+  HIPCHK(hipEventRecord(e, sA));
+  HIPCHK(hipStreamWaitEvent(h->side, e, 0));
+  return run_wgrad(h, g, h->side);
+}
+
 int bias_grad(kmb_handle* h, const bf16_t* dy, int ld, int M, int N, float* out, hipStream_t s) {
   HIPCHK(kmb_colsum_launch(dy, ld, M, N, h->parts, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, kmb_colsum_parts(M), N, out, N, s));
@@ -321,19 +340,27 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   float* loss_rows = bp.take<float>(Md);
   bf16_t* dhdec = bp.take<bf16_t>(Md * d);
   bf16_t* dyA = bp.take<bf16_t>(Mmax * d); bf16_t* dyB = bp.take<bf16_t>(Mmax * d);
-  bf16_t* dz = bp.take<bf16_t>(Mmax * d); bf16_t* dsub = bp.take<bf16_t>(Mmax * d);
+  bf16_t* dz = bp.take<bf16_t>(Mmax * d);
   const int Fmax = Fe > Fd ? Fe : Fd;
-  bf16_t* du = bp.take<bf16_t>(Mmax * Fmax);
-  bf16_t* dqkv = bp.take<bf16_t>(Mmax * 3 * d);
-  bf16_t* dcq = bp.take<bf16_t>(Md * d); bf16_t* dckv = bp.take<bf16_t>(Me * 2 * d);
+  kmb_handle::BwdBufs bb[2];
+  for (int k = 0; k < 2; ++k) {
+    for (int site = 0; site < 3; ++site) {
+      bb[k].dz[site] = bp.take<bf16_t>(Mmax * d);
+      bb[k].dsub[site] = bp.take<bf16_t>(Mmax * d);
+    }
+    bb[k].du = bp.take<bf16_t>(Mmax * Fmax);
+    bb[k].dqkv = bp.take<bf16_t>(Mmax * 3 * d);
+    bb[k].dcq = bp.take<bf16_t>(Md * d);
+    bb[k].dckv = bp.take<bf16_t>(Me * 2 * d);
+  }
   bf16_t* dob = bp.take<bf16_t>(Mmax * d); bf16_t* denc = bp.take<bf16_t>(Me * d);
   float* parts = bp.take<float>(parts_floats(h, (int)Mmax, B));
   if (assign) {
     H->status = status; H->count = count; H->loss_dev = loss_dev; H->xf = xf; H->img_emb = img_emb; H->dimg = dimg;
     H->img_src = img_src; H->ze0 = ze0; H->me0 = me0; H->re0 = re0; H->zd0 = zd0; H->md0 = md0; H->rd0 = rd0;
     H->xe = xe; H->xd = xd; H->ea = ea; H->da = da; H->logits_c = logits_c; H->dlogits_c = dlogits_c;
-    H->loss_rows = loss_rows; H->dhdec = dhdec; H->dyA = dyA; H->dyB = dyB; H->dz = dz; H->dsub = dsub; H->du = du;
-    H->dqkv = dqkv; H->dcq = dcq; H->dckv = dckv; H->dob = dob; H->denc = denc; H->parts = parts;
+    H->loss_rows = loss_rows; H->dhdec = dhdec; H->dyA = dyA; H->dyB = dyB; H->dz = dz;
+    H->bb[0] = bb[0]; H->bb[1] = bb[1]; H->dob = dob; H->denc = denc; H->parts = parts;
     H->slab = slab; H->slab_floats = slab_floats;
   }
   return bp.used();
@@ -392,20 +419,21 @@ int ffn_forward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, bf16_t* 
 // backward of the FFN block.  dy: grad wrt LN output.  Result: grad wrt block input x in dx_out.
 int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const bf16_t* u, const bf16_t* hh,
                  const bf16_t* z, const float* mean, const float* rstd, const bf16_t* dy, bf16_t* dx_out, int M,
-                 KmbDrop dr, hipStream_t s) {
+                 KmbDrop dr, kmb_handle::BwdBufs& bb, hipStream_t s) {
   const int d = h->d;
-  bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
-  KCHK(ln_backward(h, dy, z, mean, rstd, L.ln_g, L.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
+  bf16_t* dz = bb.dz[0];
+  bf16_t* dsub = dr.thr16 ? bb.dsub[0] : dz;
+  KCHK(ln_backward(h, dy, z, mean, rstd, L.ln_g, L.ln_b, dz, dr.thr16 ? dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
                    L.fc2_b));
-  KCHK(run_wgrad(h, lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
+  KCHK(wgrad_side(h, lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(L.fc2_w), M, d, F);
-  g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = h->du; g.ld_out_bf16 = F;
+  g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = bb.du; g.ld_out_bf16 = F;
   g.colsum = h->parts;  // per-64-row-block column sums of du = partials of the fc1 bias gradient
   KCHK(run_gemm(g, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, (M + 63) / 64, F, h->gf(L.fc1_b), F, s));
-  KCHK(run_wgrad(h, lin_wgrad(h->du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
-  g = lin_dgrad(h->du, F, h->wb(L.fc1_w), M, F, d);
-  g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
+  KCHK(wgrad_side(h, lin_wgrad(bb.du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
+  g = lin_dgrad(bb.du, F, h->wb(L.fc1_w), M, F, d);
+  g.residual = dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
   return 0;
 }
@@ -430,22 +458,23 @@ int self_attn_forward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf1
 
 int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf16_t* qkv, bf16_t* o, float* lse,
                        const bf16_t* z, const float* mean, const float* rstd, const bf16_t* dy, bf16_t* dx_out, int B,
-                       int T, const int64_t* mask, int causal, KmbDrop dr, hipStream_t s) {
+                       int T, const int64_t* mask, int causal, KmbDrop dr, kmb_handle::BwdBufs& bb, hipStream_t s) {
   const int d = h->d, M = B * T;
-  bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
-  KCHK(ln_backward(h, dy, z, mean, rstd, A.ln_g, A.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
+  bf16_t* dz = bb.dz[1];
+  bf16_t* dsub = dr.thr16 ? bb.dsub[1] : dz;
+  KCHK(ln_backward(h, dy, z, mean, rstd, A.ln_g, A.ln_b, dz, dr.thr16 ? dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
                    A.o_b));
-  KCHK(run_wgrad(h, lin_wgrad(dsub, d, o, d, h->gf(A.o_w), M, d, d, 0.f), s));
+  KCHK(wgrad_side(h, lin_wgrad(dsub, d, o, d, h->gf(A.o_w), M, d, d, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(A.o_w), M, d, d);
   g.out_bf16 = h->dob; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
   AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
-  KCHK(attn_backward(h, io, B, H, o, lse, h->dob, h->dqkv, 3 * d, h->dqkv + d, h->dqkv + 2 * d, 3 * d, h->parts,
+  KCHK(attn_backward(h, io, B, H, o, lse, h->dob, bb.dqkv, 3 * d, bb.dqkv + d, bb.dqkv + 2 * d, 3 * d, h->parts,
                      h->parts + d, h->parts + 2 * d, 3 * d, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(A.qkv_b), 3 * d, s));
-  KCHK(run_wgrad(h, lin_wgrad(h->dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
-  g = lin_dgrad(h->dqkv, 3 * d, h->wb(A.qkv_w), M, 3 * d, d);
-  g.residual = h->dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
+  KCHK(wgrad_side(h, lin_wgrad(bb.dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
+  g = lin_dgrad(bb.dqkv, 3 * d, h->wb(A.qkv_w), M, 3 * d, d);
+  g.residual = dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
   return 0;
 }
@@ -557,6 +586,9 @@ int kmb_create(const kmb_config* cfg, kmb_handle** out) {
 void kmb_destroy(kmb_handle* h) {
   if (!h) return;
   for (auto e : h->events) if (e) (void)hipEventDestroy(e);
+  for (auto e : h->ring) if (e) (void)hipEventDestroy(e);
+  for (auto e : h->layer_done) if (e) (void)hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
 
@@ -731,7 +763,39 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   const int Le = h->cfg.encoder_layers, Ld = h->cfg.decoder_layers;
   for (auto& e : h->events)
     if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (h->side_on && h->side == nullptr) {
+    const char* env = getenv("KMB_NO_SIDE_STREAM");
+    if (env && env[0] == '1') {
+      h->side_on = false;
+    } else {
+      HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+      h->ring.resize(64);
+      for (auto& e : h->ring) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->layer_done.resize(Le + Ld + 2);
+      for (auto& e : h->layer_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+  }
+  const bool side = h->side_on && h->side != nullptr;
   int ev = 0;
+  // layer c may only start once the side stream has finished layer c-2 (it still reads that layer's gradient buffers)
+  auto layer_begin = [&](int c) -> int {
+    if (side && c >= 2) HIPCHK(hipStreamWaitEvent(s, h->layer_done[c - 2], 0));
+    return 0;
+  };
+  // the bucket of layer c is complete when BOTH streams are past this point: record its event on the side stream
+  // behind a marker of the main stream, so the main stream never waits here
+  auto layer_end = [&](int c, int bucket) -> int {
+    if (side) {
+      hipEvent_t e = h->next_event();
+      HIPCHK(hipEventRecord(e, s));
+      HIPCHK(hipStreamWaitEvent(h->side, e, 0));
+      HIPCHK(hipEventRecord(h->events[bucket], h->side));
+      HIPCHK(hipEventRecord(h->layer_done[c], h->side));
+    } else {
+      HIPCHK(hipEventRecord(h->events[bucket], s));
+    }
+    return 0;
+  };
   if (loss_scale != 1.f) {
     HIPCHK(kmb_scale_bf16_launch(h->dhdec, (size_t)Md * d, loss_scale, s));
     HIPCHK(kmb_scale_f32_launch(h->gf(h->shared), (size_t)h->V * d, loss_scale, s));
@@ -739,46 +803,49 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   const bf16_t* enc = h->xe[Le];
   const bf16_t* dy = h->dhdec;
   bf16_t* pp[2] = {h->dyA, h->dyB};
-  int cur = 0;
+  int cur = 0, c = 0;
   bool denc_init = false;
   // ---- decoder layers
-  for (int l = Ld - 1; l >= 0; --l) {
+  for (int l = Ld - 1; l >= 0; --l, ++c) {
     const LayerP& L = h->dec[l];
     DecAct& a = h->da[l];
+    kmb_handle::BwdBufs& bb = h->bb[c & 1];
+    KCHK(layer_begin(c));
     bf16_t* t0 = pp[cur]; bf16_t* t1 = pp[cur ^ 1];
-    KCHK(ffn_backward(h, L, h->Fd, a.y2, a.u, a.hh, a.z3, a.m3, a.r3, dy, t0, Md, h->drop_site(102 + 3 * l, tr), s));
+    KCHK(ffn_backward(h, L, h->Fd, a.y2, a.u, a.hh, a.z3, a.m3, a.r3, dy, t0, Md, h->drop_site(102 + 3 * l, tr), bb, s));
     {  // cross-attention block: y2 = LN(z2), z2 = y1 + drop(out_proj(attn(cq, ckv)))
       const KmbDrop dr = h->drop_site(101 + 3 * l, tr);
-      bf16_t* dsub = dr.thr16 ? h->dsub : h->dz;
-      KCHK(ln_backward(h, t0, a.z2, a.m2, a.r2, L.ca.ln_g, L.ca.ln_b, h->dz, dr.thr16 ? h->dsub : nullptr,
+      bf16_t* dz = bb.dz[2];
+      bf16_t* dsub = dr.thr16 ? bb.dsub[2] : dz;
+      KCHK(ln_backward(h, t0, a.z2, a.m2, a.r2, L.ca.ln_g, L.ca.ln_b, dz, dr.thr16 ? dsub : nullptr,
                        KmbDrop{0u, 0u, 1.f}, dr, Md, s, L.ca.o_b));
-      KCHK(run_wgrad(h, lin_wgrad(dsub, d, a.o2, d, h->gf(L.ca.o_w), Md, d, d, 0.f), s));
+      KCHK(wgrad_side(h, lin_wgrad(dsub, d, a.o2, d, h->gf(L.ca.o_w), Md, d, d, 0.f), s));
       KmbGemm g = lin_dgrad(dsub, d, h->wb(L.ca.o_w), Md, d, d);
       g.out_bf16 = h->dob; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
       AttnIO io{a.cq, d, a.ckv, a.ckv + d, 2 * d, T, S, bt.attention_mask, 0};
-      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, h->dcq, d, h->dckv, h->dckv + d, 2 * d, h->parts,
+      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, bb.dcq, d, bb.dckv, bb.dckv + d, 2 * d, h->parts,
                          h->parts + d, h->parts + 2 * d, 3 * d, s));
       // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn: q|k|v biases are adjacent
       HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(L.ca.qkv_b), 3 * d, s));
-      KCHK(run_wgrad(h, lin_wgrad(h->dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
-      g = lin_dgrad(h->dcq, d, h->wb(L.ca.qkv_w), Md, d, d);
-      g.residual = h->dz; g.ld_res = d; g.out_bf16 = t1; g.ld_out_bf16 = d;
+      KCHK(wgrad_side(h, lin_wgrad(bb.dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
+      g = lin_dgrad(bb.dcq, d, h->wb(L.ca.qkv_w), Md, d, d);
+      g.residual = dz; g.ld_res = d; g.out_bf16 = t1; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
-      KCHK(run_wgrad(h, lin_wgrad(h->dckv, 2 * d, enc, d, h->gf(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d, 0.f), s));
-      g = lin_dgrad(h->dckv, 2 * d, h->wb(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d);
+      KCHK(wgrad_side(h, lin_wgrad(bb.dckv, 2 * d, enc, d, h->gf(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d, 0.f), s));
+      g = lin_dgrad(bb.dckv, 2 * d, h->wb(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d);
       if (denc_init) { g.residual = h->denc; g.ld_res = d; }
       g.out_bf16 = h->denc; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
       denc_init = true;
     }
     KCHK(self_attn_backward(h, L.sa, h->Hd, h->xd[l], a.qkv, a.o1, a.lse1, a.z1, a.m1, a.r1, t1, t0, B, T,
-                            bt.decoder_attention_mask, 1, h->drop_site(100 + 3 * l, tr), s));
+                            bt.decoder_attention_mask, 1, h->drop_site(100 + 3 * l, tr), bb, s));
     dy = t0;  // t0 now holds d(loss)/d(xd[l]); keep it as the input of the next iteration
     cur ^= 1;  // next iteration writes its first result into the other buffer
-    HIPCHK(hipEventRecord(h->events[ev++], s));
+    KCHK(layer_end(c, ev++));
   }
-  // ---- decoder embedding: xd[0] = drop(LN(zd0))
+  // ---- decoder embedding: xd[0] = drop(LN(zd0))  (main stream only)
   KCHK(ln_backward(h, dy, h->zd0, h->md0, h->rd0, h->dec_lne_g, h->dec_lne_b, h->dz, nullptr, h->drop_site(2, tr),
                    KmbDrop{0u, 0u, 1.f}, Md, s));
   HIPCHK(kmb_embed_bwd_launch(h->dz, bt.decoder_input_ids, nullptr, scale, h->gf(h->shared), nullptr,
@@ -789,15 +856,17 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   if (!denc_init) HIPCHK(hipMemsetAsync(h->denc, 0, (size_t)Me * d * sizeof(bf16_t), s));
   dy = h->denc;
   cur = 0;
-  for (int l = Le - 1; l >= 0; --l) {
+  for (int l = Le - 1; l >= 0; --l, ++c) {
     const LayerP& L = h->enc[l];
     EncAct& a = h->ea[l];
+    kmb_handle::BwdBufs& bb = h->bb[c & 1];
+    KCHK(layer_begin(c));
     bf16_t* t0 = pp[cur]; bf16_t* t1 = pp[cur ^ 1];
-    KCHK(ffn_backward(h, L, h->Fe, a.y1, a.u, a.hh, a.z2, a.m2, a.r2, dy, t0, Me, h->drop_site(11 + 2 * l, tr), s));
+    KCHK(ffn_backward(h, L, h->Fe, a.y1, a.u, a.hh, a.z2, a.m2, a.r2, dy, t0, Me, h->drop_site(11 + 2 * l, tr), bb, s));
     KCHK(self_attn_backward(h, L.sa, h->He, h->xe[l], a.qkv, a.o, a.lse, a.z1, a.m1, a.r1, t0, t1, B, S,
-                            bt.attention_mask, 0, h->drop_site(10 + 2 * l, tr), s));
+                            bt.attention_mask, 0, h->drop_site(10 + 2 * l, tr), bb, s));
     dy = t1;  // t0 / t1 keep their roles: the next ffn_backward reads t1 and writes t0
-    HIPCHK(hipEventRecord(h->events[ev++], s));
+    KCHK(layer_end(c, ev++));
   }
   // ---- encoder embedding (+ image projection, src/model/modules.py:24-41)
   KCHK(ln_backward(h, dy, h->ze0, h->me0, h->re0, h->enc_lne_g, h->enc_lne_b, h->dz, nullptr, h->drop_site(1, tr),
@@ -807,10 +876,15 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   HIPCHK(kmb_pos_bwd_launch(h->dz, B, S, d, h->gf(h->enc_pos), h->cfg.extra_pos_embeddings, h->Prows, s));
   if (h->Ntot > 0) {
     KCHK(bias_grad(h, h->dimg, d, h->Ntot, d, h->gf(h->img_b), s));
-    KCHK(run_wgrad(h, lin_wgrad(h->dimg, d, h->xf, h->Fpad, h->gf(h->img_w), h->Ntot, d, h->Fin, 0.f), s));
+    KCHK(wgrad_side(h, lin_wgrad(h->dimg, d, h->xf, h->Fpad, h->gf(h->img_w), h->Ntot, d, h->Fin, 0.f), s));  // shares the slab
   } else {
     HIPCHK(hipMemsetAsync(h->gf(h->img_w), 0, ((size_t)d * h->Fin) * sizeof(float), s));
     HIPCHK(hipMemsetAsync(h->gf(h->img_b), 0, (size_t)d * sizeof(float), s));
+  }
+  if (side) {  // everything the optimizer reads must be ordered behind the side stream's last weight gradient
+    hipEvent_t e = h->next_event();
+    HIPCHK(hipEventRecord(e, h->side));
+    HIPCHK(hipStreamWaitEvent(s, e, 0));
   }
   HIPCHK(hipEventRecord(h->events[ev++], s));
   HIPCHK(hipEventRecord(h->events[ev++], s));  // tied matrix: complete once the encoder-side scatter-add is in
