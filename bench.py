@@ -197,6 +197,8 @@ def main():
         lib = _lib.load()
         agg = {}
         n_prof = 3
+        lib.kmb_set_side_stream(model._engine.h, 0)  # kernels timed one at a time, not overlapped with each other
+        step()
         for _ in range(n_prof):
             lib.kmb_profile_gemm(1)
             step()
@@ -209,6 +211,7 @@ def main():
                 a[1] += ms.value
                 a[2] += fl.value
             lib.kmb_profile_gemm(0)
+        lib.kmb_set_side_stream(model._engine.h, 1)
         tot_ms = sum(a[1] for a in agg.values())
         tot_fl = sum(a[2] for a in agg.values())
         launches = sum(a[0] for a in agg.values())
@@ -216,7 +219,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_kernel<A_KC,B_KC> (all GEMM launches of a step)",
+            "kernel": "gemm_kernel_v2/v4<A_KC,B_KC> (all GEMM launches of a step, timed serially)",
             "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
             "gemm_ms_per_step": round(tot_ms / n_prof, 3),
             "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),

@@ -891,6 +891,12 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   return 0;
 }
 
+// 0: weight-gradient GEMMs stay on the caller's stream (serial backward; used while timing single kernels)
+int kmb_set_side_stream(kmb_handle* h, int enable) {
+  h->side_on = enable != 0;
+  return 0;
+}
+
 int kmb_profile_gemm(int enable) {
   g_prof.on = enable != 0;
   if (enable) { g_prof.used = 0; g_prof.recs.clear(); }
