@@ -36,6 +36,8 @@ typedef struct kmb_config {
   int32_t scale_embedding;
   float dropout, attention_dropout, activation_dropout;
   float layer_norm_eps;
+  /* pre-training heads (src/model/model.py:133-158); 0 = head absent (MultiModalBartForConditionalGeneration) */
+  int32_t num_labels, num_attributes, num_relations;
 } kmb_config;
 
 /* one training / scoring batch; layout = what the reference Collator emits
@@ -69,6 +71,7 @@ typedef struct KmbGemm {
   float* out_f32; int32_t ld_out_f32; float beta;
   int32_t split_k; float* slab;   /* split_k > 1: slice s writes raw fp32 accumulators to slab[s][M][N]; no epilogue */
   float* colsum;                  /* optional [ceil(M/64)][N]: per-64-row-block column sums of the stored values */
+  int32_t tile_order;             /* set by the launcher: 0 = linear tile ids, 1 = contiguous tile range per XCD */
 } KmbGemm;
 
 /* ---- fused attention (csrc/attention.hip) -------------------------------------------------- */
@@ -146,6 +149,21 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream);
 int kmb_adamw_step(kmb_handle* h, const KmbAdamW* hp, int64_t offset, int64_t count, void* stream);
 /* status word written by device-side input validation (bit 0: #<img_feat> ids != #region rows) */
 int kmb_read_status(kmb_handle* h, int32_t* status_host, void* stream);
+
+/* ---- multi-task pre-training (MultiModalBartForPreTraining.forward, src/model/model.py:162-309) ----
+ * rows index the flattened decoder positions [B*T]; every pointer is a device pointer; n_* may be 0 */
+typedef struct kmb_pretrain {
+  int32_t n_mrm; const int32_t* mrm_rows; const float* mrm_targets;     /* soft labels [n_mrm, num_labels] (model.py:248-257) */
+  int32_t n_attr; const int32_t* attr_rows; const int64_t* attr_labels; /* (model.py:259-268) */
+  int32_t n_rel; const int32_t* rel_obj_rows; const int32_t* rel_subj_rows; const int64_t* rel_labels; /* (:270-289) */
+  float lm_factor, mrm_factor, attr_factor, rel_factor;                 /* config.*_loss_factor (:304-307) */
+  float* losses_out;                                                    /* device float[5]: loss, lm, mrm, attribute, relation */
+} kmb_pretrain;
+/* room for up to n gathered head rows in the workspace (call before kmb_workspace_bytes) */
+int kmb_reserve_head_rows(kmb_handle* h, int n);
+/* kmb_forward plus the three classification heads; `labels` must already carry -100 at <cls> positions (:297-298) */
+int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, int train, int need_grad,
+                         float* logits_out, kmb_bf16* enc_out, void* stream);
 
 /* ================= generation ================= */
 /* encoder once (src/model/mixins.py:281-283) + cross-attention K/V of every decoder layer */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libkmbart_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "embed.hip", "loss.hip", "optim.hip", "engine.cpp", "capi_ops.cpp"]
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "embed.hip", "loss.hip", "optim.hip", "heads.hip", "engine.cpp", "capi_ops.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 

@@ -51,6 +51,7 @@ struct ParamInfo { std::string name; size_t off; int rows, cols; };
 struct AttnP { size_t qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
 struct LayerP { AttnP sa, ca; size_t fc1_w, fc1_b, fc2_w, fc2_b, ln_g, ln_b; };
 struct Bucket { size_t off, count; };
+struct HeadP { size_t dw = 0, db = 0, ow = 0, ob = 0; int d_in = 0, C = 0; bool on = false; };
 
 struct EncAct { bf16_t *qkv, *o, *z1, *y1, *u, *hh, *z2; float *lse, *m1, *r1, *m2, *r2; };
 struct DecAct {
@@ -82,6 +83,8 @@ struct kmb_handle {
   size_t arena = 0;
   size_t img_w, img_b, enc_pos, enc_lne_g, enc_lne_b, dec_pos, dec_lne_g, dec_lne_b, shared;
   std::vector<LayerP> enc, dec;
+  HeadP head[3];                    // mrm, attribute, relation (src/model/model.py:133-158)
+  size_t heads_begin = 0, heads_end = 0; int head_rows_cap = 0;
   std::vector<Bucket> buckets;      // in backward completion order
   std::vector<hipEvent_t> events;
   // bound memory
@@ -109,6 +112,9 @@ struct kmb_handle {
   std::vector<hipEvent_t> ring; size_t ring_pos = 0;
   std::vector<hipEvent_t> layer_done;   // recorded on the side stream
   float* parts = nullptr;
+  // pre-training head scratch
+  bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr; float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
+  float* losses5 = nullptr;
   float* slab = nullptr; size_t slab_floats = 0;
   hipEvent_t next_event() { hipEvent_t e = ring[ring_pos]; ring_pos = (ring_pos + 1) % ring.size(); return e; }
   // ---- generation state
@@ -355,6 +361,19 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   }
   bf16_t* dob = bp.take<bf16_t>(Mmax * d); bf16_t* denc = bp.take<bf16_t>(Me * d);
   float* parts = bp.take<float>(parts_floats(h, (int)Mmax, B));
+  // pre-training head scratch (only when heads exist and rows were reserved)
+  bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr;
+  float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
+  float* losses5 = bp.take<float>(8);
+  if ((h->head[0].on || h->head[1].on || h->head[2].on) && h->head_rows_cap > 0) {
+    const size_t n = (size_t)h->head_rows_cap;
+    size_t Cpad = 8;
+    for (int k = 0; k < 3; ++k)
+      if (h->head[k].on && align_up((size_t)h->head[k].C, 8) > Cpad) Cpad = align_up((size_t)h->head[k].C, 8);
+    hx = bp.take<bf16_t>(n * 2 * d); hy = bp.take<bf16_t>(n * d); hdy = bp.take<bf16_t>(n * d);
+    hdx = bp.take<bf16_t>(n * 2 * d); hdlg = bp.take<bf16_t>(n * Cpad); hlg = bp.take<float>(n * Cpad);
+    hloss = bp.take<float>(n); dhead = bp.take<float>(Md * d);
+  }
   if (assign) {
     H->status = status; H->count = count; H->loss_dev = loss_dev; H->xf = xf; H->img_emb = img_emb; H->dimg = dimg;
     H->img_src = img_src; H->ze0 = ze0; H->me0 = me0; H->re0 = re0; H->zd0 = zd0; H->md0 = md0; H->rd0 = rd0;
@@ -362,6 +381,8 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     H->loss_rows = loss_rows; H->dhdec = dhdec; H->dyA = dyA; H->dyB = dyB; H->dz = dz;
     H->bb[0] = bb[0]; H->bb[1] = bb[1]; H->dob = dob; H->denc = denc; H->parts = parts;
     H->slab = slab; H->slab_floats = slab_floats;
+    H->hx = hx; H->hy = hy; H->hdy = hdy; H->hdx = hdx; H->hdlg = hdlg; H->hlg = hlg; H->hloss = hloss; H->dhead = dhead;
+    H->losses5 = losses5;
   }
   return bp.used();
 }
@@ -479,6 +500,57 @@ int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf
   return 0;
 }
 
+
+// One BartClassificationHead (dense -> tanh -> out_proj, classif_dropout = 0) on gathered decoder rows, its loss
+// and, with need_grad, all of its gradients: parameter gradients go to the arena, the gradient wrt the decoder
+// states is scatter-added (fp32) into h->dhead.  Reference src/model/model.py:133-158, :248-289.
+int head_run(kmb_handle* h, int k, const bf16_t* hdec, int n, const int32_t* rows_a, const int32_t* rows_b,
+             const float* soft_targets, const int64_t* labels, float factor, bool need_grad, float* loss_out,
+             hipStream_t s) {
+  const HeadP& H = h->head[k];
+  const int d = h->d, din = H.d_in, C = H.C;
+  const int Cpad = (int)align_up((size_t)C, 8);
+  if (n <= 0) {  // the reference skips the term; its parameters get no gradient this step
+    HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), s));
+    if (need_grad) HIPCHK(hipMemsetAsync(h->gf(H.dw), 0, (H.ob + (size_t)C - H.dw) * sizeof(float), s));
+    return 0;
+  }
+  if (n > h->head_rows_cap || h->hx == nullptr) return fail("head rows %d exceed the reserved %d (kmb_reserve_head_rows)", n, h->head_rows_cap);
+  // gather: [n, d] (or [n, 2d] = object | subject for the relation head)
+  HIPCHK(kmb_gather_rows_bf16_launch(hdec, d, rows_a, h->hx, din, n, d, s));
+  if (rows_b) HIPCHK(kmb_gather_rows_bf16_launch(hdec, d, rows_b, h->hx + d, din, n, d, s));
+  KmbGemm g = lin_fwd(h->hx, din, h->wb(H.dw), h->pf(H.db), n, d, din);
+  g.act = 3; g.out_bf16 = h->hy; g.ld_out_bf16 = d;
+  KCHK(run_gemm(g, s));
+  g = lin_fwd(h->hy, d, h->wb(H.ow), h->pf(H.ob), n, C, d);
+  g.out_f32 = h->hlg; g.ld_out_f32 = Cpad;
+  KCHK(run_gemm(g, s));
+  if (soft_targets) {  // F.kl_div(log_softmax(pred), target, reduction='batchmean') * factor
+    HIPCHK(kmb_kl_div_launch(h->hlg, Cpad, C, soft_targets, C, n, factor, h->hloss, need_grad ? h->hdlg : nullptr, Cpad, s));
+    HIPCHK(kmb_mean_rows_launch(h->hloss, n, factor, (float)n, loss_out, s));
+  } else {             // CrossEntropyLoss()(pred, labels) * factor
+    HIPCHK(kmb_count_valid_launch(labels, n, h->count + 1, s));
+    HIPCHK(kmb_ce_launch(h->hlg, Cpad, C, labels, n, h->count + 1, factor, h->hloss, need_grad ? h->hdlg : nullptr, s));
+    HIPCHK(kmb_mean_rows_launch(h->hloss, n, factor, (float)n, loss_out, s));
+  }
+  if (!need_grad) return 0;
+  // out_proj
+  KCHK(bias_grad(h, h->hdlg, Cpad, n, C, h->gf(H.ob), s));
+  KCHK(run_wgrad(h, lin_wgrad(h->hdlg, Cpad, h->hy, d, h->gf(H.ow), n, C, d, 0.f), s));
+  g = lin_dgrad(h->hdlg, Cpad, h->wb(H.ow), n, Cpad, d);   // reduction over the padded class dim (pad columns are zero)
+  g.N = d; g.K = Cpad; g.act = 4; g.aux = h->hy; g.ld_aux = d; g.out_bf16 = h->hdy; g.ld_out_bf16 = d;
+  KCHK(run_gemm(g, s));
+  // dense
+  KCHK(bias_grad(h, h->hdy, d, n, d, h->gf(H.db), s));
+  KCHK(run_wgrad(h, lin_wgrad(h->hdy, d, h->hx, din, h->gf(H.dw), n, d, din, 0.f), s));
+  g = lin_dgrad(h->hdy, d, h->wb(H.dw), n, d, din);
+  g.out_bf16 = h->hdx; g.ld_out_bf16 = din;
+  KCHK(run_gemm(g, s));
+  HIPCHK(kmb_scatter_add_rows_launch(h->hdx, din, rows_a, h->dhead, n, d, s));
+  if (rows_b) HIPCHK(kmb_scatter_add_rows_launch(h->hdx + d, din, rows_b, h->dhead, n, d, s));
+  return 0;
+}
+
 int encoder_forward(kmb_handle* h, const kmb_batch& bt, bool train, hipStream_t s) {
   const int d = h->d, B = bt.B, S = bt.S, Me = B * S;
   const float eps = h->cfg.layer_norm_eps;
@@ -558,6 +630,22 @@ int kmb_create(const kmb_config* cfg, kmb_handle** out) {
     add_ffn(h, p, h->Fd, h->dec[l]);
   }
   marks.push_back(align_up(h->arena, 64));
+  {  // BartClassificationHead: dense -> tanh -> out_proj
+    const char* names[3] = {"mrm_head", "attribute_head", "relation_head"};
+    const int C[3] = {cfg->num_labels, cfg->num_attributes, cfg->num_relations};
+    h->heads_begin = align_up(h->arena, 64);
+    for (int k = 0; k < 3; ++k) {
+      if (C[k] <= 0) continue;
+      HeadP& H = h->head[k];
+      H.on = true; H.C = C[k]; H.d_in = (k == 2) ? 2 * d : d;
+      const std::string n = names[k];
+      H.dw = add_param(h, n + ".dense.weight", d, H.d_in);
+      H.db = add_param(h, n + ".dense.bias", 1, d);
+      H.ow = add_param(h, n + ".out_proj.weight", H.C, d);
+      H.ob = add_param(h, n + ".out_proj.bias", 1, H.C);
+    }
+    h->heads_end = align_up(h->arena, 64);
+  }
   h->shared = add_param(h, "model.shared.weight", h->V, d);
   h->arena = align_up(h->arena, 64);
   // arena segments: [0,m0) enc embed+img | enc layers | dec embed | dec layers | shared
@@ -565,10 +653,12 @@ int kmb_create(const kmb_config* cfg, kmb_handle** out) {
   const int Le = cfg->encoder_layers, Ld = cfg->decoder_layers;
   auto seg = [&](size_t a, size_t b) { h->buckets.push_back({a, b - a}); };
   for (int l = Ld - 1; l >= 0; --l) seg(marks[Le + 1 + l], marks[Le + 2 + l]);
+  // (the decoder-layer-0 segment ends where the heads begin; the heads' gradients are complete after forward and
+  //  ride in the last bucket together with the tied matrix)
   seg(marks[Le], marks[Le + 1]);
   for (int l = Le - 1; l >= 0; --l) seg(marks[l], marks[l + 1]);
   seg(0, marks[0]);
-  seg(h->shared, h->arena);
+  seg(h->heads_begin, h->arena);  // heads (if any) + tied matrix
   h->events.resize(h->buckets.size());
   for (auto& e : h->events) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
@@ -660,8 +750,8 @@ int kmb_read_status(kmb_handle* h, int32_t* status_host, void* stream) {
 }
 
 // --------------------------------------------------------------------------------- forward
-int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad, float* loss_out, float* logits_out,
-                kmb_bf16* enc_out, void* stream) {
+static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, int train, int need_grad,
+                        float* loss_out, float* logits_out, kmb_bf16* enc_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   KCHK(check_bound(h));
   if (!batch || !batch->input_ids || !batch->decoder_input_ids || !batch->feat_offsets)
@@ -730,7 +820,7 @@ int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad,
       g.out_f32 = lg; g.ld_out_f32 = h->Vpad;
       KCHK(run_gemm(g, s));
       if (!bt.labels) continue;
-      HIPCHK(kmb_ce_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, 1.f, h->loss_rows + r0,
+      HIPCHK(kmb_ce_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, extra ? extra->lm_factor : 1.f, h->loss_rows + r0,
                            need_grad ? h->dlogits_c + (size_t)r0 * h->Vpad : nullptr, s));
     }
     if (bt.labels && need_grad) {
@@ -746,8 +836,49 @@ int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad,
       if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
     }
   }
+  if (extra) {
+    // ---- pre-training heads on the decoder states (src/model/model.py:248-289) and the weighted total (:304-307)
+    const bool any = (extra->n_mrm > 0 && h->head[0].on) || (extra->n_attr > 0 && h->head[1].on) ||
+                     (extra->n_rel > 0 && h->head[2].on);
+    if (need_grad && any) HIPCHK(hipMemsetAsync(h->dhead, 0, (size_t)Md * d * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(h->losses5, 0, 8 * sizeof(float), s));
+    if (bt.labels) HIPCHK(kmb_mean_rows_launch(h->loss_dev, 1, extra->lm_factor, 1.f, h->losses5 + 1, s));
+    if (h->head[0].on)
+      KCHK(head_run(h, 0, hdec, extra->n_mrm, extra->mrm_rows, nullptr, extra->mrm_targets, nullptr, extra->mrm_factor,
+                    need_grad != 0, h->losses5 + 2, s));
+    if (h->head[1].on)
+      KCHK(head_run(h, 1, hdec, extra->n_attr, extra->attr_rows, nullptr, nullptr, extra->attr_labels,
+                    extra->attr_factor, need_grad != 0, h->losses5 + 3, s));
+    if (h->head[2].on)
+      KCHK(head_run(h, 2, hdec, extra->n_rel, extra->rel_obj_rows, extra->rel_subj_rows, nullptr, extra->rel_labels,
+                    extra->rel_factor, need_grad != 0, h->losses5 + 4, s));
+    if (need_grad && any) HIPCHK(kmb_add_f32_into_bf16_launch(h->dhdec, h->dhead, (size_t)Md * d, s));
+    HIPCHK(kmb_mean_rows_launch(h->losses5 + 1, 4, 1.f, 1.f, h->losses5, s));
+    if (extra->losses_out)
+      HIPCHK(hipMemcpyAsync(extra->losses_out, h->losses5, 5 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   h->have_fwd = need_grad != 0;
   return 0;
+}
+
+int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad, float* loss_out, float* logits_out,
+                kmb_bf16* enc_out, void* stream) {
+  return forward_impl(h, batch, nullptr, train, need_grad, loss_out, logits_out, enc_out, stream);
+}
+
+int kmb_reserve_head_rows(kmb_handle* h, int n) {
+  if (n < 0) return fail("kmb_reserve_head_rows: negative row count");
+  h->head_rows_cap = n;
+  return 0;
+}
+
+int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, int train, int need_grad,
+                         float* logits_out, kmb_bf16* enc_out, void* stream) {
+  if (!extra) return fail("kmb_forward_pretrain: extra is required");
+  if (need_grad && !batch->labels) return fail("kmb_forward_pretrain: need_grad requires labels");
+  if ((extra->n_mrm > 0 && !h->head[0].on) || (extra->n_attr > 0 && !h->head[1].on) || (extra->n_rel > 0 && !h->head[2].on))
+    return fail("kmb_forward_pretrain: rows given for a head this model was built without (num_labels / num_attributes / num_relations)");
+  return forward_impl(h, batch, extra, train, need_grad, nullptr, logits_out, enc_out, stream);
 }
 
 // --------------------------------------------------------------------------------- backward

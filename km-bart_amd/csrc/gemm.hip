@@ -30,6 +30,15 @@ constexpr int CS256 = 16 * 128 * 4, CS512 = 32 * 128 * 4;  // column-sum scratch
 constexpr int EPI_BYTES = BM * EPI_LD * 4;
 constexpr int LDS_BYTES = ((EPI_BYTES > 2 * STAGE_BYTES) ? EPI_BYTES : 2 * STAGE_BYTES) + CS256;  // 74 KB: two per CU
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2): give every XCD a contiguous range
+// of tile ids so that neighbouring tiles -- which share an A row panel -- hit the same L2 (bijective for any grid).
+// Measured need: rocprof FETCH_SIZE showed the A panel fetched ~6x its size without the remap.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 __device__ __forceinline__ int swz_nkc(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
 // ---- global -> register staging of one 128x64 (KC) or 64x128 (non-KC) tile: 4 chunks / thread ----
@@ -183,6 +192,18 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
+    } else if (p.act == 3) {  // BartClassificationHead: tanh
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+    } else if (p.act == 4) {  // multiply by tanh'(.) = 1 - y^2, aux = y (the stored tanh output)
+      float y[8];
+      if (nvalid == 8) {
+        unpack8(*reinterpret_cast<const u32x4*>(p.aux + (size_t)grow * p.ld_aux + gcol), y);
+      } else {
+        for (int e = 0; e < 8; ++e) y[e] = e < nvalid ? bf2f(p.aux[(size_t)grow * p.ld_aux + gcol + e]) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= (1.f - y[e] * y[e]);
     }
     if (p.drop_thr16 != 0u) {
 #pragma unroll
@@ -251,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
@@ -346,7 +368,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
@@ -465,7 +488,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN4 - 1) / BN4;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM4, col0 = tn * BN4;
 
@@ -588,6 +612,12 @@ __device__ __forceinline__ void epilogue_regs(const KmbGemm& p, f32x4 (&acc)[MI]
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(u[e]);
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      } else if (p.act == 4) {
+        const bf16_t* a = p.aux + (size_t)grow * p.ld_aux + gcol;
+        for (int e = 0; e < nvalid; ++e) { const float y = bf2f(a[e]); v[e] *= (1.f - y * y); }
       }
       if (p.drop_thr16 != 0u) {
 #pragma unroll
@@ -642,7 +672,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v5(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int tile = blockIdx.x / nsl, slice = blockIdx.x % nsl;
+  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
@@ -704,7 +735,7 @@ const char* kmb_gemm_check(const KmbGemm& p) {
   if (p.aux && ((p.ld_aux & 7) || ((uintptr_t)p.aux & 15))) return "gemm: aux alignment";
   if (p.preact && ((p.ld_preact & 7) || ((uintptr_t)p.preact & 15))) return "gemm: preact alignment";
   if (p.out_f32 && ((uintptr_t)p.out_f32 & 15)) return "gemm: f32 output alignment";
-  if (p.act == 2 && !p.aux) return "gemm: gelu-backward epilogue needs aux";
+  if ((p.act == 2 || p.act == 4) && !p.aux) return "gemm: derivative epilogue needs aux";
   if (!p.a_kc && p.b_kc) return "gemm: (M-contiguous A, K-contiguous B) is not instantiated";
   if (p.colsum && p.split_k > 1) return "gemm: column sums are not available with split-K";
   if (p.split_k > 1) {
@@ -792,35 +823,39 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   if (!dma_ok) return launch_variant(1, p, stream);
   if (forced) {
     int v = forced;
-    if (v == 3 || (v == 4 && !(big && p.N > 128))) v = 5;
+    if (v == 3 || (v == 4 && !(big && p.N > 128))) v = 2;
     return launch_variant(v, p, stream);
   }
-  if (!big || p.N <= 128) return launch_variant(5, p, stream);
+  if (!big || p.N <= 128) return launch_variant(2, p, stream);
   const TuneKey key{p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act};
   auto it = g_best.find(key);
   if (it == g_best.end()) {
-    if (!autotune || writes_an_input(p)) return launch_variant(5, p, stream);
-    const int cands[3] = {2, 5, 4};
+    if (!autotune || writes_an_input(p)) return launch_variant(2, p, stream);
+    const int cands[4] = {2, 2 + 16, 4, 4 + 16};   // variant | (tile_order << 4)
     float best_ms = 1e30f;
     int best = 2;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_variant(2, p, stream);
     for (int c : cands) {
-      hipError_t e = launch_variant(c, p, stream);  // warm
+      KmbGemm q = p;
+      q.tile_order = c >> 4;
+      hipError_t e = launch_variant(c & 15, q, stream);  // warm
       if (e != hipSuccess) return e;
       (void)hipEventRecord(e0, stream);
-      for (int rep = 0; rep < 3; ++rep) (void)launch_variant(c, p, stream);
+      for (int rep = 0; rep < 3; ++rep) (void)launch_variant(c & 15, q, stream);
       (void)hipEventRecord(e1, stream);
       if (hipEventSynchronize(e1) != hipSuccess) return hipGetLastError();
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, e0, e1);
-      if (verbose) fprintf(stderr, "[kmb gemm tune] akc=%d bkc=%d M=%d N=%d K=%d split=%d act=%d v%d %.1f us\n", p.a_kc,
-                           p.b_kc, p.M, p.N, p.K, p.split_k, p.act, c, ms / 3 * 1e3);
+      if (verbose) fprintf(stderr, "[kmb gemm tune] akc=%d bkc=%d M=%d N=%d K=%d split=%d act=%d v%d order%d %.1f us\n",
+                           p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act, c & 15, c >> 4, ms / 3 * 1e3);
       if (ms < best_ms) { best_ms = ms; best = c; }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     it = g_best.emplace(key, best).first;
   }
-  return launch_variant(it->second, p, stream);
+  KmbGemm q = p;
+  q.tile_order = it->second >> 4;
+  return launch_variant(it->second & 15, q, stream);
 }

@@ -95,3 +95,13 @@ hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst
 hipError_t kmb_dropout_mask_launch(uint32_t seed, uint32_t thr16, int rows, int cols, uint8_t* keep, hipStream_t stream);
 hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, hipStream_t stream);
 hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, hipStream_t stream);
+
+// ---------------------------------------------------------------- heads.hip
+hipError_t kmb_kl_div_launch(const float* logits, int ld, int C, const float* target, int ldt, int rows,
+                             float grad_scale, float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream);
+hipError_t kmb_gather_rows_bf16_launch(const bf16_t* src, int src_ld, const int32_t* idx, bf16_t* dst, int dst_ld,
+                                       int rows, int cols, hipStream_t stream);
+hipError_t kmb_scatter_add_rows_launch(const bf16_t* src, int src_ld, const int32_t* idx, float* acc, int rows, int cols,
+                                       hipStream_t stream);
+hipError_t kmb_add_f32_into_bf16_launch(bf16_t* y, const float* a, size_t n, hipStream_t stream);
+hipError_t kmb_mean_rows_launch(const float* rows, int n, float factor, float denom, float* out, hipStream_t stream);

@@ -19,7 +19,8 @@ class KmbConfig(C.Structure):
         "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_position_embeddings",
         "extra_pos_embeddings", "image_feature_size", "pad_token_id", "bos_token_id", "eos_token_id",
         "img_feat_id", "cls_token_id", "scale_embedding")] + [
-        ("dropout", f32), ("attention_dropout", f32), ("activation_dropout", f32), ("layer_norm_eps", f32)]
+        ("dropout", f32), ("attention_dropout", f32), ("activation_dropout", f32), ("layer_norm_eps", f32),
+        ("num_labels", i32), ("num_attributes", i32), ("num_relations", i32)]
 
 
 class KmbBatch(C.Structure):
@@ -28,13 +29,21 @@ class KmbBatch(C.Structure):
                 ("n_features", i32), ("decoder_input_ids", c_p), ("decoder_attention_mask", c_p), ("labels", c_p)]
 
 
+class KmbPretrain(C.Structure):
+    _fields_ = [("n_mrm", i32), ("mrm_rows", c_p), ("mrm_targets", c_p),
+                ("n_attr", i32), ("attr_rows", c_p), ("attr_labels", c_p),
+                ("n_rel", i32), ("rel_obj_rows", c_p), ("rel_subj_rows", c_p), ("rel_labels", c_p),
+                ("lm_factor", f32), ("mrm_factor", f32), ("attr_factor", f32), ("rel_factor", f32),
+                ("losses_out", c_p)]
+
+
 class KmbGemm(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("lda", i32), ("ldb", i32), ("a_kc", i32), ("b_kc", i32),
                 ("M", i32), ("N", i32), ("K", i32), ("bias", c_p), ("col_scale", f32), ("col_scale_n", i32),
                 ("act", i32), ("preact", c_p), ("ld_preact", i32), ("aux", c_p), ("ld_aux", i32),
                 ("drop_thr16", u32), ("drop_seed", u32), ("drop_scale", f32), ("residual", c_p), ("ld_res", i32),
                 ("out_bf16", c_p), ("ld_out_bf16", i32), ("out_f32", c_p), ("ld_out_f32", i32), ("beta", f32),
-                ("split_k", i32), ("slab", c_p), ("colsum", c_p)]
+                ("split_k", i32), ("slab", c_p), ("colsum", c_p), ("tile_order", i32)]
 
 
 class KmbAttn(C.Structure):
@@ -80,6 +89,8 @@ PROTOTYPES = {
     "kmb_stream_wait_bucket": (C.c_int, [c_p, C.c_int, c_p]),
     "kmb_logits_ld": (C.c_int, [c_p]),
     "kmb_forward": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p, c_p, c_p, c_p]),
+    "kmb_reserve_head_rows": (C.c_int, [c_p, C.c_int]),
+    "kmb_forward_pretrain": (C.c_int, [c_p, C.POINTER(KmbBatch), C.POINTER(KmbPretrain), C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_backward": (C.c_int, [c_p, f32, c_p]),
     "kmb_adamw_step": (C.c_int, [c_p, C.POINTER(KmbAdamW), i64, i64, c_p]),
     "kmb_read_status": (C.c_int, [c_p, C.POINTER(i32), c_p]),

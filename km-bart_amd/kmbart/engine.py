@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import KmbAdamW, KmbBatch, KmbConfig, check, ptr
+from ._lib import KmbAdamW, KmbBatch, KmbConfig, KmbPretrain, check, ptr
 
 _CFG_INT_FIELDS = ("vocab_size", "d_model", "encoder_layers", "decoder_layers", "encoder_attention_heads",
                    "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_position_embeddings",
@@ -36,7 +36,7 @@ def pack_features(image_features, feat_dim, device):
 class Engine:
     """One model replica on one GPU."""
 
-    def __init__(self, config, device):
+    def __init__(self, config, device, with_heads=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.KmbError("the KM-BART hot path needs an MI355X (HIP) device; there is no CPU fallback")
@@ -52,6 +52,12 @@ class Engine:
         c.attention_dropout = float(config.attention_dropout)
         c.activation_dropout = float(config.activation_dropout)
         c.layer_norm_eps = 1e-5
+        if with_heads:  # MultiModalBartForPreTraining (reference src/model/model.py:133-158)
+            if float(getattr(config, "classif_dropout", 0.0)) != 0.0:
+                raise NotImplementedError("classif_dropout != 0 is not implemented (pretrain_base.json uses 0.0)")
+            c.num_labels = int(config.num_labels)
+            c.num_attributes = int(config.num_attributes)
+            c.num_relations = int(config.num_relations)
         self._ccfg = c
         h = C.c_void_p()
         check(self.lib.kmb_create(C.byref(c), C.byref(h)))
@@ -152,6 +158,48 @@ class Engine:
             if logits is not None:
                 logits = logits.view(B, T, self.logits_ld)[:, :, : int(self.config.vocab_size)]
             return loss, logits, enc
+
+    def forward_pretrain(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask,
+                         labels, mrm=None, attr=None, rel=None, factors=(1.0, 1.0, 1.0, 1.0), train=False,
+                         need_grad=False, want_logits=False):
+        """mrm = (rows int32 [n], soft targets fp32 [n, C]); attr = (rows, labels int64); rel = (obj rows, subj rows,
+        labels).  Returns (losses fp32 [5] = total, lm, mrm, attribute, relation; logits or None)."""
+        with torch.cuda.device(self.device):
+            b, keep, (B, S, T, ntot) = self._batch(input_ids, image_features, attention_mask, decoder_input_ids,
+                                                   decoder_attention_mask, labels)
+            dev = self.device
+
+            def i32(t):
+                return t.to(device=dev, dtype=torch.int32).contiguous()
+
+            ex = KmbPretrain(lm_factor=factors[0], mrm_factor=factors[1], attr_factor=factors[2], rel_factor=factors[3])
+            nmax = 0
+            if mrm is not None and mrm[0].numel() > 0:
+                rows, tgt = i32(mrm[0]), mrm[1].to(device=dev, dtype=torch.float32).contiguous()
+                ex.n_mrm, ex.mrm_rows, ex.mrm_targets = rows.numel(), ptr(rows), ptr(tgt)
+                keep += [rows, tgt]
+                nmax = max(nmax, rows.numel())
+            if attr is not None and attr[0].numel() > 0:
+                rows, lab = i32(attr[0]), attr[1].to(device=dev, dtype=torch.int64).contiguous()
+                ex.n_attr, ex.attr_rows, ex.attr_labels = rows.numel(), ptr(rows), ptr(lab)
+                keep += [rows, lab]
+                nmax = max(nmax, rows.numel())
+            if rel is not None and rel[0].numel() > 0:
+                ro, rs, lab = i32(rel[0]), i32(rel[1]), rel[2].to(device=dev, dtype=torch.int64).contiguous()
+                ex.n_rel, ex.rel_obj_rows, ex.rel_subj_rows, ex.rel_labels = ro.numel(), ptr(ro), ptr(rs), ptr(lab)
+                keep += [ro, rs, lab]
+                nmax = max(nmax, ro.numel())
+            check(self.lib.kmb_reserve_head_rows(self.h, max(nmax, 8)))
+            self._ensure_ws(self.lib.kmb_workspace_bytes(self.h, B, S, T, ntot))
+            losses = torch.zeros(5, dtype=torch.float32, device=dev)
+            ex.losses_out = ptr(losses)
+            logits = torch.empty((B * T, self.logits_ld), dtype=torch.float32, device=dev) if want_logits else None
+            check(self.lib.kmb_forward_pretrain(self.h, C.byref(b), C.byref(ex), 1 if train else 0,
+                                                1 if need_grad else 0, ptr(logits), None, _stream()))
+            self._keep = keep
+            if logits is not None:
+                logits = logits.view(B, T, self.logits_ld)[:, :, : int(self.config.vocab_size)]
+            return losses, logits
 
     def check_inputs(self):
         """Raises if the device-side validation of the last forward flagged the batch (syncs)."""

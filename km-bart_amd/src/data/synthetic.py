@@ -69,3 +69,39 @@ def make_batch(batch_size, enc_len=64, dec_len=32, num_regions=36, seed=1234, fe
         "index": list(range(b)),
         "task_type": ["intent"] * b,
     }
+
+
+def make_pretrain_batch(batch_size, enc_len=80, dec_len=48, num_regions=50, seed=1234, num_labels=1601,
+                        num_attributes=129, num_relations=129, mrm_probability=0.2, n_attr=4, n_rel=3, cls_id=50276,
+                        **kw):
+    """Synthetic multi-task pre-training batch (BASELINE config 4): the VCG batch plus
+    masked-region-modelling targets (soft labels over `num_labels` classes at decoder positions whose label is
+    <cls>, reference src/data/collation.py:113-147), attribute labels and relation triples."""
+    b = make_batch(batch_size, enc_len=enc_len, dec_len=dec_len, num_regions=num_regions, seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed + 7)
+    labels = b["labels"]
+    B, T = labels.shape
+    valid = labels != -100
+    mrm_mask = (torch.rand((B, T), generator=g) < mrm_probability) & valid
+    mrm_mask[:, 0] = False
+    labels[mrm_mask] = cls_id                      # collation.py: masked regions carry <cls> as their label
+    b["mrm_mask"] = labels == cls_id
+    b["mrm_labels"] = [torch.softmax(torch.randn((int(m.sum()), num_labels), generator=g), dim=-1) for m in b["mrm_mask"]]
+    attr_mask = torch.zeros((B, T))
+    attr_labels, rel_labels = [], []
+    for i in range(B):
+        pos = torch.nonzero(valid[i] & ~b["mrm_mask"][i]).reshape(-1)
+        pick = pos[torch.randperm(len(pos), generator=g)[: min(n_attr, len(pos))]]
+        attr_mask[i, pick] = 1
+        attr_labels.append(torch.randint(0, num_attributes, (len(pick),), generator=g))
+        rels = []
+        for _ in range(n_rel):
+            o, s = [int(x) for x in pos[torch.randint(0, len(pos), (2,), generator=g)]]
+            rels.append({"object_index": o, "subject_index": s,
+                         "label": int(torch.randint(0, num_relations, (1,), generator=g))})
+        rel_labels.append(rels)
+    # the reference orders attribute labels by position (boolean-mask order)
+    b["attribute_mask"] = attr_mask
+    b["attribute_labels"] = attr_labels
+    b["relation_labels"] = rel_labels
+    return b

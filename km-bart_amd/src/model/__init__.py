@@ -1,4 +1,6 @@
 from src.model.config import MultiModalBartConfig
-from src.model.model import (LazyLogits, MultiModalBartForConditionalGeneration, MultiModalBartModel)
+from src.model.model import (LazyLogits, MultiModalBartForConditionalGeneration, MultiModalBartForPreTraining,
+                             MultiModalBartModel)
 
-__all__ = ["MultiModalBartConfig", "MultiModalBartForConditionalGeneration", "MultiModalBartModel", "LazyLogits"]
+__all__ = ["MultiModalBartConfig", "MultiModalBartForConditionalGeneration", "MultiModalBartForPreTraining",
+           "MultiModalBartModel", "LazyLogits"]

@@ -19,7 +19,7 @@ WEIGHTS_NAME = "pytorch_model.bin"
 _TIED = ("model.encoder.embed_tokens.weight", "model.decoder.embed_tokens.weight")
 
 
-def _param_names(cfg):
+def _param_names(cfg, with_heads=False):
     names = ["model.encoder.embed_images.linear.weight", "model.encoder.embed_images.linear.bias",
              "model.encoder.embed_positions.weight", "model.encoder.layernorm_embedding.weight",
              "model.encoder.layernorm_embedding.bias"]
@@ -46,12 +46,21 @@ def _param_names(cfg):
     for i in range(cfg.decoder_layers):
         p = f"model.decoder.layers.{i}."
         names += attn(p, "self_attn") + attn(p, "encoder_attn") + ffn(p)
+    for head, attr in (("mrm_head", "num_labels"), ("attribute_head", "num_attributes"), ("relation_head", "num_relations")):
+        if with_heads and getattr(cfg, attr, 0) > 0:
+            names += [f"{head}.dense.weight", f"{head}.dense.bias", f"{head}.out_proj.weight", f"{head}.out_proj.bias"]
     names.append("model.shared.weight")
     return names
 
 
 def _param_shape(cfg, name):
     d = cfg.d_model
+    for head, attr, mult in (("mrm_head", "num_labels", 1), ("attribute_head", "num_attributes", 1),
+                             ("relation_head", "num_relations", 2)):
+        if name.startswith(head + "."):
+            C = getattr(cfg, attr)
+            return {"dense.weight": (d, mult * d), "dense.bias": (d,), "out_proj.weight": (C, d),
+                    "out_proj.bias": (C,)}[name[len(head) + 1:]]
     if name == "model.shared.weight":
         return (cfg.vocab_size, d)
     if name.endswith("embed_images.linear.weight"):
@@ -140,13 +149,14 @@ class BeamHypotheses:
 class MultiModalBartForConditionalGeneration(nn.Module):
     base_model_prefix = "model"
     config_class = MultiModalBartConfig
+    _with_heads = False
 
     def __init__(self, config: MultiModalBartConfig):
         super().__init__()
         config.check_supported()
         self.config = config
         self._engine = None
-        self._names = _param_names(config)
+        self._names = _param_names(config, self._with_heads)
         g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
         self._p = {}
         # transformers `init_weights` (model.py:37): N(0, init_std), zero biases / pad rows, LayerNorm (1, 0)
@@ -226,7 +236,7 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             if self._engine.device != device:
                 raise RuntimeError("model already lives on %s" % self._engine.device)
             return self
-        eng = Engine(self.config, device)
+        eng = Engine(self.config, device, with_heads=self._with_heads)
         with torch.no_grad():
             for n in self._names:
                 eng.view(eng.params, n).copy_(self._p[n].detach().to(device))
@@ -537,6 +547,79 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                     tgt[tuple(slice(0, s) for s in val.shape)] = val
         model.eval()
         return model
+
+
+class _DeviceLossDict(dict):
+    """`outputs[0]` of MultiModalBartForPreTraining: {'loss', 'lm_loss', 'mrm_loss', ...} of 0-dim device tensors."""
+
+
+class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
+    """Multi-task pre-training model (reference src/model/model.py:125-309): the conditional-generation model plus
+    three BartClassificationHeads on the decoder states -- masked-region modelling (KL divergence to soft labels),
+    attribute prediction and relation prediction (cross entropy) -- and the weighted loss
+    lm_loss_factor * lm + mrm_loss_factor * mrm + attribute_loss_factor * attr + relation_loss_factor * rel."""
+    _with_heads = True
+
+    def forward(self, input_ids, image_features, attention_mask=None, encoder_outputs=None, decoder_input_ids=None,
+                decoder_attention_mask=None, decoder_cached_states=None, labels=None, mrm_labels=None, mrm_mask=None,
+                attribute_labels=None, attribute_mask=None, relation_labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_logits=None, **unused):
+        eng = self._need_engine()
+        cfg = self.config
+        if encoder_outputs is not None or decoder_cached_states is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("only the training forward of MultiModalBartForPreTraining is implemented")
+        if labels is None and mrm_labels is None and attribute_labels is None and relation_labels is None:
+            return super().forward(input_ids, image_features, attention_mask=attention_mask,
+                                   decoder_input_ids=decoder_input_ids, decoder_attention_mask=decoder_attention_mask)
+        B, T = decoder_input_ids.shape
+        dev = eng.device
+        mrm = attr = rel = None
+        if mrm_labels is not None:
+            rows = torch.nonzero(mrm_mask.reshape(-1).to(dev), as_tuple=False).reshape(-1)
+            tgt = torch.cat([m.to(dev) for m in mrm_labels], 0) if len(mrm_labels) else torch.zeros((0, cfg.num_labels))
+            if rows.numel() != tgt.shape[0]:
+                raise RuntimeError("mrm_mask selects %d rows but mrm_labels holds %d" % (rows.numel(), tgt.shape[0]))
+            mrm = (rows, tgt)
+        if attribute_labels is not None:
+            rows = torch.nonzero(attribute_mask.reshape(-1).to(dev), as_tuple=False).reshape(-1)
+            lab = torch.cat([a.to(dev).reshape(-1) for a in attribute_labels], 0) if len(attribute_labels) else torch.zeros(0)
+            if rows.numel() != lab.numel():
+                raise RuntimeError("attribute_mask selects %d rows but attribute_labels holds %d" % (rows.numel(), lab.numel()))
+            attr = (rows, lab)
+        if relation_labels is not None:  # list (per sample) of dicts {object_index, subject_index, label} (model.py:274-280)
+            ro, rs, lab = [], [], []
+            for i, rels in enumerate(relation_labels):
+                for r in rels:
+                    ro.append(i * T + int(r["object_index"]))
+                    rs.append(i * T + int(r["subject_index"]))
+                    lab.append(int(r["label"]))
+            rel = (torch.tensor(ro, dtype=torch.int32), torch.tensor(rs, dtype=torch.int32),
+                   torch.tensor(lab, dtype=torch.int64))
+        lm_labels = None
+        if labels is not None:
+            lm_labels = labels.clone()
+            lm_labels[lm_labels == cfg.cls_token_id] = -100   # model.py:297-298
+        if lm_labels is None:
+            raise NotImplementedError("pre-training forward without LM labels is not implemented")
+        need_grad = torch.is_grad_enabled()
+        factors = (float(cfg.lm_loss_factor), float(cfg.mrm_loss_factor), float(cfg.attribute_loss_factor),
+                   float(cfg.relation_loss_factor))
+        losses, logits = eng.forward_pretrain(input_ids, image_features, attention_mask, decoder_input_ids,
+                                              decoder_attention_mask, lm_labels, mrm=mrm, attr=attr, rel=rel,
+                                              factors=factors, train=self.training, need_grad=need_grad,
+                                              want_logits=bool(return_logits))
+        total = _LossFn.apply(self._anchor, self, losses[0:1]) if need_grad else losses[0]
+        out = _DeviceLossDict(loss=total, lm_loss=losses[1])
+        if mrm is not None and mrm[0].numel() > 0:
+            out["mrm_loss"] = losses[2]
+        if attr is not None and attr[0].numel() > 0:
+            out["attribute_loss"] = losses[3]
+        if rel is not None and rel[0].numel() > 0:
+            out["relation_loss"] = losses[4]
+        if logits is None:
+            args = (input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask)
+            logits = LazyLogits(lambda: self._logits_only(*args))
+        return (out, logits)
 
 
 def _top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("inf"), min_tokens_to_keep=1):

@@ -7,7 +7,7 @@ the small inputs and the expected outputs.
 import numpy as np
 import torch
 
-from .kmbart_oracle import OracleConfig, param_names, param_shape
+from .kmbart_oracle import OracleConfig, head_param_names, param_names, param_shape
 
 # special ids of the tiny vocabulary: same ordering as src/data/tokenization.py:36-57,
 # re-based from 50265 to 480 so they fit V=512
@@ -46,7 +46,7 @@ def golden_state_dict(cfg, seed=7):
     too (non-trivial values exercise the bias / gamma / beta paths); pad rows zero."""
     sd = {}
     a = cfg.init_std * (3.0 ** 0.5)
-    for k, n in enumerate(param_names(cfg)):
+    for k, n in enumerate(param_names(cfg) + head_param_names(cfg)):
         shp = param_shape(cfg, n)
         u = torch.from_numpy(lcg_uniform(int(np.prod(shp)), seed * 1000 + k)).view(shp)
         if "layer_norm" in n or "layernorm" in n:

@@ -52,7 +52,8 @@ DEFAULTS = dict(
     attention_dropout=0.0, dropout=0.1, max_position_embeddings=1024,
     init_std=0.02, pad_token_id=1, bos_token_id=0, eos_token_id=2,
     img_feat_id=50273, cls_token_id=50276, scale_embedding=False,
-    decoder_start_token_id=0,
+    decoder_start_token_id=0, num_labels=0, num_attributes=0, num_relations=0,
+    lm_loss_factor=1.0, mrm_loss_factor=1.0, attribute_loss_factor=1.0, relation_loss_factor=1.0,
     # transformers 3.0.2 PretrainedConfig generation defaults
     max_length=20, min_length=0, num_beams=1, length_penalty=1.0,
     early_stopping=False, num_return_sequences=1,
@@ -103,8 +104,25 @@ def param_names(cfg):
     return names
 
 
+HEADS = (("mrm_head", "num_labels", 1), ("attribute_head", "num_attributes", 1), ("relation_head", "num_relations", 2))
+
+
+def head_param_names(cfg):
+    """BartClassificationHead parameters of MultiModalBartForPreTraining (src/model/model.py:133-158)."""
+    out = []
+    for name, attr, _ in HEADS:
+        if getattr(cfg, attr, 0) > 0:
+            out += [f"{name}.dense.weight", f"{name}.dense.bias", f"{name}.out_proj.weight", f"{name}.out_proj.bias"]
+    return out
+
+
 def param_shape(cfg, name):
     d = cfg.d_model
+    for hname, attr, mult in HEADS:
+        if name.startswith(hname + "."):
+            C = getattr(cfg, attr)
+            return {"dense.weight": (d, mult * d), "dense.bias": (d,), "out_proj.weight": (C, d),
+                    "out_proj.bias": (C,)}[name[len(hname) + 1:]]
     if name == "model.shared.weight":
         return (cfg.vocab_size, d)
     if name.endswith("embed_images.linear.weight"):
@@ -305,6 +323,54 @@ def forward(sd, cfg, input_ids, image_features, attention_mask=None, decoder_inp
     if labels is not None:
         loss = F.cross_entropy(logits.view(-1, cfg.vocab_size), labels.view(-1))  # ignore_index=-100, mean
     return loss, logits, encoder_out
+
+
+def classification_head(sd, name, x):
+    """HF3.0.2 BartClassificationHead with classif_dropout = 0: out_proj(tanh(dense(x)))."""
+    return _lin(torch.tanh(_lin(x, sd, name + ".dense")), sd, name + ".out_proj")
+
+
+def pretrain_forward(sd, cfg, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask,
+                     labels=None, mrm_labels=None, mrm_mask=None, attribute_labels=None, attribute_mask=None,
+                     relation_labels=None, training=False):
+    """MultiModalBartForPreTraining.forward (src/model/model.py:162-309): LM loss with <cls> labels ignored,
+    KL-div(batchmean) masked-region modelling, attribute CE, relation CE on cat(object, subject) rows, weighted sum.
+    Returns (losses dict, lm_logits)."""
+    enc = encoder_forward(sd, cfg, input_ids, image_features, attention_mask, training)
+    pm, causal = prepare_decoder_masks(cfg, decoder_input_ids, decoder_attention_mask)
+    h, _ = decoder_forward(sd, cfg, decoder_input_ids, enc, attention_mask, pm, causal, training=training)
+    losses = {}
+    mrm_loss = attribute_loss = relation_loss = lm_loss = 0
+    if mrm_labels is not None:
+        rep = h[mrm_mask.bool()]
+        if len(rep) > 0:
+            pred = F.log_softmax(classification_head(sd, "mrm_head", rep), dim=1)
+            mrm_loss = F.kl_div(pred, torch.cat(mrm_labels, 0), reduction="batchmean") * cfg.mrm_loss_factor
+            losses["mrm_loss"] = mrm_loss
+    if attribute_labels is not None:
+        rep = h[attribute_mask.bool()]
+        if len(rep) > 0:
+            pred = classification_head(sd, "attribute_head", rep)
+            attribute_loss = F.cross_entropy(pred, torch.cat(attribute_labels, 0).reshape(-1)) * cfg.attribute_loss_factor
+            losses["attribute_loss"] = attribute_loss
+    if relation_labels is not None:
+        reps, ids = [], []
+        for i, rels in enumerate(relation_labels):
+            for rel in rels:
+                reps.append(torch.cat([h[i][rel["object_index"]], h[i][rel["subject_index"]]], 0))
+                ids.append(rel["label"])
+        if reps:
+            pred = classification_head(sd, "relation_head", torch.stack(reps))
+            relation_loss = F.cross_entropy(pred, torch.tensor(ids)) * cfg.relation_loss_factor
+            losses["relation_loss"] = relation_loss
+    logits = F.linear(h, sd["model.shared.weight"], sd["final_logits_bias"])
+    if labels is not None:
+        lab = labels.clone()
+        lab[lab == cfg.cls_token_id] = -100
+        lm_loss = F.cross_entropy(logits.view(-1, cfg.vocab_size), lab.reshape(-1)) * cfg.lm_loss_factor
+        losses["lm_loss"] = lm_loss
+    losses["loss"] = lm_loss + mrm_loss + attribute_loss + relation_loss
+    return losses, logits
 
 
 # --------------------------------------------------------------------------- #

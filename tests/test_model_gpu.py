@@ -265,3 +265,45 @@ def test_checkpoint_roundtrip_and_partial_load(tmp_path):
     part = MultiModalBartForConditionalGeneration.from_pretrained(str(tmp_path), config=cfg, state_dict=small)
     w = dict(part.named_parameters())["model.shared.weight"]
     assert torch.equal(w[:400], saved["model.shared.weight"][:400]) and w.shape[0] == 512
+
+
+def test_pretraining_heads_against_oracle():
+    """MultiModalBartForPreTraining (reference src/model/model.py:162-309): every loss term and every gradient,
+    including the three classification heads, against the oracle's autograd."""
+    from src.data.synthetic import make_pretrain_batch
+    from src.model import MultiModalBartForPreTraining
+    ocfg = G.tiny_config(num_labels=37, num_attributes=11, num_relations=9, lm_loss_factor=5.0, mrm_loss_factor=1.0,
+                         attribute_loss_factor=2.0, relation_loss_factor=0.5)
+    sd = G.golden_state_dict(ocfg, seed=33)
+    b = make_pretrain_batch(3, enc_len=24, dec_len=16, num_regions=6, seed=77, num_labels=37, num_attributes=11,
+                            num_relations=9, vocab_hi=G.TINY_SPECIAL_BASE, img_feat_id=ocfg.img_feat_id,
+                            special_base=G.TINY_SPECIAL_BASE, cls_id=ocfg.cls_token_id, mrm_probability=0.3)
+    b["image_features"] = G.golden_features([6, 6, 6])
+    osd = {k: v.clone().requires_grad_(k != "final_logits_bias") for k, v in sd.items()}
+    ref, _ = O.pretrain_forward(osd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"],
+                                b["decoder_input_ids"], b["decoder_attention_mask"], b["labels"], b["mrm_labels"],
+                                b["mrm_mask"], b["attribute_labels"], b["attribute_mask"], b["relation_labels"])
+    ref["loss"].backward()
+    cfg = cfg_from_oracle(ocfg, num_labels=37, num_attributes=11, num_relations=9, lm_loss_factor=5.0,
+                          mrm_loss_factor=1.0, attribute_loss_factor=2.0, relation_loss_factor=0.5)
+    model = MultiModalBartForPreTraining(cfg)
+    model.load_state_dict(sd, strict=False)
+    model.to(DEV).eval()
+    out = model(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
+                attention_mask=b["attention_mask"].to(DEV), decoder_input_ids=b["decoder_input_ids"].to(DEV),
+                decoder_attention_mask=b["decoder_attention_mask"].to(DEV), labels=b["labels"].to(DEV),
+                mrm_labels=b["mrm_labels"], mrm_mask=b["mrm_mask"], attribute_labels=b["attribute_labels"],
+                attribute_mask=b["attribute_mask"], relation_labels=b["relation_labels"])
+    losses = out[0]
+    for k in ("loss", "lm_loss", "mrm_loss", "attribute_loss", "relation_loss"):
+        assert abs(float(losses[k]) - float(ref[k])) <= 2e-3 * abs(float(ref[k])) + 1e-4, (k, float(losses[k]), float(ref[k]))
+    losses["loss"].backward()
+    worst = ("", 0.0)
+    for n, p in model.named_parameters():
+        r = osd[n].grad
+        if r is None or float(r.norm()) < 1e-10:
+            continue
+        e = rel(p.grad, r)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < GRAD_TOL, worst
