@@ -112,3 +112,29 @@ def test_generate_text_record_schema():
                         logger=types.SimpleNamespace(info=lambda m: None))
     assert [r["index"] for r in out] == [0, 1] and out[1]["generations"] == ["6 7 8", "9 10 11"]
     assert set(out[0]) == {"index", "task_type", "generations"}
+
+
+def test_pretrain_loop_uses_the_loss_dict():
+    """reference src/training.py:9-93: outputs[0] is a dict; 'loss' drives backward; kwargs of the forward call."""
+    from src.data.synthetic import make_pretrain_batch
+    from src.training import pretrain
+    log, lines = [], []
+
+    class M:
+        def train(self):
+            log.append("train")
+
+        def forward(self, **kw):
+            assert {"mrm_labels", "mrm_mask", "attribute_labels", "attribute_mask", "relation_labels", "labels"} <= set(kw)
+            assert isinstance(kw["mrm_labels"], list) and kw["mrm_mask"].dtype == torch.bool
+            log.append("forward")
+            return ({"loss": _FakeLoss(log, 2.0), "lm_loss": _FakeLoss([], 1.5), "mrm_loss": _FakeLoss([], 0.5)},)
+
+    b = make_pretrain_batch(2, enc_len=24, dec_len=16, num_regions=6, num_labels=11, num_attributes=5, num_relations=4)
+    assert b["mrm_labels"][0].shape == (int(b["mrm_mask"][0].sum()), 11)
+    assert abs(float(b["mrm_labels"][0].sum(-1)[0]) - 1.0) < 1e-5 and len(b["relation_labels"][1]) == 3
+    assert int(b["attribute_mask"][0].sum()) == len(b["attribute_labels"][0])
+    logger = types.SimpleNamespace(info=lambda m, pad=False: lines.append(m))
+    pretrain(0, M(), [b], _FakeOpt(log), "cpu", types.SimpleNamespace(amp=False, epochs=2), logger=logger)
+    assert log == ["train", "forward", "item", "zero_grad", "backward", "step"]
+    assert lines[0].startswith("Epoch [1/2], Step [1/1], Loss: 2.0000, ETA: ")
