@@ -222,6 +222,13 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[e] += v[e];
+    if (p.tile_order & 256) {  // ablation build path (tools/gemm_ablate.py): keep the math alive, drop the stores
+      float keep = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) keep += v[e];
+      if (keep == 1.2345e30f) p.out_bf16[0] = 0;
+      continue;
+    }
     if (p.out_bf16 != nullptr) {
       if (nvalid == 8) {
         *reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol) = pack8(v);
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
@@ -387,7 +394,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  const int nt_run = (p.tile_order & 512) ? 1 : nt;  // ablation: one K step only
+  for (int t = 0; t < nt_run; ++t) {
     char* cur = smem + (t & 1) * STAGE_BYTES;
     char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
     if (t + 1 < nt) {
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN4 - 1) / BN4;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM4, col0 = tn * BN4;
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v5(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int bid = p.tile_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tile = bid / nsl, slice = bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
