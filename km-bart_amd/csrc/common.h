@@ -15,17 +15,16 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4; // one 16-byte chunk
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+// (one instruction per two elements; the integer-arithmetic form costs ~6 VALU each and dominated the epilogues)
+typedef __attribute__((ext_vector_type(2))) __bf16 kmb_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float kmb_f32x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const kmb_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, kmb_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
+
 __device__ __forceinline__ float lo_bf(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
