@@ -56,14 +56,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // Returns cdf = Phi(x) and e = exp(-x^2 / 2) (shared with the derivative).
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-  e = __expf(-z * z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));      // v_rcp_f32 (1 ulp), no division sequence
+  e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);              // exp(-x^2 / 2) as one v_exp_f32
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
   poly = fmaf(poly, t, 0.254829592f);
-  const float erf_abs = 1.0f - poly * t * e;      // erf(|x| / sqrt 2)
-  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  const float h = 0.5f * poly * t * e;                                   // 0.5 * (1 - erf(|x| / sqrt 2))
+  cdf = x >= 0.f ? 1.0f - h : h;
 }
 __device__ __forceinline__ float gelu_f(float x) {
   float cdf, e;
@@ -83,6 +83,8 @@ __device__ __forceinline__ uint32_t kmb_hash32(uint32_t x) {
   return x;
 }
 __device__ __forceinline__ bool drop_keep(uint32_t site_seed, uint32_t row, uint32_t col, uint32_t thr16) {
-  const uint32_t h = kmb_hash32((row * 0x9E3779B1u) ^ (col * 0x85EBCA77u + 0x165667B1u) ^ site_seed);
-  return (h >> 16) >= thr16;  // P(drop) = thr16 / 65536
+  // one 32-bit hash per PAIR of columns (16 random bits each): callers that walk consecutive columns share it
+  const uint32_t h = kmb_hash32((row * 0x9E3779B1u) ^ ((col >> 1) * 0x85EBCA77u + 0x165667B1u) ^ site_seed);
+  const uint32_t bits = (col & 1u) ? (h >> 16) : (h & 0xffffu);
+  return bits >= thr16;  // P(drop) = thr16 / 65536
 }
