@@ -111,6 +111,7 @@ struct kmb_handle {
   hipStream_t side = nullptr; bool side_on = true;
   std::vector<hipEvent_t> ring; size_t ring_pos = 0;
   std::vector<hipEvent_t> layer_done;   // recorded on the side stream
+  hipEvent_t head_wgrad_done = nullptr; bool head_wgrad_pending = false;
   float* parts = nullptr;
   // pre-training head scratch
   bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr; float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
@@ -246,6 +247,19 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
   return 0;
 }
 
+int ensure_side(kmb_handle* h) {
+  if (!h->side_on || h->side != nullptr) return 0;
+  const char* env = getenv("KMB_NO_SIDE_STREAM");
+  if (env && env[0] == '1') { h->side_on = false; return 0; }
+  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  h->ring.resize(64);
+  for (auto& e : h->ring) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  h->layer_done.resize(h->cfg.encoder_layers + h->cfg.decoder_layers + 2);
+  for (auto& e : h->layer_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->head_wgrad_done, hipEventDisableTiming));
+  return 0;
+}
+
 // Weight gradients are off the critical path (nothing in backward reads them): enqueue them on the side stream
 // behind an event that marks "everything the main stream has produced so far".  Two different GEMMs in flight are
 // out of phase, so one's output-store burst overlaps the other's matrix work and partial waves get filled.
@@ -285,7 +299,7 @@ size_t parts_floats(const kmb_handle* h, int Mmax, int B) {
   size_t maxN = 3 * d;
   if ((size_t)h->Fe > maxN) maxN = h->Fe;
   if ((size_t)h->Fd > maxN) maxN = h->Fd;
-  size_t need = (size_t)256 * 3 * d;
+  size_t need = (size_t)512 * 3 * d;
   const size_t attn = (size_t)B * 3 * d;
   const size_t gsum = ((size_t)Mmax + 63) / 64 * maxN;
   const size_t csum = (size_t)64 * maxN;
@@ -678,6 +692,7 @@ void kmb_destroy(kmb_handle* h) {
   for (auto e : h->events) if (e) (void)hipEventDestroy(e);
   for (auto e : h->ring) if (e) (void)hipEventDestroy(e);
   for (auto e : h->layer_done) if (e) (void)hipEventDestroy(e);
+  if (h->head_wgrad_done) (void)hipEventDestroy(h->head_wgrad_done);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
@@ -829,7 +844,13 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       gd.out_bf16 = h->dhdec; gd.ld_out_bf16 = d;
       KCHK(run_gemm(gd, s));
       // dE[V,d] = dlogits^T H  (overwrites: the embedding scatter-adds of backward come on top)
-      KCHK(run_wgrad(h, lin_wgrad(h->dlogits_c, h->Vpad, hdec, d, h->gf(h->shared), Md, h->V, d, 0.f), s));
+      // (on the side stream: it overlaps the start of backward; the embedding scatter-adds wait for it)
+      KCHK(ensure_side(h));
+      KCHK(wgrad_side(h, lin_wgrad(h->dlogits_c, h->Vpad, hdec, d, h->gf(h->shared), Md, h->V, d, 0.f), s));
+      if (h->side_on && h->side) {
+        HIPCHK(hipEventRecord(h->head_wgrad_done, h->side));
+        h->head_wgrad_pending = true;
+      }
     }
     if (bt.labels) {
       HIPCHK(kmb_loss_finish_launch(h->loss_rows, Md, h->count, h->loss_dev, s));
@@ -894,18 +915,7 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   const int Le = h->cfg.encoder_layers, Ld = h->cfg.decoder_layers;
   for (auto& e : h->events)
     if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if (h->side_on && h->side == nullptr) {
-    const char* env = getenv("KMB_NO_SIDE_STREAM");
-    if (env && env[0] == '1') {
-      h->side_on = false;
-    } else {
-      HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-      h->ring.resize(64);
-      for (auto& e : h->ring) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      h->layer_done.resize(Le + Ld + 2);
-      for (auto& e : h->layer_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-  }
+  KCHK(ensure_side(h));
   const bool side = h->side_on && h->side != nullptr;
   int ev = 0;
   // layer c may only start once the side stream has finished layer c-2 (it still reads that layer's gradient buffers)
@@ -927,6 +937,9 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
     }
     return 0;
   };
+  if (h->head_wgrad_pending) {  // the tied matrix's head gradient is written on the side stream
+    if (loss_scale != 1.f) HIPCHK(hipStreamWaitEvent(s, h->head_wgrad_done, 0));
+  }
   if (loss_scale != 1.f) {
     HIPCHK(kmb_scale_bf16_launch(h->dhdec, (size_t)Md * d, loss_scale, s));
     HIPCHK(kmb_scale_f32_launch(h->gf(h->shared), (size_t)h->V * d, loss_scale, s));
@@ -979,6 +992,10 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   // ---- decoder embedding: xd[0] = drop(LN(zd0))  (main stream only)
   KCHK(ln_backward(h, dy, h->zd0, h->md0, h->rd0, h->dec_lne_g, h->dec_lne_b, h->dz, nullptr, h->drop_site(2, tr),
                    KmbDrop{0u, 0u, 1.f}, Md, s));
+  if (h->head_wgrad_pending) {
+    HIPCHK(hipStreamWaitEvent(s, h->head_wgrad_done, 0));
+    h->head_wgrad_pending = false;
+  }
   HIPCHK(kmb_embed_bwd_launch(h->dz, bt.decoder_input_ids, nullptr, scale, h->gf(h->shared), nullptr,
                               h->cfg.pad_token_id, Md, d, s));
   HIPCHK(kmb_pos_bwd_launch(h->dz, B, T, d, h->gf(h->dec_pos), h->cfg.extra_pos_embeddings, h->Prows, s));

@@ -240,7 +240,7 @@ hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* b
 }
 
 static int ln_bwd_rows_per_block(int M) {
-  int rpb = (M + 255) / 256;  // <= 256 blocks (one per CU): fewer partial rows to reduce
+  int rpb = (M + 511) / 512;  // <= 512 blocks (two per CU: enough loads in flight to stream at HBM rate)
   if (rpb < 4) rpb = 4;
   return rpb;
 }
