@@ -103,7 +103,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
   }
 }
 
-template <int NT>
+template <int NT, bool HOIST = true>
 __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
                                                      int col0, int slice);
 
@@ -124,10 +124,11 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
 }
 
 // cs: [NT/16][128] fp32 scratch (only touched when p.colsum != nullptr)
-template <int NT>
+template <int NT, bool HOIST>
 __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
                                                      int col0, int slice) {
   constexpr int RPP = NT / 16;  // rows per pass
+  constexpr int NH = HOIST ? 8 : 1;
   // ---- phase 2: row-major math + 16-byte stores ----
   const int c8 = (tid & 15) * 8;
   const int gcol = col0 + c8;
@@ -156,18 +157,35 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = (p.bias != nullptr && e < nvalid) ? p.bias[gcol + e] : 0.f;
 
-#pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
+  // ---- gather everything the 8 row-iterations need first (LDS reads and global residual / aux loads are then in
+  //      flight together instead of one dependent round trip per iteration) ----
+  const bool full8 = nvalid == 8;
+  f32x4 vlo[NH], vhi[NH];
+  u32x4 resv[NH], auxv[NH];
+  auto gather = [&](int it, int slot) {
     const int lrow = (tid >> 4) + RPP * it;
     const int grow = row0 + lrow;
-    if (grow >= p.M || nvalid == 0) break;
-    float v[8];
-    {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8 + 4);
-      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    const bool ok = grow < p.M && nvalid > 0;
+    vlo[slot] = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8);
+    vhi[slot] = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8 + 4);
+    resv[slot] = u32x4{0u, 0u, 0u, 0u};
+    auxv[slot] = u32x4{0u, 0u, 0u, 0u};
+    if (ok && full8) {
+      if (p.residual != nullptr) resv[slot] = *reinterpret_cast<const u32x4*>(p.residual + (size_t)grow * p.ld_res + gcol);
+      if (p.act == 2 || p.act == 4) auxv[slot] = *reinterpret_cast<const u32x4*>(p.aux + (size_t)grow * p.ld_aux + gcol);
     }
+  };
+  if (HOIST) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) gather(it, it);
+  }
+  auto process = [&](int it0, int it) -> bool {
+    const int lrow = (tid >> 4) + RPP * it0;
+    const int grow = row0 + lrow;
+    if (grow >= p.M || nvalid == 0) return false;
+    float v[8];
+    v[0] = vlo[it][0]; v[1] = vlo[it][1]; v[2] = vlo[it][2]; v[3] = vlo[it][3];
+    v[4] = vhi[it][0]; v[5] = vhi[it][1]; v[6] = vhi[it][2]; v[7] = vhi[it][3];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       v[e] += bias8[e];
@@ -175,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     }
     if (p.act == 1) {
       if (p.preact != nullptr) {
-        if (nvalid == 8) {
+        if (full8) {
           *reinterpret_cast<u32x4*>(p.preact + (size_t)grow * p.ld_preact + gcol) = pack8(v);
         } else {
           for (int e = 0; e < nvalid; ++e) p.preact[(size_t)grow * p.ld_preact + gcol + e] = f2bf(v[e]);
@@ -183,27 +201,23 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-    } else if (p.act == 2) {
+    } else if (p.act == 2 || p.act == 4) {
       float u[8];
-      if (nvalid == 8) {
-        unpack8(*reinterpret_cast<const u32x4*>(p.aux + (size_t)grow * p.ld_aux + gcol), u);
+      if (full8) {
+        unpack8(auxv[it], u);
       } else {
         for (int e = 0; e < 8; ++e) u[e] = e < nvalid ? bf2f(p.aux[(size_t)grow * p.ld_aux + gcol + e]) : 0.f;
       }
+      if (p.act == 2) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
+      } else {  // tanh'(.) = 1 - y^2, aux = y
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= (1.f - u[e] * u[e]);
+      }
     } else if (p.act == 3) {  // BartClassificationHead: tanh
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-    } else if (p.act == 4) {  // multiply by tanh'(.) = 1 - y^2, aux = y (the stored tanh output)
-      float y[8];
-      if (nvalid == 8) {
-        unpack8(*reinterpret_cast<const u32x4*>(p.aux + (size_t)grow * p.ld_aux + gcol), y);
-      } else {
-        for (int e = 0; e < 8; ++e) y[e] = e < nvalid ? bf2f(p.aux[(size_t)grow * p.ld_aux + gcol + e]) : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= (1.f - y[e] * y[e]);
     }
     if (p.drop_thr16 != 0u) {
 #pragma unroll
@@ -212,8 +226,8 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     }
     if (p.residual != nullptr) {
       float rr[8];
-      if (nvalid == 8) {
-        unpack8(*reinterpret_cast<const u32x4*>(p.residual + (size_t)grow * p.ld_res + gcol), rr);
+      if (full8) {
+        unpack8(resv[it], rr);
       } else {
         for (int e = 0; e < 8; ++e) rr[e] = e < nvalid ? bf2f(p.residual[(size_t)grow * p.ld_res + gcol + e]) : 0.f;
       }
@@ -227,10 +241,10 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
 #pragma unroll
       for (int e = 0; e < 8; ++e) keep += v[e];
       if (keep == 1.2345e30f) p.out_bf16[0] = 0;
-      continue;
+      return true;
     }
     if (p.out_bf16 != nullptr) {
-      if (nvalid == 8) {
+      if (full8) {
         *reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol) = pack8(v);
       } else {
         for (int e = 0; e < nvalid; ++e) p.out_bf16[(size_t)grow * p.ld_out_bf16 + gcol + e] = f2bf(v[e]);
@@ -238,7 +252,7 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     }
     if (p.out_f32 != nullptr) {
       float* o = p.out_f32 + (size_t)grow * p.ld_out_f32 + gcol;
-      const bool vec = (nvalid == 8) && ((p.ld_out_f32 & 3) == 0);
+      const bool vec = full8 && ((p.ld_out_f32 & 3) == 0);
       if (p.beta != 0.f) {
         for (int e = 0; e < nvalid; ++e) v[e] += p.beta * o[e];
       }
@@ -248,6 +262,18 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
       } else {
         for (int e = 0; e < nvalid; ++e) o[e] = v[e];
       }
+    }
+    return true;
+  };
+  if (HOIST) {
+#pragma unroll
+    for (int it0 = 0; it0 < 8; ++it0)
+      if (!process(it0, it0)) break;
+  } else {
+#pragma unroll 2
+    for (int it0 = 0; it0 < 8; ++it0) {
+      gather(it0, 0);
+      if (!process(it0, 0)) break;
     }
   }
   if (p.colsum != nullptr) {
@@ -554,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
             ef[(wm * 128 + i * 16 + g * 4 + q) * EPI_LD + (wn & 1) * 64 + j * 16 + r] = acc[i][j][q];
     }
     __syncthreads();
-    gemm_epilogue_phase2<512>(p, ef, reinterpret_cast<float*>(smem + 2 * EPI_BYTES), tid, row0, col0 + h * 128, slice);
+    gemm_epilogue_phase2<512, false>(p, ef, reinterpret_cast<float*>(smem + 2 * EPI_BYTES), tid, row0, col0 + h * 128, slice);
     __syncthreads();
   }
 }
