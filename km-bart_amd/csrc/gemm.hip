@@ -103,7 +103,9 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
   }
 }
 
-template <int NT, bool HOIST = true>
+// NIT row-iterations over a staging image of row stride LD floats; SWZ: 16-column groups XOR-swapped by
+// ((row >> 2) & 1) instead of padded rows; TILE_ROWS: rows of C covered by one call (column-sum contract)
+template <int NT, bool HOIST = true, int NIT = 8, int LD = EPI_LD, bool SWZ = false, int TILE_ROWS = (NT == 512 ? 256 : 128)>
 __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
                                                      int col0, int slice);
 
@@ -124,11 +126,12 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
 }
 
 // cs: [NT/16][128] fp32 scratch (only touched when p.colsum != nullptr)
-template <int NT, bool HOIST>
+template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS>
 __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
                                                      int col0, int slice) {
   constexpr int RPP = NT / 16;  // rows per pass
-  constexpr int NH = HOIST ? 8 : 1;
+  constexpr int NH = HOIST ? NIT : 1;
+  auto eoff = [&](int lrow, int c) { return lrow * LD + (SWZ ? (c ^ (((lrow >> 2) & 1) << 4)) : c); };
   // ---- phase 2: row-major math + 16-byte stores ----
   const int c8 = (tid & 15) * 8;
   const int gcol = col0 + c8;
@@ -139,16 +142,16 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   if (p.split_k > 1) {  // raw partial sums of this K slice -> slab[slice][M][N]
     float* slab = p.slab + (size_t)slice * p.M * p.N;
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int lrow = (tid >> 4) + RPP * it;
       const int grow = row0 + lrow;
       if (grow >= p.M) break;
       float* o = slab + (size_t)grow * p.N + gcol;
       if (nvalid == 8 && (p.N & 3) == 0) {
-        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8);
-        *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8 + 4);
+        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8));
+        *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8) + 4);
       } else {
-        for (int e = 0; e < nvalid; ++e) o[e] = ef[lrow * EPI_LD + c8 + e];
+        for (int e = 0; e < nvalid; ++e) o[e] = ef[eoff(lrow, c8) + e];
       }
     }
     return;
@@ -166,8 +169,8 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     const int lrow = (tid >> 4) + RPP * it;
     const int grow = row0 + lrow;
     const bool ok = grow < p.M && nvalid > 0;
-    vlo[slot] = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8);
-    vhi[slot] = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD + c8 + 4);
+    vlo[slot] = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8));
+    vhi[slot] = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8) + 4);
     resv[slot] = u32x4{0u, 0u, 0u, 0u};
     auxv[slot] = u32x4{0u, 0u, 0u, 0u};
     if (ok && full8) {
@@ -177,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
   };
   if (HOIST) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) gather(it, it);
+    for (int it = 0; it < NIT; ++it) gather(it, it);
   }
   auto process = [&](int it0, int it) -> bool {
     const int lrow = (tid >> 4) + RPP * it0;
@@ -267,11 +270,11 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
   };
   if (HOIST) {
 #pragma unroll
-    for (int it0 = 0; it0 < 8; ++it0)
+    for (int it0 = 0; it0 < NIT; ++it0)
       if (!process(it0, it0)) break;
   } else {
 #pragma unroll 2
-    for (int it0 = 0; it0 < 8; ++it0) {
+    for (int it0 = 0; it0 < NIT; ++it0) {
       gather(it0, 0);
       if (!process(it0, 0)) break;
     }
@@ -288,7 +291,6 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
       // contract: one partial row per 64 rows of C; this tile fills its first row and zeroes the rest
       const int prow = row0 >> 6;
       p.colsum[(size_t)prow * p.N + col0 + tid] = t;
-      constexpr int TILE_ROWS = NT == 512 ? 256 : 128;
       for (int k = 1; k < TILE_ROWS / 64; ++k)
         if (row0 + 64 * k < p.M) p.colsum[(size_t)(prow + k) * p.N + col0 + tid] = 0.f;
     }
@@ -586,173 +588,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// v5: v2's main loop with the MFMA operand roles swapped (the instruction computes the TRANSPOSED 16x16 block:
-// accumulator register q of lane (r, g) is C[m = r][n = 4g + q]), so every lane owns 4 CONSECUTIVE columns of
-// one output row.  The epilogue then runs straight from registers with 8-byte (bf16) / 16-byte (fp32) accesses:
-// no fp32 LDS round trip, no barriers, and a workgroup that has finished its K loop streams its tile out while
-// the other workgroup of the CU keeps the matrix cores busy.
-template <int MI>
-__device__ __forceinline__ void epilogue_regs(const KmbGemm& p, f32x4 (&acc)[MI][4], int row_base, int col_base, int r,
-                                              int g, int slice, int colsum_row) {
-  // lane owns rows row_base + i*16 + r (i < MI) and columns col_base + j*16 + g*4 + {0..3} (j < 4)
-  float csum[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) csum[j][q] = 0.f;
-  float* slab = p.split_k > 1 ? p.slab + (size_t)slice * p.M * p.N : nullptr;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int gcol = col_base + j * 16 + g * 4;
-    if (gcol >= p.N) continue;
-    const int nvalid = (p.N - gcol) < 4 ? (p.N - gcol) : 4;
-    const bool vec4 = nvalid == 4;
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && slab == nullptr)
-      for (int e = 0; e < nvalid; ++e) b4[e] = p.bias[gcol + e];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int grow = row_base + i * 16 + r;
-      if (grow >= p.M) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (slab != nullptr) {
-        float* o = slab + (size_t)grow * p.N + gcol;
-        if (vec4 && (p.N & 3) == 0) *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-        else for (int e = 0; e < nvalid; ++e) o[e] = v[e];
-        continue;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] += b4[e];
-        if (gcol + e < p.col_scale_n) v[e] *= p.col_scale;
-      }
-      if (p.act == 1) {
-        if (p.preact != nullptr) {
-          bf16_t* o = p.preact + (size_t)grow * p.ld_preact + gcol;
-          if (vec4) *reinterpret_cast<uint2*>(o) = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          else for (int e = 0; e < nvalid; ++e) o[e] = f2bf(v[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-      } else if (p.act == 2) {
-        const bf16_t* a = p.aux + (size_t)grow * p.ld_aux + gcol;
-        float u[4] = {0.f, 0.f, 0.f, 0.f};
-        if (vec4) {
-          const uint2 t = *reinterpret_cast<const uint2*>(a);
-          u[0] = lo_bf(t.x); u[1] = hi_bf(t.x); u[2] = lo_bf(t.y); u[3] = hi_bf(t.y);
-        } else {
-          for (int e = 0; e < nvalid; ++e) u[e] = bf2f(a[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(u[e]);
-      } else if (p.act == 3) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-      } else if (p.act == 4) {
-        const bf16_t* a = p.aux + (size_t)grow * p.ld_aux + gcol;
-        for (int e = 0; e < nvalid; ++e) { const float y = bf2f(a[e]); v[e] *= (1.f - y * y); }
-      }
-      if (p.drop_thr16 != 0u) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = drop_keep(p.drop_seed, (uint32_t)grow, (uint32_t)(gcol + e), p.drop_thr16) ? v[e] * p.drop_scale : 0.f;
-      }
-      if (p.residual != nullptr) {
-        const bf16_t* a = p.residual + (size_t)grow * p.ld_res + gcol;
-        if (vec4) {
-          const uint2 t = *reinterpret_cast<const uint2*>(a);
-          v[0] += lo_bf(t.x); v[1] += hi_bf(t.x); v[2] += lo_bf(t.y); v[3] += hi_bf(t.y);
-        } else {
-          for (int e = 0; e < nvalid; ++e) v[e] += bf2f(a[e]);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) csum[j][e] += (e < nvalid) ? v[e] : 0.f;
-      if (p.out_bf16 != nullptr) {
-        bf16_t* o = p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol;
-        if (vec4) *reinterpret_cast<uint2*>(o) = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        else for (int e = 0; e < nvalid; ++e) o[e] = f2bf(v[e]);
-      }
-      if (p.out_f32 != nullptr) {
-        float* o = p.out_f32 + (size_t)grow * p.ld_out_f32 + gcol;
-        if (p.beta != 0.f) for (int e = 0; e < nvalid; ++e) v[e] += p.beta * o[e];
-        if (vec4 && (p.ld_out_f32 & 3) == 0) *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-        else for (int e = 0; e < nvalid; ++e) o[e] = v[e];
-      }
-    }
-  }
-  if (p.colsum != nullptr && slab == nullptr) {
-    // column sums over this wave's rows: reduce the 16 row-lanes (r) by butterflies; lanes r == 0 hold the sums.
-    // One partial row per 64-row wave block: the host reduces ceil(M/64) rows.
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = csum[j][e];
-        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-        const int gcol = col_base + j * 16 + g * 4 + e;
-        if (r == 0 && gcol < p.N) p.colsum[(size_t)colsum_row * p.N + gcol] = t;
-      }
-  }
-}
-
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v5(const KmbGemm p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 15, g = lane >> 4;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int tile = bid / nsl, slice = bid % nsl;
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int row0 = tm * BM, col0 = tn * BN;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nt_all = p.K / BK;
-  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
-  const int nt = t_end - t_begin;
-  glds_tile<A_KC>(smem, p.A, p.lda, row0, p.M, t_begin * BK, wave, lane);
-  glds_tile<B_KC>(smem + BM * BK * 2, p.B, p.ldb, col0, p.N, t_begin * BK, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * STAGE_BYTES;
-    char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-    if (t + 1 < nt) {
-      glds_tile<A_KC>(nxt, p.A, p.lda, row0, p.M, (t_begin + t + 1) * BK, wave, lane);
-      glds_tile<B_KC>(nxt + BM * BK * 2, p.B, p.ldb, col0, p.N, (t_begin + t + 1) * BK, wave, lane);
-    }
-    const char* la = cur;
-    const char* lb = cur + BM * BK * 2;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(la, wm * 4 + i, kk, r, g);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(lb, wn * 4 + j, kk, r, g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)  // operands swapped: the block comes out transposed (see header comment)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    if (t + 1 < nt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  }
-  epilogue_regs<4>(p, acc, row0 + wm * 64, col0 + wn * 64, r, g, slice, (row0 >> 6) + wm);
-}
+// Variants that were built, verified bit-identical and then REMOVED because they measured slower on every training
+// shape (MI355X, b=256): a 256x128 three-stage ring with counted vmcnt (one workgroup per CU: -10..25 %), a
+// transposed-block MFMA with a register epilogue and 8-byte stores (-20 %: the stores are issue-bound), and several
+// tiles per workgroup with the next tile's first K step prefetched under the epilogue (-5..30 %: fewer independent
+// workgroups to overlap).  What did pay: LDS-DMA staging, hoisted epilogue loads, hardware bf16 conversion, split-K
+// for the weight gradients, per-shape choice between the 128x128 and 256x256 tiles and the XCD tile order.
 
 }  // namespace
 
@@ -792,11 +633,7 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   } else {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles * nsl), block(256);
-    if (variant == 5) {
-      if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v5<true, true>), grid, block, 2 * STAGE_BYTES, stream, p);
-      else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v5<true, false>), grid, block, 2 * STAGE_BYTES, stream, p);
-      else hipLaunchKernelGGL((gemm_kernel_v5<false, false>), grid, block, 2 * STAGE_BYTES, stream, p);
-    } else if (variant == 2) {
+    if (variant == 2) {
       if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, true>), grid, block, LDS_BYTES, stream, p);
       else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, false>), grid, block, LDS_BYTES, stream, p);
       else hipLaunchKernelGGL((gemm_kernel_v2<false, false>), grid, block, LDS_BYTES, stream, p);
@@ -845,9 +682,6 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
@@ -858,6 +692,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   if (forced) {
     int v = forced;
     if (v == 3 || (v == 4 && !(big && p.N > 128))) v = 2;
+    if (v != 1 && v != 2 && v != 4) v = 2;
     return launch_variant(v, p, stream);
   }
   if (!big || p.N <= 128) return launch_variant(2, p, stream);
