@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) side measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,6 +192,39 @@ def main():
     }
     if parity is not None:
         out["ce_loss_rel_delta_vs_oracle_b2"] = float("%.3e" % parity[0])
+
+    if rank == 0 and args.gpus == 1 and not args.no_pcie:
+        # side measurement, never `value`: batches start in pinned HOST memory (fp32 region features, 295 KB/sample)
+        # and reach the GPU through the packed-feature prefetcher (copy of batch i+1 overlaps step i)
+        from kmbart.data import DevicePrefetcher, PackedFeatures
+        host = []
+        for i in range(3):
+            hb = make_batch(args.batch, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=99 + i)
+            hb["image_features"] = PackedFeatures.from_list(hb["image_features"], 2052, pin=True)
+            host.append(hb)
+        n_host = 12
+
+        def host_loader():
+            for i in range(n_host):
+                yield host[i % len(host)]
+
+        class _L:
+            def __iter__(self):
+                return host_loader()
+
+            def __len__(self):
+                return n_host
+
+        torch.cuda.synchronize()
+        th = None
+        for i, db in enumerate(DevicePrefetcher(_L(), dev)):
+            if i == 2:
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+            ddp.train_step_fwd_bwd(db)
+            opt.step()
+        torch.cuda.synchronize()
+        out["pcie_inclusive_tokens_per_sec"] = round(args.batch * (S_ENC + T_DEC) * (n_host - 2) / (time.perf_counter() - th), 1)
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the bf16 MFMA GEMM: time every launch of a few steps with HIP events on its stream

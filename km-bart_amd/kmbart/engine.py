@@ -20,6 +20,9 @@ def _stream():
 def pack_features(image_features, feat_dim, device):
     """list[B] of [R_i, F] fp32 (R_i may be 0 -> torch.empty(0), collation.py:73-76)
     -> (packed [Ntot, F] fp32 on device, offsets int32 [B+1] on device, Ntot)."""
+    if hasattr(image_features, "packed") and hasattr(image_features, "offsets"):   # kmbart.data.PackedFeatures
+        return (image_features.packed.to(device=device, dtype=torch.float32).contiguous(),
+                image_features.offsets.to(device=device, dtype=torch.int32).contiguous(), image_features.n_total)
     lens = [int(x.shape[0]) if x.dim() == 2 else 0 for x in image_features]
     offs = [0]
     for n in lens:

@@ -10,6 +10,11 @@ def _on(batch, key, device):
     return batch[key].to(device) if key in batch and batch[key] is not None else None
 
 
+def _features(feats, device):
+    """list of per-sample tensors (reference collator) or a kmbart.data.PackedFeatures"""
+    return feats.to(device) if hasattr(feats, "packed") else [f.to(device) for f in feats]
+
+
 def fine_tune(epoch, model, train_loader, optimizer, device, args, logger=None, callback=None, log_interval=1,
               tb_writer=None, tb_interval=1, scaler=None):
     n_steps = len(train_loader)
@@ -23,7 +28,7 @@ def fine_tune(epoch, model, train_loader, optimizer, device, args, logger=None, 
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=use_amp and torch.cuda.is_available()):
             outputs = model.forward(
                 input_ids=batch["input_ids"].to(device),
-                image_features=[f.to(device) for f in batch["image_features"]],
+                image_features=_features(batch["image_features"], device),
                 attention_mask=batch["attention_mask"].to(device),
                 decoder_input_ids=_on(batch, "decoder_input_ids", device),
                 decoder_attention_mask=_on(batch, "decoder_attention_mask", device),
@@ -74,7 +79,7 @@ def pretrain(epoch, model, train_loader, optimizer, device, args, logger=None, c
 
         outputs = model.forward(
             input_ids=batch["input_ids"].to(device),
-            image_features=[f.to(device) for f in batch["image_features"]],
+            image_features=_features(batch["image_features"], device),
             attention_mask=batch["attention_mask"].to(device),
             decoder_input_ids=opt("decoder_input_ids"),
             decoder_attention_mask=opt("decoder_attention_mask"),

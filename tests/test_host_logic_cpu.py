@@ -138,3 +138,13 @@ def test_pretrain_loop_uses_the_loss_dict():
     pretrain(0, M(), [b], _FakeOpt(log), "cpu", types.SimpleNamespace(amp=False, epochs=2), logger=logger)
     assert log == ["train", "forward", "item", "zero_grad", "backward", "step"]
     assert lines[0].startswith("Epoch [1/2], Step [1/1], Loss: 2.0000, ETA: ")
+
+
+def test_packed_features_roundtrip():
+    from kmbart.data import PackedFeatures
+    from kmbart.engine import pack_features
+    feats = [torch.ones(3, 8), torch.empty(0), torch.full((2, 8), 2.0)]
+    pf = PackedFeatures.from_list(feats, 8)
+    assert len(pf) == 3 and pf.n_total == 5 and pf.offsets.tolist() == [0, 3, 3, 5]
+    packed, offs, n = pack_features(pf, 8, "cpu")
+    assert n == 5 and torch.equal(packed, pf.packed) and offs.dtype == torch.int32
