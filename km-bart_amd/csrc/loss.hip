@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
   }
 }
 
-// Per row: logp = log_softmax(row) (or the forced-token distribution), then the k best of
-// logp + add[row] in (value desc, index asc) order by k block-wide arg-max sweeps.
+// Per row: logp = log_softmax(row) (or the forced-token distribution), then the k best of logp + add[row] in
+// (value desc, index asc) order.  Thread t owns elements t, t+256, ...; it keeps its own best in registers, a round
+// is one block-wide arg-max over those 256 candidates, and only the winner's wave rescans the winner's ~V/256
+// elements (64 lanes wide, from L2) for its next candidate -- the row is swept 3 times in total instead of k+2.
 __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, int ldv, int V,
                                                               const float* __restrict__ add, int force_token, int k,
                                                               float* __restrict__ out_val,
@@ -119,46 +121,63 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
   __shared__ float sh[8];
   __shared__ float shv[4];
   __shared__ int shi[4];
-  const int r = blockIdx.x, tid = threadIdx.x;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* row = logits + (size_t)r * ldv;
   const float a = add != nullptr ? add[r] : 0.f;
-  float lse;
   if (force_token >= 0) {
-    lse = row[force_token];  // all other logits are -inf: log_softmax gives 0 at the forced token
-  } else {
-    float m, s;
-    row_lse(row, V, sh, m, s);
-    lse = m + __logf(s);
-  }
-  float last_v = INFINITY;
-  int last_i = -1;
-  for (int j = 0; j < k; ++j) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-      float x = row[i];
-      if (force_token >= 0 && i != force_token) x = -INFINITY;
-      // candidates strictly after (last_v, last_i) in (value desc, index asc) order
-      const bool after = (x < last_v) || (x == last_v && i > last_i);
-      if (after && (x > bv || (x == bv && i < bi))) { bv = x; bi = i; }
+    // every other logit is -inf: log_softmax is 0 at the forced token, -inf elsewhere (ties in index order)
+    for (int j = tid; j < k; j += 256) {
+      out_val[(size_t)r * k + j] = j == 0 ? a : -INFINITY;
+      out_idx[(size_t)r * k + j] = j == 0 ? force_token : (j - 1 < force_token ? j - 1 : j);
     }
+    return;
+  }
+  float m, s;
+  row_lse(row, V, sh, m, s);
+  const float lse = m + __logf(s);
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < V; i += 256) {
+    const float x = row[i];
+    if (x > bv || bi == 0x7fffffff) { bv = x; bi = i; }
+  }
+  for (int j = 0; j < k; ++j) {
+    float wv = bv;
+    int wi = bi;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const float v2 = __shfl_xor(bv, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+      const float v2 = __shfl_xor(wv, o, 64);
+      const int i2 = __shfl_xor(wi, o, 64);
+      if (v2 > wv || (v2 == wv && i2 < wi)) { wv = v2; wi = i2; }
     }
-    if ((tid & 63) == 0) { shv[tid >> 6] = bv; shi[tid >> 6] = bi; }
+    if (lane == 0) { shv[tid >> 6] = wv; shi[tid >> 6] = wi; }
     __syncthreads();
-    bv = shv[0]; bi = shi[0];
+    wv = shv[0]; wi = shi[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w)
-      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+      if (shv[w] > wv || (shv[w] == wv && shi[w] < wi)) { wv = shv[w]; wi = shi[w]; }
     __syncthreads();
-    last_v = bv; last_i = bi;
     if (tid == 0) {
-      out_val[(size_t)r * k + j] = (bv - lse) + a;
-      out_idx[(size_t)r * k + j] = bi;
+      out_val[(size_t)r * k + j] = (wv - lse) + a;
+      out_idx[(size_t)r * k + j] = wi;
+    }
+    if (wi == 0x7fffffff) continue;  // fewer than k elements in the row
+    const int owner = wi & 255;
+    if ((tid >> 6) == (owner >> 6)) {  // wave-uniform: the owner's wave finds the owner's next candidate
+      float nv = -INFINITY;
+      int ni = 0x7fffffff;
+      for (int i = owner + 256 * lane; i < V; i += 256 * 64) {
+        const float x = row[i];
+        const bool after = (x < wv) || (x == wv && i > wi);
+        if (after && (x > nv || ni == 0x7fffffff || (x == nv && i < ni))) { nv = x; ni = i; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(nv, o, 64);
+        const int i2 = __shfl_xor(ni, o, 64);
+        if (i2 != 0x7fffffff && (ni == 0x7fffffff || v2 > nv || (v2 == nv && i2 < ni))) { nv = v2; ni = i2; }
+      }
+      if (tid == owner) { bv = nv; bi = ni; }
     }
   }
 }

@@ -429,14 +429,17 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                         break
             return ids.to(dev)
 
+        # Host bookkeeping on plain Python lists: indexing small CPU tensors element by element (as the reference does)
+        # costs ~10 us per access and made a beam step 6x longer than its GPU work.
         hyps = [BeamHypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
-        beam_scores = torch.zeros((B, num_beams), dtype=torch.float32)
-        beam_scores[:, 1:] = -1e9
-        beam_scores = beam_scores.view(-1)
+        beam_scores = [0.0 if (i % num_beams) == 0 else -1e9 for i in range(R)]
+        seqs = [[int(decoder_start_token_id)] for _ in range(R)]   # decoder inputs of every beam row
         done = [False] * B
         k = 2 * num_beams
+        beam_off = (torch.arange(num_beams, device=dev) * V).view(1, -1, 1)
+        last_tokens = torch.full((R,), decoder_start_token_id, dtype=torch.long, device=dev)
         while cur_len < max_length:
-            logits = eng.gen_step(ids[:, -1].to(dev), cur_len - 1)
+            logits = eng.gen_step(last_tokens, cur_len - 1)
             force = -1
             if cur_len == 1:
                 force = cfg.bos_token_id          # adjust_logits_during_generation, mixins.py:400-405
@@ -444,65 +447,71 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 force = eos_token_id
             if eos_token_id is not None and cur_len < min_length:
                 logits[:, eos_token_id] = -float("inf")
-            val, idx = eng.logsoftmax_topk(logits, k, add=beam_scores.to(dev), force_token=force)
-            val = val.view(B, num_beams * k).cpu()
-            idx = (idx.view(B, num_beams, k).long() + (torch.arange(num_beams, device=dev) * V).view(1, -1, 1)) \
-                .view(B, num_beams * k).cpu()
+            add = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
+            val, idx = eng.logsoftmax_topk(logits, k, add=add, force_token=force)
             # top 2*num_beams of the union == top 2*num_beams over num_beams * V (each row contributed its best 2*num_beams)
+            val = val.view(B, num_beams * k)
+            idx = (idx.view(B, num_beams, k).long() + beam_off).view(B, num_beams * k)
             order = torch.sort(val, dim=1, descending=True, stable=True)[1][:, :k]
-            next_scores = torch.gather(val, 1, order)
-            next_tokens = torch.gather(idx, 1, order)
-            next_batch_beam = []
+            packed = torch.stack([torch.gather(val, 1, order).double(), torch.gather(idx, 1, order).double()], 0).cpu()
+            next_scores = packed[0].tolist()
+            next_tokens = packed[1].long().tolist()
+            new_scores, new_tokens, new_idx = [], [], []
             for b in range(B):
                 if done[b]:
-                    next_batch_beam.extend([(0, pad_token_id, 0)] * num_beams)
+                    new_scores += [0.0] * num_beams
+                    new_tokens += [pad_token_id] * num_beams
+                    new_idx += [0] * num_beams
                     continue
-                sent = []
-                for rank, (tid, tscore) in enumerate(zip(next_tokens[b].tolist(), next_scores[b].tolist())):
+                n_sent = 0
+                for rank in range(k):
+                    tid, tscore = next_tokens[b][rank], next_scores[b][rank]
                     beam_id, token_id = tid // V, tid % V
                     eff = b * num_beams + beam_id
                     if eos_token_id is not None and token_id == eos_token_id:
                         if rank >= num_beams:
                             continue
-                        hyps[b].add(ids[eff].clone(), tscore)
+                        hyps[b].add(list(seqs[eff]), tscore)
                     else:
-                        sent.append((tscore, token_id, eff))
-                    if len(sent) == num_beams:
+                        new_scores.append(tscore)
+                        new_tokens.append(token_id)
+                        new_idx.append(eff)
+                        n_sent += 1
+                    if n_sent == num_beams:
                         break
-                done[b] = done[b] or hyps[b].is_done(float(next_scores[b].max()), cur_len)
-                assert len(sent) == num_beams, "Beam should always be full"
-                next_batch_beam.extend(sent)
+                done[b] = done[b] or hyps[b].is_done(max(next_scores[b]), cur_len)
+                assert n_sent == num_beams, "Beam should always be full"
             if all(done):
                 break
-            beam_scores = torch.tensor([x[0] for x in next_batch_beam], dtype=torch.float32)
-            beam_tokens = torch.tensor([x[1] for x in next_batch_beam], dtype=torch.long)
-            beam_idx = torch.tensor([x[2] for x in next_batch_beam], dtype=torch.long)
-            ids = torch.cat([ids[beam_idx, :], beam_tokens.unsqueeze(1)], dim=-1)
-            eng.gen_reorder(beam_idx.to(dev), cur_len - 1)   # _reorder_cache, mixins.py:419-434
+            beam_scores = new_scores
+            seqs = [seqs[j] + [t] for j, t in zip(new_idx, new_tokens)]
+            tok_idx = torch.tensor([new_tokens, new_idx], dtype=torch.long).to(dev)
+            last_tokens = tok_idx[0].contiguous()
+            eng.gen_reorder(tok_idx[1], cur_len - 1)   # _reorder_cache, mixins.py:419-434
             cur_len += 1
         for b in range(B):
             if done[b]:
                 continue
             for beam_id in range(num_beams):
                 eff = b * num_beams + beam_id
-                hyps[b].add(ids[eff], float(beam_scores[eff]))
+                hyps[b].add(list(seqs[eff]), beam_scores[eff])
         best, best_scores, lens = [], [], []
         for h in hyps:
             sh = sorted(h.beams, key=lambda x: x[0])
             for _ in range(num_return_sequences):
-                s, hyp = sh.pop()
+                sc, hyp = sh.pop()
                 best.append(hyp)
-                best_scores.append(s)
+                best_scores.append(sc)
                 lens.append(len(hyp))
         if min(lens) != max(lens):
             L = min(max(lens) + 1, max_length)
             out = torch.full((len(best), L), pad_token_id, dtype=torch.long)
             for i, hyp in enumerate(best):
-                out[i, : lens[i]] = hyp
+                out[i, : lens[i]] = torch.tensor(hyp, dtype=torch.long)
                 if lens[i] < max_length:
                     out[i, lens[i]] = eos_token_id
         else:
-            out = torch.stack(best).long()
+            out = torch.tensor(best, dtype=torch.long)
         out = out.to(dev)
         return (out, torch.tensor(best_scores)) if return_scores else out
 

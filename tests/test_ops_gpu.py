@@ -399,6 +399,18 @@ def test_logsoftmax_topk():
     check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), 2, k, ptr(val), ptr(idx), stream()))
     assert torch.all(idx[:, 0] == 2) and torch.allclose(val[:, 0], add, atol=1e-6)
     assert torch.all(torch.isinf(val[:, 1:]))
+    assert idx[0, 1:].tolist() == [0, 1] + list(range(3, k))
+    # winners that share one thread's stripe (i % 256 equal), exact ties (lowest index first), a masked column
+    logits[:, :V] = rnd(rows, V, seed=63)
+    logits[:, 5:5 + 256 * 12:256] = 9.0 + torch.arange(12, device=DEV).float()
+    logits[:, 7000] = logits[:, 5 + 256 * 11]
+    logits[:, 300] = logits[:, 5 + 256 * 11]
+    logits[:, 5 + 256 * 10] = -float("inf")
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, k, ptr(val), ptr(idx), stream()))
+    lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
+    order = torch.sort(lp, dim=1, descending=True, stable=True)[1][:, :k]
+    assert torch.equal(idx.long(), order)
+    assert torch.allclose(val, torch.gather(lp, 1, order), atol=1e-4)
 
 
 # ---------------------------------------------------------------------------------------- AdamW
