@@ -292,14 +292,14 @@ int ln_backward(kmb_handle* h, const bf16_t* dy, const bf16_t* z, const float* m
   return 0;
 }
 
-// scratch for partial reductions: LayerNorm [<=256][3][d], attention bias partials [B][3d],
+// scratch for partial reductions: LayerNorm [<=1024][3][d], attention bias partials [B][3d],
 // GEMM column sums [ceil(M/128)][F], colsum kernel [<=64][maxN]
 size_t parts_floats(const kmb_handle* h, int Mmax, int B) {
   const size_t d = h->d;
   size_t maxN = 3 * d;
   if ((size_t)h->Fe > maxN) maxN = h->Fe;
   if ((size_t)h->Fd > maxN) maxN = h->Fd;
-  size_t need = (size_t)512 * 3 * d;
+  size_t need = (size_t)kmb_ln_bwd_parts(Mmax) * 3 * d;
   const size_t attn = (size_t)B * 3 * d;
   const size_t gsum = ((size_t)Mmax + 63) / 64 * maxN;
   const size_t csum = (size_t)64 * maxN;

@@ -95,6 +95,89 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   }
 }
 
+// Register-resident form for rows of up to NV * 4096 columns: 1024 threads hold the whole fp32 row (NV float4 each),
+// so the logits are read from memory once (max, sum-exp and the gradient all come from registers).
+template <int NV>
+__global__ __launch_bounds__(1024) void ce_kernel_reg(const float* __restrict__ logits, int ldv, int V,
+                                                      const int64_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ count, float grad_scale,
+                                                      float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits) {
+  __shared__ float sh[32];
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* row = logits + (size_t)r * ldv;
+  const int64_t label = labels[r];
+  const bool valid = (label != -100);  // block-uniform
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+  if (!valid) {
+    if (tid == 0) loss_rows[r] = 0.f;
+    if (dlogits != nullptr) {
+      const u32x2 zero = {0u, 0u};
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int i = (tid + 1024 * j) * 4;
+        if (i < ldv) *reinterpret_cast<u32x2*>(dlogits + (size_t)r * ldv + i) = zero;
+      }
+    }
+    return;
+  }
+  f32x4 x[NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = (tid + 1024 * j) * 4;
+    if (i < ldv) {
+      x[j] = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (i + e >= V) x[j][e] = -INFINITY;
+        m = fmaxf(m, x[j][e]);
+      }
+    } else {
+      x[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) sh[wave] = m;
+  __syncthreads();
+  m = sh[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, sh[w]);
+  float s = 0.f;
+  if (m != -INFINITY) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += __expf(x[j][e] - m);
+  }
+  s = wave_sum(s);
+  if (lane == 0) sh[16 + wave] = s;
+  __syncthreads();
+  s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += sh[16 + w];
+  const float lse = m + __logf(s);
+  if (tid == 0) loss_rows[r] = lse - row[label];
+  if (dlogits == nullptr) return;
+  const int n = count[0];
+  const float gs = n > 0 ? grad_scale / (float)n : 0.f;
+  bf16_t* drow = dlogits + (size_t)r * ldv;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = (tid + 1024 * j) * 4;
+    if (i < ldv) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p = __expf(x[j][e] - lse);  // exp(-inf) = 0 in the pad columns
+        if (i + e == (int)label) p -= 1.f;
+        o[e] = p * gs;
+      }
+      const u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+      *reinterpret_cast<u32x2*>(drow + i) = pk;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ loss_rows, int rows,
                                                           const int32_t* __restrict__ count, float* __restrict__ loss) {
   __shared__ float sh[4];
@@ -193,7 +276,10 @@ hipError_t kmb_ce_launch(const float* logits, int ldv, int V, const int64_t* lab
                          float grad_scale, float* loss_rows, bf16_t* dlogits, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
   if ((ldv & 7) || ((uintptr_t)logits & 15)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, labels, count, grad_scale, loss_rows, dlogits);
+  if (ldv <= 13 * 4096)
+    hipLaunchKernelGGL((ce_kernel_reg<13>), dim3(rows), dim3(1024), 0, stream, logits, ldv, V, labels, count, grad_scale, loss_rows, dlogits);
+  else
+    hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, labels, count, grad_scale, loss_rows, dlogits);
   return hipGetLastError();
 }
 

@@ -53,7 +53,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 }
 
 // Each block owns rows [blockIdx.x * rows_per_block, ...); its 4 waves take them round-robin.
-template <int NCH>
+// One wave per row, lane l owns the 4-column groups l, l+64, ... (NQ of them: D = 768 is covered exactly by NQ = 3, no
+// idle lanes), and the next row's dy / z are already in flight while the current one is reduced: the kernel is a pure
+// stream (2 reads + 1-2 writes of M x D bf16) and a wave with one row in flight at a time is latency-bound.
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+template <int NQ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, bf16_t* __restrict__ dz,
@@ -62,36 +66,64 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [4][3][D]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nch = D >> 3;
+  const int nq = D >> 2;
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(M, r_begin + rows_per_block);
-  float dg[NCH][8], db[NCH][8], ds[NCH][8], gm[NCH][8];
+  float dg[NQ][4], db[NQ][4], ds[NQ][4], gm[NQ][4];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
+  for (int i = 0; i < NQ; ++i) {
     const int c = lane + 64 * i;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 4; ++e) {
       dg[i][e] = 0.f; db[i][e] = 0.f; ds[i][e] = 0.f;
-      gm[i][e] = (c < nch) ? gamma[c * 8 + e] : 0.f;
+      gm[i][e] = (c < nq) ? gamma[c * 4 + e] : 0.f;
     }
   }
-  for (int row = r_begin + wave; row < r_end; row += 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float g[NCH][8], xh[NCH][8];
+  u32x2 nd[NQ], nz[NQ];
+  float nmu = 0.f, nrs = 0.f;
+  int row = r_begin + wave;
+  if (row < r_end) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nq) {
+        nd[i] = *reinterpret_cast<const u32x2*>(dy + (size_t)row * D + c * 4);
+        nz[i] = *reinterpret_cast<const u32x2*>(z + (size_t)row * D + c * 4);
+      }
+    }
+    nmu = mean[row]; nrs = rstd[row];
+  }
+  for (; row < r_end; row += 4) {
+    u32x2 cd[NQ], cz[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { cd[i] = nd[i]; cz[i] = nz[i]; }
+    const float mu = nmu, rs = nrs;
+    const int nrow = row + 4;
+    if (nrow < r_end) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nq) {
+          nd[i] = *reinterpret_cast<const u32x2*>(dy + (size_t)nrow * D + c * 4);
+          nz[i] = *reinterpret_cast<const u32x2*>(z + (size_t)nrow * D + c * 4);
+        }
+      }
+      nmu = mean[nrow]; nrs = rstd[nrow];
+    }
+    float g[NQ][4], xh[NQ][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NQ; ++i) {
       const int c = lane + 64 * i;
-      if (c < nch) {
-        float d8[8], z8[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dy + (size_t)row * D + c * 8), d8);
-        unpack8(*reinterpret_cast<const u32x4*>(z + (size_t)row * D + c * 8), z8);
+      if (c < nq) {
+        const float d4[4] = {lo_bf(cd[i][0]), hi_bf(cd[i][0]), lo_bf(cd[i][1]), hi_bf(cd[i][1])};
+        const float z4[4] = {lo_bf(cz[i][0]), hi_bf(cz[i][0]), lo_bf(cz[i][1]), hi_bf(cz[i][1])};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float d = d8[e];
+        for (int e = 0; e < 4; ++e) {
+          float d = d4[e];
           if (dy_drop.thr16 != 0u)
-            d = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 8 + e), dy_drop.thr16) ? d * dy_drop.scale : 0.f;
-          const float x = (z8[e] - mu) * rs;
+            d = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e), dy_drop.thr16) ? d * dy_drop.scale : 0.f;
+          const float x = (z4[e] - mu) * rs;
           xh[i][e] = x;
           dg[i][e] += d * x;
           db[i][e] += d;
@@ -102,43 +134,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { g[i][e] = 0.f; xh[i][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { g[i][e] = 0.f; xh[i][e] = 0.f; }
       }
     }
     const float c1 = wave_sum(s1) / (float)D;
     const float c2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NQ; ++i) {
       const int c = lane + 64 * i;
-      if (c < nch) {
-        float o[8];
+      if (c < nq) {
+        float o[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
-        *reinterpret_cast<u32x4*>(dz + (size_t)row * D + c * 8) = pack8(o);
+        for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(dz + (size_t)row * D + c * 4) = pk;
         if (out2 != nullptr) {
           if (out2_drop.thr16 != 0u) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              o[e] = drop_keep(out2_drop.seed, (uint32_t)row, (uint32_t)(c * 8 + e), out2_drop.thr16)
+            for (int e = 0; e < 4; ++e)
+              o[e] = drop_keep(out2_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e), out2_drop.thr16)
                          ? o[e] * out2_drop.scale : 0.f;
           }
-          *reinterpret_cast<u32x4*>(out2 + (size_t)row * D + c * 8) = pack8(o);
+          pk[0] = pack2bf(o[0], o[1]); pk[1] = pack2bf(o[2], o[3]);
+          *reinterpret_cast<u32x2*>(out2 + (size_t)row * D + c * 4) = pk;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ds[i][e] += o[e];  // column sums of the sub-layer gradient
+        for (int e = 0; e < 4; ++e) ds[i][e] += o[e];  // column sums of the sub-layer gradient
       }
     }
   }
   // reduce the 4 waves' partial dgamma / dbeta through LDS, one partial row per block
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
+  for (int i = 0; i < NQ; ++i) {
     const int c = lane + 64 * i;
-    if (c < nch) {
+    if (c < nq) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[(wave * 3 + 0) * D + c * 8 + e] = dg[i][e];
-        red[(wave * 3 + 1) * D + c * 8 + e] = db[i][e];
-        red[(wave * 3 + 2) * D + c * 8 + e] = ds[i][e];
+      for (int e = 0; e < 4; ++e) {
+        red[(wave * 3 + 0) * D + c * 4 + e] = dg[i][e];
+        red[(wave * 3 + 1) * D + c * 4 + e] = db[i][e];
+        red[(wave * 3 + 2) * D + c * 4 + e] = ds[i][e];
       }
     }
   }
@@ -240,7 +274,7 @@ hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* b
 }
 
 static int ln_bwd_rows_per_block(int M) {
-  int rpb = (M + 511) / 512;  // <= 512 blocks (two per CU: enough loads in flight to stream at HBM rate)
+  int rpb = (M + 1023) / 1024;  // <= 1024 blocks (four per CU; every wave keeps two rows in flight)
   if (rpb < 4) rpb = 4;
   return rpb;
 }
@@ -257,12 +291,14 @@ hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mea
   const int rpb = ln_bwd_rows_per_block(M);
   dim3 grid((M + rpb - 1) / rpb), block(256);
   const size_t lds = (size_t)4 * 3 * D * sizeof(float);
-  if (D <= 512)
-    hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb);
-  else if (D <= 1024)
-    hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb);
+  const int nq = (D / 4 + 63) / 64;
+#define KMB_LN_BWD(NQ) hipLaunchKernelGGL((ln_bwd_kernel<NQ>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb)
+  if (nq <= 1) KMB_LN_BWD(1);
+  else if (nq == 2) KMB_LN_BWD(2);
+  else if (nq == 3) KMB_LN_BWD(3);
+  else if (nq == 4) KMB_LN_BWD(4);
+  else KMB_LN_BWD(8);
+#undef KMB_LN_BWD
   return hipGetLastError();
 }
 
