@@ -18,8 +18,34 @@
 #include <cstdlib>
 #include <map>
 #include <tuple>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
+
+// ---- diagnostic build only (tools/gemm_stamps.py compiles this file with -DKMB_GEMM_STAMP into a separate library):
+// per-workgroup s_memrealtime stamps (100 MHz) + HW_ID / XCC_ID, to read prologue / loop / epilogue / dispatch-gap
+// times off the real kernel.  The product library has none of this.
+#ifdef KMB_GEMM_STAMP
+__device__ unsigned long long* g_kmb_stamps = nullptr;  // [grid][8]
+extern "C" int kmb_debug_set_stamps(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_kmb_stamps), &p, sizeof(p));
+}
+#define KMB_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (g_kmb_stamps != nullptr && threadIdx.x == 0)                                                   \
+      g_kmb_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                   \
+  } while (0)
+#define KMB_STAMP_ID()                                                                                 \
+  do {                                                                                                 \
+    if (g_kmb_stamps != nullptr && threadIdx.x == 0)                                                   \
+      g_kmb_stamps[(size_t)blockIdx.x * 8 + 7] =                                                       \
+          (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |                                      \
+          ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);                               \
+  } while (0)
+#else
+#define KMB_STAMP(i)
+#define KMB_STAMP_ID()
+#endif
 
 namespace {
 
@@ -122,66 +148,58 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
       for (int q = 0; q < 4; ++q)
         ef[(wm * 64 + i * 16 + g * 4 + q) * EPI_LD + wn * 64 + j * 16 + r] = acc[i][j][q];
   __syncthreads();
+  KMB_STAMP(3);
   gemm_epilogue_phase2<NT>(p, ef, reinterpret_cast<float*>(smem + EPI_BYTES * (NT / 256)), tid, row0, col0, slice);
 }
 
 // cs: [NT/16][128] fp32 scratch (only touched when p.colsum != nullptr)
-template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS>
-__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
-                                                     int col0, int slice) {
+// The body is instantiated per epilogue class (ACT: 0 none / 1 GeLU / 2 GeLU' / -1 = read p.act at run time (tanh
+// heads); RES: residual add; CS: column sums) and entered through ONE uniform branch: with every option tested per
+// element inside the 8x-unrolled row loop the epilogue was ~90 KB of code walked once per tile -- instruction fetch,
+// not the stores, made it 4.4 us of a 17 us tile (in-kernel stamps, tools/gemm_stamps.py).
+template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS, int ACT, bool RES, bool CS>
+__device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
+                                                   int col0) {
   constexpr int RPP = NT / 16;  // rows per pass
   constexpr int NH = HOIST ? NIT : 1;
+  constexpr bool AUX = (ACT == 2 || ACT < 0);
   auto eoff = [&](int lrow, int c) { return lrow * LD + (SWZ ? (c ^ (((lrow >> 2) & 1) << 4)) : c); };
-  // ---- phase 2: row-major math + 16-byte stores ----
+  const int act = ACT < 0 ? p.act : ACT;
+  const bool res_on = RES && (ACT >= 0 || p.residual != nullptr);  // the run-time class checks its pointers
+  const bool cs_on = CS && (ACT >= 0 || p.colsum != nullptr);
   const int c8 = (tid & 15) * 8;
   const int gcol = col0 + c8;
-  if (gcol >= p.N && p.colsum == nullptr) return;
+  if (gcol >= p.N && !cs_on) return;
   const int nvalid = gcol >= p.N ? 0 : ((p.N - gcol) < 8 ? (p.N - gcol) : 8);
-  float csum[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-  if (p.split_k > 1) {  // raw partial sums of this K slice -> slab[slice][M][N]
-    float* slab = p.slab + (size_t)slice * p.M * p.N;
-    for (int it = 0; it < NIT; ++it) {
-      const int lrow = (tid >> 4) + RPP * it;
-      const int grow = row0 + lrow;
-      if (grow >= p.M) break;
-      float* o = slab + (size_t)grow * p.N + gcol;
-      if (nvalid == 8 && (p.N & 3) == 0) {
-        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8));
-        *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8) + 4);
-      } else {
-        for (int e = 0; e < nvalid; ++e) o[e] = ef[eoff(lrow, c8) + e];
-      }
-    }
-    return;
-  }
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = (p.bias != nullptr && e < nvalid) ? p.bias[gcol + e] : 0.f;
-
-  // ---- gather everything the 8 row-iterations need first (LDS reads and global residual / aux loads are then in
-  //      flight together instead of one dependent round trip per iteration) ----
   const bool full8 = nvalid == 8;
+  float csum[8], bias8[8], scale8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    csum[e] = 0.f;
+    bias8[e] = (p.bias != nullptr && e < nvalid) ? p.bias[gcol + e] : 0.f;
+    scale8[e] = (gcol + e < p.col_scale_n) ? p.col_scale : 1.0f;  // (v + bias) * scale, the reference's order
+  }
+
+  // ---- gather everything the row-iterations need first (LDS reads and global residual / aux loads are then in
+  //      flight together instead of one dependent round trip per iteration) ----
   f32x4 vlo[NH], vhi[NH];
   u32x4 resv[NH], auxv[NH];
   auto gather = [&](int it, int slot) {
     const int lrow = (tid >> 4) + RPP * it;
     const int grow = row0 + lrow;
-    const bool ok = grow < p.M && nvalid > 0;
+    const bool ok = grow < p.M && full8;
     vlo[slot] = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8));
     vhi[slot] = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8) + 4);
-    resv[slot] = u32x4{0u, 0u, 0u, 0u};
-    auxv[slot] = u32x4{0u, 0u, 0u, 0u};
-    if (ok && full8) {
-      if (p.residual != nullptr) resv[slot] = *reinterpret_cast<const u32x4*>(p.residual + (size_t)grow * p.ld_res + gcol);
-      if (p.act == 2 || p.act == 4) auxv[slot] = *reinterpret_cast<const u32x4*>(p.aux + (size_t)grow * p.ld_aux + gcol);
-    }
+    if (RES) resv[slot] = (ok && res_on) ? *reinterpret_cast<const u32x4*>(p.residual + (size_t)grow * p.ld_res + gcol) : u32x4{0u, 0u, 0u, 0u};
+    if (AUX) auxv[slot] = (ok && (act == 2 || act == 4)) ? *reinterpret_cast<const u32x4*>(p.aux + (size_t)grow * p.ld_aux + gcol)
+                                                         : u32x4{0u, 0u, 0u, 0u};
   };
   if (HOIST) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) gather(it, it);
   }
+  const bool drop = p.drop_thr16 != 0u;
+  const bool skip_stores = (p.tile_order & 256) != 0;  // ablation (tools/gemm_ablate.py): keep the math, drop the stores
   auto process = [&](int it0, int it) -> bool {
     const int lrow = (tid >> 4) + RPP * it0;
     const int grow = row0 + lrow;
@@ -190,11 +208,8 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     v[0] = vlo[it][0]; v[1] = vlo[it][1]; v[2] = vlo[it][2]; v[3] = vlo[it][3];
     v[4] = vhi[it][0]; v[5] = vhi[it][1]; v[6] = vhi[it][2]; v[7] = vhi[it][3];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[e] += bias8[e];
-      if (gcol + e < p.col_scale_n) v[e] *= p.col_scale;
-    }
-    if (p.act == 1) {
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * scale8[e];
+    if (act == 1) {
       if (p.preact != nullptr) {
         if (full8) {
           *reinterpret_cast<u32x4*>(p.preact + (size_t)grow * p.ld_preact + gcol) = pack8(v);
@@ -204,30 +219,30 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-    } else if (p.act == 2 || p.act == 4) {
+    } else if (AUX && (act == 2 || act == 4)) {
       float u[8];
       if (full8) {
         unpack8(auxv[it], u);
       } else {
         for (int e = 0; e < 8; ++e) u[e] = e < nvalid ? bf2f(p.aux[(size_t)grow * p.ld_aux + gcol + e]) : 0.f;
       }
-      if (p.act == 2) {
+      if (act == 2) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
       } else {  // tanh'(.) = 1 - y^2, aux = y
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= (1.f - u[e] * u[e]);
       }
-    } else if (p.act == 3) {  // BartClassificationHead: tanh
+    } else if (ACT < 0 && act == 3) {  // BartClassificationHead: tanh
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
     }
-    if (p.drop_thr16 != 0u) {
+    if (drop) {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         v[e] = drop_keep(p.drop_seed, (uint32_t)grow, (uint32_t)(gcol + e), p.drop_thr16) ? v[e] * p.drop_scale : 0.f;
     }
-    if (p.residual != nullptr) {
+    if (res_on) {
       float rr[8];
       if (full8) {
         unpack8(resv[it], rr);
@@ -237,9 +252,11 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rr[e];
     }
+    if (cs_on) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) csum[e] += v[e];
-    if (p.tile_order & 256) {  // ablation build path (tools/gemm_ablate.py): keep the math alive, drop the stores
+      for (int e = 0; e < 8; ++e) csum[e] += v[e];
+    }
+    if (skip_stores) {
       float keep = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) keep += v[e];
@@ -279,7 +296,7 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
       if (!process(it0, 0)) break;
     }
   }
-  if (p.colsum != nullptr) {
+  if (cs_on) {
     // column sums of this tile's stored values: reduce the row-lanes through LDS, one partial row per 128 rows
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[(tid >> 4) * 128 + c8 + e] = csum[e];
@@ -295,6 +312,50 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
         if (row0 + 64 * k < p.M) p.colsum[(size_t)(prow + k) * p.N + col0 + tid] = 0.f;
     }
   }
+}
+
+template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS>
+__device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
+                                                     int col0, int slice) {
+  constexpr int RPP = NT / 16;
+  auto eoff = [&](int lrow, int c) { return lrow * LD + (SWZ ? (c ^ (((lrow >> 2) & 1) << 4)) : c); };
+  if (p.split_k > 1) {  // raw partial sums of this K slice -> slab[slice][M][N]
+    const int c8 = (tid & 15) * 8;
+    const int gcol = col0 + c8;
+    if (gcol >= p.N) return;
+    const int nvalid = (p.N - gcol) < 8 ? (p.N - gcol) : 8;
+    float* slab = p.slab + (size_t)slice * p.M * p.N;
+    for (int it = 0; it < NIT; ++it) {
+      const int lrow = (tid >> 4) + RPP * it;
+      const int grow = row0 + lrow;
+      if (grow >= p.M) break;
+      float* o = slab + (size_t)grow * p.N + gcol;
+      if (nvalid == 8 && (p.N & 3) == 0) {
+        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8));
+        *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8) + 4);
+      } else {
+        for (int e = 0; e < nvalid; ++e) o[e] = ef[eoff(lrow, c8) + e];
+      }
+    }
+    return;
+  }
+#define KMB_EPI(ACT, RES, CS) gemm_epilogue_body<NT, HOIST, NIT, LD, SWZ, TILE_ROWS, ACT, RES, CS>(p, ef, cs, tid, row0, col0)
+  const bool res = p.residual != nullptr, csf = p.colsum != nullptr;
+  if (p.act == 0) {
+    if (!res && !csf) KMB_EPI(0, false, false);
+    else if (res && !csf) KMB_EPI(0, true, false);
+    else if (!res) KMB_EPI(0, false, true);
+    else KMB_EPI(0, true, true);
+  } else if (p.act == 1 && !res && !csf) {
+    KMB_EPI(1, false, false);
+  } else if (p.act == 2 && !res) {
+    if (csf) KMB_EPI(2, false, true);
+    else KMB_EPI(2, false, false);
+  } else {
+    // everything else (tanh heads, rare combinations): run-time act, non-hoisted compact loop
+    gemm_epilogue_body<NT, false, NIT, LD, SWZ, TILE_ROWS, -1, true, true>(p, ef, cs, tid, row0, col0);
+  }
+#undef KMB_EPI
 }
 
 template <bool A_KC, bool B_KC>
@@ -362,24 +423,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// v2: same tile / fragment maps, but the global->LDS staging is LDS-DMA (global_load_lds, 16 B per
-// lane): no staging VGPRs and no ds_write pass.  A wave instruction writes 1 KiB of LDS linearly
-// (base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE address instead: lane i of
-// piece p lands on physical chunk (i % 8 or i % 16) of its row and therefore fetches the LOGICAL
-// chunk that the swizzle maps there.  Requires K % 64 == 0 (no zero-fill on this path).
+// v7: 128x128x64 tile, 256 threads = 4 waves (2x2) of 64x64, two workgroups per CU.  Global -> LDS staging is
+// LDS-DMA (global_load_lds, 16 B per lane: no staging VGPRs, no ds_write pass).  A wave instruction writes 1 KiB of
+// LDS linearly (base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE address instead: lane i of
+// piece p lands on physical chunk (i % 8 or i % 16) of its row and therefore fetches the LOGICAL chunk that the
+// swizzle maps there.  Requires K % 64 == 0 (no zero-fill on this path; v1 handles ragged K).
+// The K loop is software-pipelined.  (A first LDS-DMA kernel issued its 8 pieces in one burst -- each costs 60-180
+// issue cycles -- and then alternated "read fragments / wait / 8 MFMAs": the matrix pipe idled during the burst and
+// during every LDS round trip.)  Each K step is two phases around ONE barrier:
+//   phase A: MFMAs of k-half 0 (fragments already in registers)  ||  ds_reads of k-half 1
+//   wait for the stage t+1 DMA, barrier (everyone is done reading stage t's LDS image)
+//   phase B: MFMAs of k-half 1  ||  ds_reads of stage t+1's k-half 0  ||  DMA of stage t+2 into the freed buffer
+// with sched_group_barrier interleaving DS / VMEM issue between the MFMAs.  DMA sources are a uniform (SGPR) tile
+// base that advances per K step plus a per-lane 32-bit offset computed once.
 template <bool KC>
-__device__ __forceinline__ void glds_tile(char* lds_tile, const bf16_t* __restrict__ X, int ld, int r0, int R, int k0,
-                                          int wave, int lane) {
+__device__ __forceinline__ void dma_offsets(uint32_t (&off)[4], int ld, int r0, int R, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;  // 16 pieces of 1 KiB per 16 KiB tile
-    const bf16_t* src;
+    const int piece = wave * 4 + i;
     if (KC) {
       const int row = piece * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
       int grow = r0 + row;
       grow = grow < R ? grow : R - 1;
-      src = X + (size_t)grow * ld + k0 + c * 8;
+      off[i] = (uint32_t)(((grow - r0) * ld + c * 8) * 2);
     } else {
       const int krow = piece * 4 + (lane >> 4);
       const int ps = lane & 15;
@@ -387,16 +454,21 @@ __device__ __forceinline__ void glds_tile(char* lds_tile, const bf16_t* __restri
       int m = r0 + c32 * 16 + (ps & 1) * 8;
       const int mlast = ((R - 1) >> 3) << 3;
       m = m < R ? m : mlast;
-      src = X + (size_t)(k0 + krow) * ld + m;
+      off[i] = (uint32_t)((krow * ld + (m - r0)) * 2);
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
   }
 }
 
+__device__ __forceinline__ void dma_piece(const char* gbase, uint32_t off, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off),
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  KMB_STAMP(0);
+  KMB_STAMP_ID();
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -417,75 +489,131 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const KmbGemm p) {
   const int nt_all = p.K / BK;
   const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
   const int nt = t_end - t_begin;
-  glds_tile<A_KC>(smem, p.A, p.lda, row0, p.M, t_begin * BK, wave, lane);
-  glds_tile<B_KC>(smem + BM * BK * 2, p.B, p.ldb, col0, p.N, t_begin * BK, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
-  const int nt_run = (p.tile_order & 512) ? 1 : nt;  // ablation: one K step only
-  for (int t = 0; t < nt_run; ++t) {
-    char* cur = smem + (t & 1) * STAGE_BYTES;
-    char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-    if (t + 1 < nt) {
-      glds_tile<A_KC>(nxt, p.A, p.lda, row0, p.M, (t_begin + t + 1) * BK, wave, lane);
-      glds_tile<B_KC>(nxt + BM * BK * 2, p.B, p.ldb, col0, p.N, (t_begin + t + 1) * BK, wave, lane);
-    }
-    const char* la = cur;
-    const char* lb = cur + BM * BK * 2;
+  uint32_t offA[4], offB[4];
+  dma_offsets<A_KC>(offA, p.lda, row0, p.M, wave, lane);
+  dma_offsets<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
+  const size_t stepA = A_KC ? (size_t)BK * 2 : (size_t)BK * p.lda * 2;
+  const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
+  const char* gA = reinterpret_cast<const char*>(p.A) +
+                   (A_KC ? ((size_t)row0 * p.lda + (size_t)t_begin * BK) * 2 : (size_t)row0 * 2) +
+                   (A_KC ? 0 : (size_t)t_begin * stepA);
+  const char* gB = reinterpret_cast<const char*>(p.B) +
+                   (B_KC ? ((size_t)col0 * p.ldb + (size_t)t_begin * BK) * 2 : (size_t)col0 * 2) +
+                   (B_KC ? 0 : (size_t)t_begin * stepB);
+  constexpr int A_TILE = BM * BK * 2;
+  char* const dstA = smem + wave * 4096;            // this wave's 4 pieces of the A image (stage 0)
+  char* const dstB = smem + A_TILE + wave * 4096;
+
+  // K step `ks` (relative to t_begin) of this tile -> LDS stage buffer; the tile base is forced into SGPRs so the
+  // loads take the saddr + 32-bit-voffset form (no per-piece 64-bit VALU address arithmetic)
+  auto uniform_ptr = [](const char* ptr) {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  auto dma_stage = [&](int ks, int stage_buf) {
+    char* da = dstA + stage_buf * STAGE_BYTES;
+    char* db = dstB + stage_buf * STAGE_BYTES;
+    const char* ga = uniform_ptr(gA + (size_t)ks * stepA);
+    const char* gb = uniform_ptr(gB + (size_t)ks * stepB);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
+    for (int i = 0; i < 4; ++i) dma_piece(ga, offA[i], da + i * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KC>(la, wm * 4 + i, kk, r, g);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KC>(lb, wn * 4 + j, kk, r, g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    for (int i = 0; i < 4; ++i) dma_piece(gb, offB[i], db + i * 1024);
+  };
+
+  bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  dma_stage(0, 0);
+  if (nt > 1) {
+    dma_stage(1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): stage 0 has landed
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   }
+  __syncthreads();
+  KMB_STAMP(1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(smem, wm * 4 + i, 0, r, g);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(smem + A_TILE, wn * 4 + j, 0, r, g);
+
+  constexpr int NDS = (A_KC ? 4 : 8) + (B_KC ? 4 : 8);  // ds_read instructions per fragment set
+  auto kstep = [&](int t, auto do_dma, auto do_next) {
+    const char* cur = smem + (t & 1) * STAGE_BYTES;
+    const char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+    // ---- phase A ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa1[i] = read_frag<A_KC>(cur, wm * 4 + i, 1, r, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb1[j] = read_frag<B_KC>(cur + A_TILE, wn * 4 + j, 1, r, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA first: they wait on phase B's reads, not on these
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);        // MFMA
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the builtin (not inline asm) so the compiler's own
+                                         // wait tracking knows the fragments have arrived
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B ----  (the DMA overwrites LDS the fragment reads may alias: reads first, DMA pieces behind them)
+    if (decltype(do_next)::value) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(nxt, wm * 4 + i, 0, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(nxt + A_TILE, wn * 4 + j, 0, r, g);
+    }
+    if (decltype(do_dma)::value) dma_stage(t + 2, t & 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+    if (decltype(do_next)::value && decltype(do_dma)::value) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+      }
+    } else if (decltype(do_next)::value) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+  int t = 0;
+  for (; t + 2 < nt; ++t) kstep(t, Yes{}, Yes{});
+  if (t + 1 < nt) { kstep(t, No{}, Yes{}); ++t; }
+  kstep(t, No{}, No{});
+  __syncthreads();
+  KMB_STAMP(2);
   gemm_epilogue<256>(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
+  KMB_STAMP(4);
 }
 
 
 // ------------------------------------------------------------------------------------------
-// LDS-DMA staging / fragment reads for tiles that are 128 or 256 rows (columns) tall; used by v4.
-// (A 256x128 three-stage variant with counted vmcnt was measured 10-25 % slower than v2 on every training
-//  shape -- one workgroup per CU loses the cross-workgroup overlap -- and was removed.)
-
-template <bool KC, int ROWS>
-__device__ __forceinline__ void glds_tile3(char* lds_tile, const bf16_t* __restrict__ X, int ld, int r0, int R, int k0,
-                                           int wave, int lane) {
-  constexpr int PIECES = ROWS / 8;   // 1 KiB pieces per tile
-  constexpr int PER_WAVE = PIECES / 8;
-#pragma unroll
-  for (int i = 0; i < PER_WAVE; ++i) {
-    const int piece = wave * PER_WAVE + i;
-    const bf16_t* src;
-    if (KC) {
-      const int row = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      int grow = r0 + row;
-      grow = grow < R ? grow : R - 1;
-      src = X + (size_t)grow * ld + k0 + c * 8;
-    } else {
-      constexpr int LPR = ROWS / 8;            // lanes (16-byte slots) per k-row
-      const int krow = piece * (64 / LPR) + lane / LPR;
-      const int ps = lane % LPR;
-      const int c32 = (ps >> 1) ^ swz_nkc(krow);
-      int m = r0 + c32 * 16 + (ps & 1) * 8;
-      const int mlast = ((R - 1) >> 3) << 3;
-      m = m < R ? m : mlast;
-      src = X + (size_t)(k0 + krow) * ld + m;
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
-  }
-}
+// fragment reads for tiles that are 256 rows (columns) tall (v8)
 
 template <bool KC, int ROWS>
 __device__ __forceinline__ bf16x8 read_frag3(const char* lds, int rowtile16, int kk, int r, int g) {
@@ -507,17 +635,49 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* lds, int rowtile16, int
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// v4: 256x256x64 tile, 512 threads = 8 waves (2x4), each wave 128x64 (8x4 MFMA tiles): 12 fragment reads per
-// 32 MFMAs instead of 8 per 16 -- the LDS read traffic per MFMA is what bounds the 64x64-per-wave kernels.
-// Two 64 KB stages filled by LDS-DMA; epilogue in two column halves (fp32 staging does not fit otherwise).
+// 256x256x64 tile, 512 threads = 8 waves (2x4), each wave 128x64 (8x4 MFMA tiles); two 64 KB stages filled by
+// LDS-DMA; epilogue in two column halves (the fp32 staging image does not fit otherwise).
 constexpr int BM4 = 256, BN4 = 256;
 constexpr int ST4 = (BM4 + BN4) * BK * 2;   // 64 KB
 constexpr int LDS4 = ((2 * ST4 > 2 * EPI_BYTES) ? 2 * ST4 : 2 * EPI_BYTES) + CS512;
 
+
+// ------------------------------------------------------------------------------------------
+// v8: the 256x256 tile with v7's software-pipelined K loop (same per-element accumulation order: bit-identical).  A 128x128 tile needs one 1 KiB LDS-DMA piece per 16 MFMAs, which keeps the CU's
+// texture-address path as busy as its matrix pipe (measured: 0.81 us per K step for two co-resident workgroups,
+// 0.49 us of it MFMA); the 256x256 tile halves that ratio.  Each K step is four sub-phases of 16 MFMAs per wave:
+//   0: A(k0, rows 0-63) x B(k0)      || read A(k0, rows 64-127)
+//   1: A(k0, rows 64-127) x B(k0)    || read A(k1, rows 0-63), B(k1)
+//   2: A(k1, rows 0-63) x B(k1)      || read A(k1, rows 64-127);  wait DMA(t+1), barrier
+//   3: A(k1, rows 64-127) x B(k1)    || read A/B(k0) of stage t+1, then DMA stage t+2 into the freed buffer
+template <bool KC>
+__device__ __forceinline__ void dma_offsets256(uint32_t (&off)[4], int ld, int r0, int R, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;  // 32 pieces of 1 KiB per 256-row tile
+    if (KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      int grow = r0 + row;
+      grow = grow < R ? grow : R - 1;
+      off[i] = (uint32_t)(((grow - r0) * ld + c * 8) * 2);
+    } else {
+      const int krow = piece * 2 + (lane >> 5);
+      const int ps = lane & 31;
+      const int c32 = (ps >> 1) ^ swz_nkc(krow);
+      int m = r0 + c32 * 16 + (ps & 1) * 8;
+      const int mlast = ((R - 1) >> 3) << 3;
+      m = m < R ? m : mlast;
+      off[i] = (uint32_t)((krow * ld + (m - r0)) * 2);
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
+__global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  KMB_STAMP(0);
+  KMB_STAMP_ID();
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -540,35 +700,123 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
   const int nt = t_end - t_begin;
   constexpr int A_BYTES = BM4 * BK * 2;
 
-  glds_tile3<A_KC, BM4>(smem, p.A, p.lda, row0, p.M, t_begin * BK, wave, lane);
-  glds_tile3<B_KC, BN4>(smem + A_BYTES, p.B, p.ldb, col0, p.N, t_begin * BK, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * ST4;
-    char* nxt = smem + ((t + 1) & 1) * ST4;
-    if (t + 1 < nt) {
-      glds_tile3<A_KC, BM4>(nxt, p.A, p.lda, row0, p.M, (t_begin + t + 1) * BK, wave, lane);
-      glds_tile3<B_KC, BN4>(nxt + A_BYTES, p.B, p.ldb, col0, p.N, (t_begin + t + 1) * BK, wave, lane);
-    }
-    const char* la = cur;
-    const char* lb = cur + A_BYTES;
+  uint32_t offA[4], offB[4];
+  dma_offsets256<A_KC>(offA, p.lda, row0, p.M, wave, lane);
+  dma_offsets256<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
+  const size_t stepA = A_KC ? (size_t)BK * 2 : (size_t)BK * p.lda * 2;
+  const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
+  const char* gA = reinterpret_cast<const char*>(p.A) + (A_KC ? (size_t)row0 * p.lda * 2 : (size_t)row0 * 2) + (size_t)t_begin * stepA;
+  const char* gB = reinterpret_cast<const char*>(p.B) + (B_KC ? (size_t)col0 * p.ldb * 2 : (size_t)col0 * 2) + (size_t)t_begin * stepB;
+  char* const dstA = smem + wave * 4096;
+  char* const dstB = smem + A_BYTES + wave * 4096;
+  auto uniform_ptr = [](const char* ptr) {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  auto dma_stage = [&](int ks, int stage_buf) {
+    char* da = dstA + stage_buf * ST4;
+    char* db = dstB + stage_buf * ST4;
+    const char* ga = uniform_ptr(gA + (size_t)ks * stepA);
+    const char* gb = uniform_ptr(gB + (size_t)ks * stepB);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[8], fb[4];
+    for (int i = 0; i < 4; ++i) dma_piece(ga, offA[i], da + i * 1024);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag3<B_KC, BN4>(lb, wn * 4 + j, kk, r, g);
+    for (int i = 0; i < 4; ++i) dma_piece(gb, offB[i], db + i * 1024);
+  };
+
+  constexpr int NDA = A_KC ? 4 : 8;  // ds_read instructions per 4 A fragments / per 4 B fragments
+  constexpr int NDB = B_KC ? 4 : 8;
+  bf16x8 fa[2][4], fb[2][4];
+  auto read_a = [&](const char* stage, int kk, int half, bf16x8 (&dst)[4]) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = read_frag3<A_KC, BM4>(la, wm * 8 + i, kk, r, g);
+    for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * 8 + half * 4 + i, kk, r, g);
+  };
+  auto read_b = [&](const char* stage, int kk, bf16x8 (&dst)[4]) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 4; ++j) dst[j] = read_frag3<B_KC, BN4>(stage + A_BYTES, wn * 4 + j, kk, r, g);
+  };
+  auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[half * 4 + i][j], 0, 0, 0);
+  };
+
+  dma_stage(0, 0);
+  if (nt > 1) {
+    dma_stage(1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): stage 0 has landed
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   }
+  __syncthreads();
+  KMB_STAMP(1);
+  read_b(smem, 0, fb[0]);
+  read_a(smem, 0, 0, fa[0]);
+
+  auto kstep = [&](int t, auto do_dma, auto do_next) {
+    const char* cur = smem + (t & 1) * ST4;
+    const char* nxt = smem + ((t + 1) & 1) * ST4;
+    // ---- sub-phase 0 ----
+    read_a(cur, 0, 1, fa[1]);
+    mma(0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- sub-phase 1 ----
+    read_b(cur, 1, fb[1]);
+    read_a(cur, 1, 0, fa[0]);
+    mma(1, fa[1], fb[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, NDB, 1);  // B(k1) does not overwrite anything in use
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- sub-phase 2 ----
+    read_a(cur, 1, 1, fa[1]);
+    mma(0, fa[0], fb[1]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
+    __builtin_amdgcn_sched_group_barrier(0x100, NDA, 2);
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage t+1 landed, this wave is done reading stage t
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- sub-phase 3 ----
+    if (decltype(do_next)::value) {
+      read_b(nxt, 0, fb[0]);
+      read_a(nxt, 0, 0, fa[0]);
+    }
+    if (decltype(do_dma)::value) dma_stage(t + 2, t & 1);
+    mma(1, fa[1], fb[1]);
+    if (decltype(do_next)::value && decltype(do_dma)::value) {
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB, 3);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 3);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA, 3);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 3);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 3);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 3);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+  int t = 0;
+  for (; t + 2 < nt; ++t) kstep(t, Yes{}, Yes{});
+  if (t + 1 < nt) { kstep(t, No{}, Yes{}); ++t; }
+  kstep(t, No{}, No{});
+  __syncthreads();
+  KMB_STAMP(2);
   // epilogue: two passes over the column halves; in pass h the waves with (wn >> 1) == h stage their accumulators
   float* ef = reinterpret_cast<float*>(smem);
   for (int h = 0; h < 2; ++h) {
@@ -582,18 +830,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(const KmbGemm p) {
             ef[(wm * 128 + i * 16 + g * 4 + q) * EPI_LD + (wn & 1) * 64 + j * 16 + r] = acc[i][j][q];
     }
     __syncthreads();
+    if (h == 0) KMB_STAMP(3);
     gemm_epilogue_phase2<512, false>(p, ef, reinterpret_cast<float*>(smem + 2 * EPI_BYTES), tid, row0, col0 + h * 128, slice);
     __syncthreads();
   }
+  KMB_STAMP(4);
 }
 
 
 // Variants that were built, verified bit-identical and then REMOVED because they measured slower on every training
 // shape (MI355X, b=256): a 256x128 three-stage ring with counted vmcnt (one workgroup per CU: -10..25 %), a
-// transposed-block MFMA with a register epilogue and 8-byte stores (-20 %: the stores are issue-bound), and several
-// tiles per workgroup with the next tile's first K step prefetched under the epilogue (-5..30 %: fewer independent
-// workgroups to overlap).  What did pay: LDS-DMA staging, hoisted epilogue loads, hardware bf16 conversion, split-K
-// for the weight gradients, per-shape choice between the 128x128 and 256x256 tiles and the XCD tile order.
+// transposed-block MFMA with a register epilogue and 8-byte stores (-20 %), several tiles per workgroup with the
+// next tile's first K step prefetched under the epilogue (-5..30 %), and the un-pipelined forms of v7 / v8 (their K
+// loops were 3-25 % slower).  A start-time phase stagger between co-resident workgroups / between CUs was also
+// measured (stamps: the K loop gets shorter, the epilogue longer, the tile time does not move) and dropped.
+// What did pay: LDS-DMA staging, the software-pipelined K loop, one uniform branch into a class-specialised epilogue
+// (instruction fetch, not the stores, bounded the generic one), hoisted epilogue loads, hardware bf16 conversion,
+// split-K for the weight gradients, per-shape choice between the 128x128 and 256x256 tiles and the XCD tile order.
 
 }  // namespace
 
@@ -622,21 +875,22 @@ const char* kmb_gemm_check(const KmbGemm& p) {
 
 namespace {
 
+// variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  if (variant == 4) {
+  if (variant == 8) {
     const int tiles = ((p.M + BM4 - 1) / BM4) * ((p.N + BN4 - 1) / BN4);
     dim3 grid(tiles * nsl), block(512);
-    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v4<true, true>), grid, block, LDS4, stream, p);
-    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v4<true, false>), grid, block, LDS4, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel_v4<false, false>), grid, block, LDS4, stream, p);
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v8<true, true>), grid, block, LDS4, stream, p);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v8<true, false>), grid, block, LDS4, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel_v8<false, false>), grid, block, LDS4, stream, p);
   } else {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles * nsl), block(256);
-    if (variant == 2) {
-      if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, true>), grid, block, LDS_BYTES, stream, p);
-      else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v2<true, false>), grid, block, LDS_BYTES, stream, p);
-      else hipLaunchKernelGGL((gemm_kernel_v2<false, false>), grid, block, LDS_BYTES, stream, p);
+    if (variant == 7) {
+      if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v7<true, true>), grid, block, LDS_BYTES, stream, p);
+      else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v7<true, false>), grid, block, LDS_BYTES, stream, p);
+      else hipLaunchKernelGGL((gemm_kernel_v7<false, false>), grid, block, LDS_BYTES, stream, p);
     } else {
       if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, LDS_BYTES, stream, p);
       else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, LDS_BYTES, stream, p);
@@ -679,32 +933,32 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
   }
   const bool dma_ok = (p.K % BK) == 0;           // LDS-DMA variants have no K-edge zero fill
   const bool big = dma_ok && p.M > 128;
   if (!dma_ok) return launch_variant(1, p, stream);
   if (forced) {
     int v = forced;
-    if (v == 3 || (v == 4 && !(big && p.N > 128))) v = 2;
-    if (v != 1 && v != 2 && v != 4) v = 2;
+    if (v == 8 && !(big && p.N > 128)) v = 7;
+    if (v != 1 && v != 7 && v != 8) v = 7;
     return launch_variant(v, p, stream);
   }
-  if (!big || p.N <= 128) return launch_variant(2, p, stream);
+  if (!big || p.N <= 128) return launch_variant(7, p, stream);
   const TuneKey key{p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act};
   auto it = g_best.find(key);
   if (it == g_best.end()) {
-    if (!autotune || writes_an_input(p)) return launch_variant(2, p, stream);
-    const int cands[4] = {2, 2 + 16, 4, 4 + 16};   // variant | (tile_order << 4)
+    if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
+    const int cands[4] = {7, 7 + 16, 8, 8 + 16};   // variant | (tile_order << 4)
     float best_ms = 1e30f;
-    int best = 2;
+    int best = 7;
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_variant(2, p, stream);
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_variant(7, p, stream);
     for (int c : cands) {
       KmbGemm q = p;
       q.tile_order = c >> 4;

@@ -1,5 +1,6 @@
 """Thin helpers that call single HIP kernels through the C-ABI with torch tensors (GPU tests only)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -19,7 +20,7 @@ def bf(x):
 
 def gemm(A, B, a_kc=True, b_kc=True, M=None, N=None, K=None, bias=None, col_scale=1.0, col_scale_n=0, act=0,
          preact=None, aux=None, drop_p=0.0, drop_seed=0, residual=None, out_bf16=None, out_f32=None, beta=0.0,
-         split_k=0, slab=None, colsum=None):
+         split_k=0, slab=None, colsum=None, tile_order=None):
     """A, B are bf16 2-D tensors in their STORAGE layout; M/N/K default from the shapes."""
     lib = _lib.load()
     if M is None:
@@ -53,6 +54,7 @@ def gemm(A, B, a_kc=True, b_kc=True, M=None, N=None, K=None, bias=None, col_scal
     g.split_k = split_k
     g.slab = ptr(slab)
     g.colsum = ptr(colsum)
+    g.tile_order = int(os.environ.get("KMB_TILE_ORDER", "0"), 0) if tile_order is None else tile_order
     check(lib.kmb_op_gemm(C.byref(g), stream()))
 
 

@@ -1,4 +1,5 @@
-"""Where does a short-K GEMM spend its time?  v2 with (a) everything, (b) no epilogue stores, (c) one K step only."""
+"""Epilogue cost of a short-K GEMM: plain, GeLU + pre-activation store, and with the stores dropped (tile_order bit 256).
+The per-phase timeline comes from tools/gemm_stamps.py."""
 import os
 import sys
 
@@ -11,7 +12,7 @@ from kmbart import _lib  # noqa: E402
 from kmbart._lib import KmbGemm, check, ptr  # noqa: E402
 from gpu_util import DEV, bf, stream  # noqa: E402
 
-os.environ.setdefault("KMB_GEMM_VARIANT", "2")
+os.environ.setdefault("KMB_GEMM_VARIANT", "7")
 lib = _lib.load()
 for (M, N, K) in [(16384, 3072, 768), (16384, 768, 768), (16384, 768, 3072), (16384, 2304, 768)]:
     A = bf(torch.randn((M, K), device=DEV))
@@ -19,8 +20,7 @@ for (M, N, K) in [(16384, 3072, 768), (16384, 768, 768), (16384, 768, 3072), (16
     out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     bias = torch.zeros(N, device=DEV)
-    for label, order, act in (("full", 0, 0), ("full+gelu+preact", 0, 1), ("no-stores", 256, 0), ("one-k-step", 512, 0),
-                              ("one-k-step,no-stores", 768, 0)):
+    for label, order, act in (("full", 0, 0), ("full+gelu+preact", 0, 1), ("no-stores", 256, 0)):
         g = KmbGemm()
         g.A, g.B, g.lda, g.ldb, g.a_kc, g.b_kc = ptr(A), ptr(B), K, K, 1, 1
         g.M, g.N, g.K = M, N, K

@@ -1,4 +1,4 @@
-"""GEMM microbenchmark for one kernel variant (KMB_GEMM_VARIANT=1..4): correctness vs torch + TFLOP/s per shape."""
+"""GEMM microbenchmark for one kernel variant (KMB_GEMM_VARIANT=1, 7 or 8): correctness vs torch + TFLOP/s per shape."""
 import os
 import sys
 

@@ -1,5 +1,5 @@
-"""Debug: v1 (register staged) and v2 (LDS-DMA) GEMM kernels must agree bit for bit; run in two processes
-(KMB_GEMM_V1=1 / unset) writing checksums, or repeat launches to screen for races."""
+"""Debug: every GEMM variant (KMB_GEMM_VARIANT=1, 7, 8) must agree bit for bit; run once per variant
+and diff the printed checksums, or repeat launches to screen for races."""
 import hashlib
 import os
 import sys
