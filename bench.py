@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) side measurement")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling aid: weight-gradient GEMMs on the main stream (no overlap), so a rocprofv3 "
+                         "kernel trace shows every kernel's stand-alone duration; not the product configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +141,8 @@ def main():
     model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(VCG_BASE))
     model.to(dev)
     model._engine.set_seed(1234 + rank)
+    if args.serial:
+        _lib.load().kmb_set_side_stream(model._engine.h, 0)
     ddp = DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
     ddp.train()
     opt = AdamW(model.parameters(), lr=args.lr)
@@ -253,7 +258,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_kernel_v2/v4<A_KC,B_KC> (all GEMM launches of a step, timed serially)",
+            "kernel": "gemm_kernel_v7/v8<A_KC,B_KC> (all GEMM launches of a step, timed serially)",
             "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
             "gemm_ms_per_step": round(tot_ms / n_prof, 3),
             "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),

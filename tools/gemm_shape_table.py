@@ -25,6 +25,7 @@ for _ in range(3):
     opt.step()
 torch.cuda.synchronize()
 lib = _lib.load()
+lib.kmb_set_side_stream(model._engine.h, 0)  # time the launches one at a time, not overlapped with each other
 lib.kmb_profile_gemm(1)
 model.train_step_fwd_bwd(batch)
 torch.cuda.synchronize()
