@@ -831,6 +831,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
     }
     __syncthreads();
     if (h == 0) KMB_STAMP(3);
+    // HOIST = false: the other column half's accumulators are still live, hoisting the loads spills 242 VGPRs
     gemm_epilogue_phase2<512, false>(p, ef, reinterpret_cast<float*>(smem + 2 * EPI_BYTES), tid, row0, col0 + h * 128, slice);
     __syncthreads();
   }

@@ -188,22 +188,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 
 // out[c] = beta*out[c] + sum_p partials[p*stride + c].  Two shapes of the same reduction:
 //  (a) many partial rows, few columns (LayerNorm / bias gradients): 32 columns x 8 part-lanes per block
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ partials, int nparts, size_t stride,
-                                                           float* __restrict__ out, int n) {
-  __shared__ float red[8][33];
+template <int PL>  // part-lanes per block: 32 columns x PL part-lanes
+__global__ __launch_bounds__(32 * PL) void reduce_parts_kernel(const float* __restrict__ partials, int nparts,
+                                                               size_t stride, float* __restrict__ out, int n) {
+  __shared__ float red[PL][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
   if (c < n) {
 #pragma unroll 8
-    for (int p = pl; p < nparts; p += 8) s += partials[(size_t)p * stride + c];
+    for (int p = pl; p < nparts; p += PL) s += partials[(size_t)p * stride + c];
   }
   red[pl][cl] = s;
   __syncthreads();
   if (pl == 0 && c < n) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    for (int k = 0; k < PL; ++k) t += red[k][cl];
     out[c] = t;
   }
 }
@@ -305,7 +306,12 @@ hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mea
 hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride, float* out, int n,
                                    hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, partials, nparts, (size_t)stride, out, n);
+  // only n / 32 blocks exist (72 for a LayerNorm): with many partial rows the kernel is latency-bound, so give each
+  // block 32 part-lanes (1024 threads) worth of loads in flight
+  if (nparts >= 256)
+    hipLaunchKernelGGL((reduce_parts_kernel<32>), dim3((n + 31) / 32), dim3(1024), 0, stream, partials, nparts, (size_t)stride, out, n);
+  else
+    hipLaunchKernelGGL((reduce_parts_kernel<8>), dim3((n + 31) / 32), dim3(256), 0, stream, partials, nparts, (size_t)stride, out, n);
   return hipGetLastError();
 }
 
