@@ -33,6 +33,22 @@ class PackedFeatures:
     def __len__(self):
         return self.offsets.numel() - 1
 
+    # list-of-tensors view (what the reference's collator hands out, collation.py:73-76): views, no copies
+    def __getitem__(self, i):
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        a, b = int(self.offsets[i]), int(self.offsets[i + 1])
+        return self.packed[a:b] if b > a else torch.empty(0)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def as_list(self):
+        return list(self)
+
 
 class DevicePrefetcher:
     """Iterates a loader of collated batches (dicts), returning batches whose tensors already live on `device`;
