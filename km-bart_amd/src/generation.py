@@ -3,6 +3,11 @@ model.generate over a loader and return `{index, task_type, generations}` record
 from datetime import datetime
 
 
+def _features(feats, device):
+    """list of per-sample tensors (reference collator) or a kmbart.data.PackedFeatures (two copies, not B)"""
+    return feats.to(device) if hasattr(feats, "packed") else [f.to(device) for f in feats]
+
+
 def generate_text(model, gen_loader, tokenizer, args, device, logger=None, log_interval=1):
     n_steps = len(gen_loader)
     model.eval()
@@ -12,7 +17,7 @@ def generate_text(model, gen_loader, tokenizer, args, device, logger=None, log_i
     for i, batch in enumerate(gen_loader):
         out = model.generate(
             input_ids=batch["input_ids"].to(device),
-            image_features=[f.to(device) for f in batch["image_features"]],
+            image_features=_features(batch["image_features"], device),
             attention_mask=batch["attention_mask"].to(device),
             num_beams=args.num_beams,
             num_return_sequences=num_gen,

@@ -1,6 +1,7 @@
 """Generation driver: counterpart of the reference's vcg_generate.py (flags of vcg_generate.py:71-123).
 Loads a checkpoint, runs generate_text over a loader and writes the `{index, task_type, generations}` JSON.
-Offline only `--synthetic N` inputs are available; ids are written un-decoded when no tokenizer is present."""
+`--data_dir DIR` reads "<split>_eval.json" + feature pickles in the reference's format (tokenizer: the BART-large files
+on disk or `--tokenizer_json`); `--synthetic N` needs no files and writes the generated ids un-decoded."""
 import argparse
 import json
 import os
@@ -31,15 +32,26 @@ def main(args):
     logger = Logger(args.log_dir)
     model = MultiModalBartForConditionalGeneration.from_pretrained(args.checkpoint)
     model.to(device)
-    if args.synthetic <= 0:
-        raise NotImplementedError("only --synthetic N inputs are available offline")
+    tokenizer = IdTokenizer()
     loader = []
-    for i in range(args.synthetic):
-        b = make_batch(args.batch_size, seed=4321 + i, num_regions=36 if args.use_image else 0,
-                       event_lens=None if args.use_image else [59] * args.batch_size)
-        b["index"] = [i * args.batch_size + j for j in range(args.batch_size)]
-        loader.append(b)
-    generated = generate_text(model, loader, IdTokenizer(), args, device, logger=logger)
+    if args.synthetic > 0:
+        for i in range(args.synthetic):
+            b = make_batch(args.batch_size, seed=4321 + i, num_regions=36 if args.use_image else 0,
+                           event_lens=None if args.use_image else [59] * args.batch_size)
+            b["index"] = [i * args.batch_size + j for j in range(args.batch_size)]
+            loader.append(b)
+    else:   # vcg_generate.py:37-57: the eval split (one record per image), no labels
+        from torch.utils.data import DataLoader
+        from src.data.collation import Collator
+        from src.data.dataset import VCGDataset
+        from src.data.offline_tokenizer import load_base_tokenizer
+        from src.data.tokenization import ConditionTokenizer
+        tokenizer = ConditionTokenizer(base_tokenizer=load_base_tokenizer(args.tokenizer_json or "facebook/bart-large"))
+        dataset = VCGDataset(args.data_dir, split=args.split, use_image=args.use_image, use_event=args.use_event,
+                             eval_mode=True)
+        loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
+                            collate_fn=Collator(tokenizer, has_label=False, pin_memory=True))
+    generated = generate_text(model, loader, tokenizer, args, device, logger=logger)
     with open(args.output_file, "w") as f:
         json.dump(generated, f)
 
@@ -65,10 +77,13 @@ def parse_args(argv=None):
     p.add_argument("--batch_size", type=int, default=64)
     p.add_argument("--num_workers", type=int, default=0)
     p.add_argument("--synthetic", type=int, default=0)
+    p.add_argument("--tokenizer_json", default=None, type=str)
     p.set_defaults(use_event=True, use_image=True)
     args = p.parse_args(argv)
     if args.cpu:
         raise ValueError("--cpu: this build has no CPU path")
+    if args.synthetic <= 0 and args.data_dir is None:
+        raise ValueError("give --data_dir or --synthetic N")
     return args
 
 

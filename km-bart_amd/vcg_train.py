@@ -2,8 +2,10 @@
 on the MI355X engine.  One process per GPU (`--gpu_num N` spawns N ranks, reference vcg_train.py:350-355),
 RCCL gradient all-reduce, fused AdamW.
 
-The reference's data pipeline (BART-large BPE vocabulary, per-image pickles) is outside the hot path and not
-available offline; `--synthetic N` trains on N synthetic VCG batches per epoch instead.
+`--data_dir DIR` reads the reference's on-disk format (src/data/dataset.py) through the Collator into packed, pinned
+batches that a side stream copies one step ahead; the BART-large vocabulary is needed for real data
+(`--tokenizer_json FILE` loads any `tokenizers` JSON instead -- there is no network here).  `--synthetic N` trains on
+N synthetic VCG batches per epoch with no files at all.
 """
 import argparse
 import json
@@ -19,6 +21,7 @@ import torch.multiprocessing as mp  # noqa: E402
 
 from kmbart.optim import AdamW  # noqa: E402
 from kmbart.parallel import DistributedDataParallel  # noqa: E402
+from kmbart.data import DevicePrefetcher  # noqa: E402
 from src.data.synthetic import make_batch  # noqa: E402
 from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration  # noqa: E402
 from src.training import fine_tune  # noqa: E402
@@ -39,6 +42,23 @@ class SyntheticLoader:
             b = make_batch(self.bs, seed=(1234 + self.rank) * 100003 + i, num_regions=36 if self.use_image else 0,
                            event_lens=None if self.use_image else [59] * self.bs)
             yield b
+
+
+def build_vcg_loader(args, rank, device):
+    """VCGDataset -> DistributedSampler -> DataLoader(Collator) -> DevicePrefetcher (vcg_train.py:115-142)"""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from src.data.collation import Collator
+    from src.data.dataset import VCGDataset
+    from src.data.offline_tokenizer import load_base_tokenizer
+    from src.data.tokenization import ConditionTokenizer
+    base = load_base_tokenizer(args.tokenizer_json or "facebook/bart-large")
+    tokenizer = ConditionTokenizer(base_tokenizer=base)
+    dataset = VCGDataset(args.data_dir, split="train", use_image=args.use_image, use_event=args.use_event)
+    sampler = DistributedSampler(dataset, num_replicas=args.gpu_num, rank=rank)
+    loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
+                        sampler=sampler, collate_fn=Collator(tokenizer, has_label=True, pin_memory=True))
+    return DevicePrefetcher(loader, device)
 
 
 def main(rank, args):
@@ -68,10 +88,10 @@ def main(rank, args):
     start_epoch = 0
     if args.continue_training:
         start_epoch = load_training_data(args.checkpoint, optimizer=optimizer, map_location="cpu")["epoch"] + 1
-    if args.synthetic <= 0:
-        raise NotImplementedError("only --synthetic N is available offline (the VCG dataset / BART vocabulary are "
-                                  "not part of the hot path; SURVEY.md section 8f rows 1 and 4)")
-    loader = SyntheticLoader(args.synthetic, args.batch_size, rank, use_image=args.use_image)
+    if args.synthetic > 0:
+        loader = SyntheticLoader(args.synthetic, args.batch_size, rank, use_image=args.use_image)
+    else:
+        loader = build_vcg_loader(args, rank, device)
     for epoch in range(start_epoch, args.epochs):
         logger.info("Epoch {}".format(epoch + 1), pad=True)
         fine_tune(epoch, model, loader, optimizer, device, args, logger=logger, log_interval=args.log_interval)
@@ -112,6 +132,8 @@ def parse_args(argv=None):
     p.add_argument("--batch_size", type=int, default=64)
     p.add_argument("--num_workers", type=int, default=0)
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic VCG batches per epoch")
+    p.add_argument("--tokenizer_json", default=None, type=str,
+                   help="a `tokenizers` JSON to use instead of the facebook/bart-large vocabulary files")
     p.add_argument("--log_interval", type=int, default=1)
     p.set_defaults(use_event=True, use_image=True)
     args = p.parse_args(argv)
@@ -119,6 +141,8 @@ def parse_args(argv=None):
         raise ValueError("--cpu: this build has no CPU path (the hot path runs on MI355X only)")
     if args.checkpoint is None and args.model_config is None:
         raise ValueError("--model_config and --checkpoint cannot be empty at the same time")
+    if args.synthetic <= 0 and args.data_dir is None:
+        raise ValueError("give --data_dir (the reference's dataset format) or --synthetic N")
     return args
 
 

@@ -116,3 +116,34 @@ def test_dataloader_pipeline(tmp_path):
         assert b["labels"].shape == b["decoder_input_ids"].shape == b["decoder_attention_mask"].shape
         assert int((b["labels"] == tok.eos_token_id).sum()) == 4
         assert torch.equal(b["decoder_input_ids"][:, 0], torch.full((4,), tok.bos_token_id))
+
+
+def test_pretrain_cli_arguments_and_dataset_list(tmp_path):
+    """pretrain.py flag checks (reference pretrain.py:414-434) and the NAME -> dataset class mapping (:128-247)"""
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("kmb_pretrain_cli", os.path.join(ROOT, "km-bart_amd", "pretrain.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    base = ["--checkpoint_dir", str(tmp_path), "--model_config", "x.json"]
+    with pytest.raises(ValueError, match="repeated"):
+        cli.parse_args(base + ["--dataset", "coco_train", "a", "--dataset", "coco_train", "b"])
+    with pytest.raises(ValueError, match="not a valid dataset"):
+        cli.parse_args(base + ["--dataset", "imagenet", "a"])
+    with pytest.raises(ValueError, match="VG"):
+        cli.parse_args(base + ["--dataset", "vg_train", "a", "--no_image"])
+    with pytest.raises(ValueError, match="cannot be empty"):
+        cli.parse_args(["--checkpoint_dir", str(tmp_path), "--synthetic", "1"])
+    with pytest.raises(ValueError):
+        cli.parse_args(base)                                   # neither --dataset nor --synthetic
+    d = str(tmp_path)
+    write_synthetic_split(os.path.join(d, "c"), "train", n_images=2, records_per_image=1, regions=3)
+    write_synthetic_split(os.path.join(d, "r"), "val", n_images=2, records_per_image=1, regions=3, reason=True)
+    write_synthetic_vg(os.path.join(d, "g"), "train", n_images=1)
+    args = cli.parse_args(base + ["--dataset", "vg_train", os.path.join(d, "g"), "--dataset", "vcg_train",
+                                  os.path.join(d, "c"), "--dataset", "sbu_reason_val", os.path.join(d, "r"),
+                                  "--dataset", "cc_train", os.path.join(d, "c")])
+    assert args.mrm_enabled and args.ap_enabled and args.rp_enabled and args.mlm_probability == 0.2
+    kinds = [type(x).__name__ for x in cli.build_datasets(args)]
+    assert kinds == ["ReasonDataset", "VGDataset", "CCDataset", "VCGDataset"]   # the reference's fixed order
+    assert cli.build_datasets(args)[3][0]["task_type"] == TaskType.CAPTION       # vcg_train is used with pretrain=True
