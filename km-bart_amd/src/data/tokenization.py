@@ -7,7 +7,7 @@ ids (tokenization.py:36-57 appends them after the base vocabulary), so only the 
 label) go through the BPE -- in one batched call -- and the masks are known from the piece boundaries instead of
 being searched for.  The two agree id for id with a fast (Rust) BART tokenizer, which tokenizes the text between two
 markers exactly as it tokenizes that text alone; tests/test_collation_cpu.py pins this against outputs of the
-reference class itself (oracle/make_golden_collation.py).
+reference class itself.
 
 The base vocabulary is pluggable (`base_tokenizer=`): anything with the HuggingFace tokenizer call convention.
 `facebook/bart-large` is loaded when none is given and its files are on disk; offline use
