@@ -42,9 +42,18 @@ extern "C" int kmb_debug_set_stamps(void* p) {
           (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |                                      \
           ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);                               \
   } while (0)
+#define KMB_WAIT_BEGIN() const uint64_t kmb_w0 = __builtin_amdgcn_s_memrealtime()
+#define KMB_WAIT_END(acc) (acc) += __builtin_amdgcn_s_memrealtime() - kmb_w0
+#define KMB_STAMP_VALUE(i, v)                                                                          \
+  do {                                                                                                 \
+    if (g_kmb_stamps != nullptr && threadIdx.x == 0) g_kmb_stamps[(size_t)blockIdx.x * 8 + (i)] = (v); \
+  } while (0)
 #else
 #define KMB_STAMP(i)
 #define KMB_STAMP_ID()
+#define KMB_WAIT_BEGIN()
+#define KMB_WAIT_END(acc)
+#define KMB_STAMP_VALUE(i, v)
 #endif
 
 namespace {
@@ -157,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
 // heads); RES: residual add; CS: column sums) and entered through ONE uniform branch: with every option tested per
 // element inside the 8x-unrolled row loop the epilogue was ~90 KB of code walked once per tile -- instruction fetch,
 // not the stores, made it 4.4 us of a 17 us tile (in-kernel stamps, tools/gemm_stamps.py).
-template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS, int ACT, bool RES, bool CS>
+template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS, int ACT, bool RES, bool CS, bool FAST>
 __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
                                                    int col0) {
   constexpr int RPP = NT / 16;  // rows per pass
@@ -169,9 +178,10 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
   const bool cs_on = CS && (ACT >= 0 || p.colsum != nullptr);
   const int c8 = (tid & 15) * 8;
   const int gcol = col0 + c8;
-  if (gcol >= p.N && !cs_on) return;
-  const int nvalid = gcol >= p.N ? 0 : ((p.N - gcol) < 8 ? (p.N - gcol) : 8);
-  const bool full8 = nvalid == 8;
+  // FAST: the whole tile lies inside C (a workgroup-uniform fact): no per-row / per-column edge handling at all
+  if (!FAST && gcol >= p.N && !cs_on) return;
+  const int nvalid = FAST ? 8 : (gcol >= p.N ? 0 : ((p.N - gcol) < 8 ? (p.N - gcol) : 8));
+  const bool full8 = FAST || nvalid == 8;
   float csum[8], bias8[8], scale8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -187,7 +197,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
   auto gather = [&](int it, int slot) {
     const int lrow = (tid >> 4) + RPP * it;
     const int grow = row0 + lrow;
-    const bool ok = grow < p.M && full8;
+    const bool ok = FAST || (grow < p.M && full8);
     vlo[slot] = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8));
     vhi[slot] = *reinterpret_cast<const f32x4*>(ef + eoff(lrow, c8) + 4);
     if (RES) resv[slot] = (ok && res_on) ? *reinterpret_cast<const u32x4*>(p.residual + (size_t)grow * p.ld_res + gcol) : u32x4{0u, 0u, 0u, 0u};
@@ -203,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
   auto process = [&](int it0, int it) -> bool {
     const int lrow = (tid >> 4) + RPP * it0;
     const int grow = row0 + lrow;
-    if (grow >= p.M || nvalid == 0) return false;
+    if (!FAST && (grow >= p.M || nvalid == 0)) return false;
     float v[8];
     v[0] = vlo[it][0]; v[1] = vlo[it][1]; v[2] = vlo[it][2]; v[3] = vlo[it][3];
     v[4] = vhi[it][0]; v[5] = vhi[it][1]; v[6] = vhi[it][2]; v[7] = vhi[it][3];
@@ -218,7 +228,10 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
         }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      for (int e = 0; e < 8; e += 2) {
+        const kmb_f32x2 y = gelu2(kmb_f32x2{v[e], v[e + 1]});
+        v[e] = y[0]; v[e + 1] = y[1];
+      }
     } else if (AUX && (act == 2 || act == 4)) {
       float u[8];
       if (full8) {
@@ -228,7 +241,10 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
       }
       if (act == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(u[e]);
+        for (int e = 0; e < 8; e += 2) {
+          const kmb_f32x2 d = gelu_grad2(kmb_f32x2{u[e], u[e + 1]});
+          v[e] *= d[0]; v[e + 1] *= d[1];
+        }
       } else {  // tanh'(.) = 1 - y^2, aux = y
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= (1.f - u[e] * u[e]);
@@ -301,7 +317,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[(tid >> 4) * 128 + c8 + e] = csum[e];
     __syncthreads();
-    if (tid < 128 && col0 + tid < p.N) {
+    if (tid < 128 && (FAST || col0 + tid < p.N)) {
       float t = 0.f;
 #pragma unroll 8
       for (int k = 0; k < RPP; ++k) t += cs[k * 128 + tid];
@@ -309,7 +325,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
       const int prow = row0 >> 6;
       p.colsum[(size_t)prow * p.N + col0 + tid] = t;
       for (int k = 1; k < TILE_ROWS / 64; ++k)
-        if (row0 + 64 * k < p.M) p.colsum[(size_t)(prow + k) * p.N + col0 + tid] = 0.f;
+        if (FAST || row0 + 64 * k < p.M) p.colsum[(size_t)(prow + k) * p.N + col0 + tid] = 0.f;
     }
   }
 }
@@ -339,7 +355,12 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     }
     return;
   }
-#define KMB_EPI(ACT, RES, CS) gemm_epilogue_body<NT, HOIST, NIT, LD, SWZ, TILE_ROWS, ACT, RES, CS>(p, ef, cs, tid, row0, col0)
+  const bool interior = (row0 + TILE_ROWS <= p.M) && (col0 + 128 <= p.N);   // uniform per workgroup
+#define KMB_EPI(ACT, RES, CS)                                                                                     \
+  do {                                                                                                            \
+    if (interior) gemm_epilogue_body<NT, HOIST, NIT, LD, SWZ, TILE_ROWS, ACT, RES, CS, true>(p, ef, cs, tid, row0, col0);  \
+    else gemm_epilogue_body<NT, HOIST, NIT, LD, SWZ, TILE_ROWS, ACT, RES, CS, false>(p, ef, cs, tid, row0, col0);          \
+  } while (0)
   const bool res = p.residual != nullptr, csf = p.colsum != nullptr;
   if (p.act == 0) {
     if (!res && !csf) KMB_EPI(0, false, false);
@@ -353,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
     else KMB_EPI(2, false, false);
   } else {
     // everything else (tanh heads, rare combinations): run-time act, non-hoisted compact loop
-    gemm_epilogue_body<NT, false, NIT, LD, SWZ, TILE_ROWS, -1, true, true>(p, ef, cs, tid, row0, col0);
+    gemm_epilogue_body<NT, false, NIT, LD, SWZ, TILE_ROWS, -1, true, true, false>(p, ef, cs, tid, row0, col0);
   }
 #undef KMB_EPI
 }
@@ -729,6 +750,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
   constexpr int NDA = A_KC ? 4 : 8;  // ds_read instructions per 4 A fragments / per 4 B fragments
   constexpr int NDB = B_KC ? 4 : 8;
   bf16x8 fa[2][4], fb[2][4];
+  [[maybe_unused]] uint64_t kmb_wait_ticks = 0;  // diagnostic build only
   auto read_a = [&](const char* stage, int kk, int half, bf16x8 (&dst)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * 8 + half * 4 + i, kk, r, g);
@@ -786,8 +808,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
     __builtin_amdgcn_sched_group_barrier(0x100, NDA, 2);
     __builtin_amdgcn_sched_group_barrier(0x008, 12, 2);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage t+1 landed, this wave is done reading stage t
-    __builtin_amdgcn_s_barrier();
+    {
+      KMB_WAIT_BEGIN();
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage t+1 landed, this wave is done reading stage t
+      __builtin_amdgcn_s_barrier();
+      KMB_WAIT_END(kmb_wait_ticks);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- sub-phase 3 ----
     if (decltype(do_next)::value) {
@@ -817,6 +843,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
   kstep(t, No{}, No{});
   __syncthreads();
   KMB_STAMP(2);
+  KMB_STAMP_VALUE(5, kmb_wait_ticks);
   // epilogue: two passes over the column halves; in pass h the waves with (wn >> 1) == h stage their accumulators
   float* ef = reinterpret_cast<float*>(smem);
   for (int h = 0; h < 2; ++h) {
@@ -844,7 +871,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 // transposed-block MFMA with a register epilogue and 8-byte stores (-20 %), several tiles per workgroup with the
 // next tile's first K step prefetched under the epilogue (-5..30 %), and the un-pipelined forms of v7 / v8 (their K
 // loops were 3-25 % slower).  A start-time phase stagger between co-resident workgroups / between CUs was also
-// measured (stamps: the K loop gets shorter, the epilogue longer, the tile time does not move) and dropped.
+// measured (stamps: the K loop gets shorter, the epilogue longer, the tile time does not move) and dropped, and so was
+// a four-deep ring of 32-wide K stages for the 256x256 tile (DMA issued three steps ahead): bit-identical, same speed
+// -- the time a wave spends at v8's per-step barrier is its SIMD partner's turn on the matrix pipe, not DMA latency;
+// the 256x256 K loop already runs at ~1.36 GHz-equivalent of back-to-back MFMA issue (4096^3: 1.29 PFLOP/s).
 // What did pay: LDS-DMA staging, the software-pipelined K loop, one uniform branch into a class-specialised epilogue
 // (instruction fetch, not the stores, bounded the generic one), hoisted epilogue loads, hardware bf16 conversion,
 // split-K for the weight gradients, per-shape choice between the 128x128 and 256x256 tiles and the XCD tile order.

@@ -79,7 +79,7 @@ def build_loader(args, rank, device):
     collate = Collator(tokenizer, mlm_enabled=True, mlm_probability=args.mlm_probability,
                        mrm_enabled=args.mrm_enabled, mrm_probability=args.mrm_probability, ap_enabled=args.ap_enabled,
                        rp_enabled=args.rp_enabled, lm_max_len=args.lm_max_len, max_img_num=args.max_img_num,
-                       pin_memory=True)
+                       pin_memory=args.num_workers == 0)   # worker processes must not touch the GPU runtime
     dataset = ConcatDataset(build_datasets(args))
     sampler = DistributedSampler(dataset, num_replicas=args.gpu_num, rank=rank)
     loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,

@@ -50,7 +50,7 @@ def main(args):
         dataset = VCGDataset(args.data_dir, split=args.split, use_image=args.use_image, use_event=args.use_event,
                              eval_mode=True)
         loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
-                            collate_fn=Collator(tokenizer, has_label=False, pin_memory=True))
+                            collate_fn=Collator(tokenizer, has_label=False, pin_memory=args.num_workers == 0))
     generated = generate_text(model, loader, tokenizer, args, device, logger=logger)
     with open(args.output_file, "w") as f:
         json.dump(generated, f)

@@ -57,7 +57,7 @@ def build_vcg_loader(args, rank, device):
     dataset = VCGDataset(args.data_dir, split="train", use_image=args.use_image, use_event=args.use_event)
     sampler = DistributedSampler(dataset, num_replicas=args.gpu_num, rank=rank)
     loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
-                        sampler=sampler, collate_fn=Collator(tokenizer, has_label=True, pin_memory=True))
+                        sampler=sampler, collate_fn=Collator(tokenizer, has_label=True, pin_memory=args.num_workers == 0))
     return DevicePrefetcher(loader, device)
 
 

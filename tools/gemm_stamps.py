@@ -72,6 +72,9 @@ def main():
     print(f"M={M} N={N} K={K} akc={int(akc)} bkc={int(bkc)} tiles={tiles} kernel span {(s[:, 4].max() - t0) * tick:.1f} us")
     for k, v in ph.items():
         print(f"  {k:11s} median {np.median(v):6.2f}  p10 {np.percentile(v, 10):6.2f}  p90 {np.percentile(v, 90):6.2f} us")
+    if s[:, 5].any():
+        w = s[:, 5] * tick
+        print(f"  wave 0 parked at the K-loop wait+barrier: median {np.median(w):6.2f}  p10 {np.percentile(w, 10):6.2f}  p90 {np.percentile(w, 90):6.2f} us")
     hw = s[:, 7] & 0xFFFFFFFF
     xcc = (s[:, 7] >> 32) & 0xF
     cu = (hw >> 8) & 0xF
