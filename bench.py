@@ -129,8 +129,13 @@ def main():
     torch.set_num_threads(usable_cores())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # KMB_BENCH_FORCE_DIST=1: take the multi-GPU code path (process group, bucketed RCCL all-reduce on the side stream,
+    # barrier + MAX over ranks) with ONE rank -- the only way to run that path on a one-GPU box
+    force_dist = os.environ.get("KMB_BENCH_FORCE_DIST", "0") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from kmbart import _lib
@@ -145,7 +150,7 @@ def main():
     model._engine.set_seed(1234 + rank)
     if args.serial:
         _lib.load().kmb_set_side_stream(model._engine.h, 0)
-    ddp = DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    ddp = DistributedDataParallel(model, device_ids=[local], reduce_single_rank=force_dist) if use_dist else model
     ddp.train()
     opt = AdamW(model.parameters(), lr=args.lr)
 
@@ -165,7 +170,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +182,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -273,7 +278,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,8 +24,10 @@ class BucketedAllReducer:
     (HIP event on the GPU path; None on the CPU/gloo test path where backward has already finished).
     """
 
-    def __init__(self, flat, buckets, process_group=None, wait_ready=None, comm_stream=None, max_bucket_elems=None):
+    def __init__(self, flat, buckets, process_group=None, wait_ready=None, comm_stream=None, max_bucket_elems=None,
+                 always=False):
         self.flat = flat
+        self.always = always   # issue the collectives even in a one-rank group (single-GPU test of the RCCL path)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.wait_ready = wait_ready
@@ -44,7 +46,7 @@ class BucketedAllReducer:
         self._works = []
 
     def launch(self):
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         use_avg = self.backend == "nccl"
         op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
@@ -84,14 +86,14 @@ class _Null:
 
 class DistributedDataParallel(torch.nn.Module):
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None,
-                 max_bucket_mb=64):
+                 max_bucket_mb=64, reduce_single_rank=False):
         super().__init__()
         self.__dict__["module"] = module  # not a registered child: parameters() must not be re-wrapped
         eng = module._need_engine()
         self.engine = eng
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None
-        if self.world > 1:
+        if self.world > 1 or (reduce_single_rank and dist.is_initialized()):
             # C2: parameters and the logits-bias buffer start identical on every rank
             dist.broadcast(eng.params, src=0, group=process_group)
             dist.broadcast(eng.final_logits_bias, src=0, group=process_group)
@@ -100,7 +102,7 @@ class DistributedDataParallel(torch.nn.Module):
             self.reducer = BucketedAllReducer(
                 eng.grads, eng.buckets(), process_group,
                 wait_ready=lambda i, stream: eng.stream_wait_bucket(i, stream), comm_stream=comm,
-                max_bucket_elems=max_bucket_mb * (1 << 20) // 4)
+                max_bucket_elems=max_bucket_mb * (1 << 20) // 4, always=reduce_single_rank)
             module._post_backward = self._reduce
 
     def _reduce(self):

@@ -1,0 +1,69 @@
+"""The data-parallel gradient path on the real RCCL backend.  The box has ONE GPU, so the group
+has one rank -- the arithmetic is the identity -- but everything else is the production path: parameter broadcast,
+per-bucket HIP events recorded inside kmb_backward, the communication stream waiting on them, `nccl` all-reduce (AVG)
+of every bucket of the flat gradient arena, the compute stream waiting for the collectives before AdamW.  The
+world_size-2 arithmetic is covered on gloo (tests/test_dp_gloo_cpu.py)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "km-bart_amd"), os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_rccl_reducer_matches_plain_step():
+    from oracle import goldenlib as G
+    from oracle.make_golden import tiny_batch
+    from kmbart.optim import AdamW
+    from kmbart.parallel import DistributedDataParallel
+    from test_model_gpu import build
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29533"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ocfg = G.tiny_config(dropout=0.0)
+        sd = G.golden_state_dict(ocfg, seed=7)
+        b = tiny_batch()
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+        batch["image_features"] = [f.to(dev) for f in b["image_features"]]
+
+        def run(wrap):
+            model = build(ocfg, sd).train()
+            ddp = DistributedDataParallel(model, device_ids=[0], reduce_single_rank=True) if wrap else model
+            opt = AdamW(model.parameters(), lr=1e-3)
+            losses, grads = [], None
+            for i in range(3):
+                losses.append(float(ddp.train_step_fwd_bwd(batch)))
+                if i == 0:
+                    torch.cuda.synchronize()
+                    grads = model._engine.grads.clone()
+                opt.step()
+            torch.cuda.synchronize()
+            if wrap:
+                assert ddp.reducer is not None and len(ddp.reducer.pieces) >= len(model._engine.buckets())
+                assert ddp.module is model
+            return losses, grads, model._engine
+
+        plain_losses, plain_grads, eng = run(False)
+        rccl_losses, rccl_grads, _ = run(True)
+        # AVG over one rank is the identity: every gradient slice comes back bit for bit -- except the tied embedding
+        # matrix, whose token-gradient scatter uses fp32 atomics and differs run to run in the last bit either way
+        off, rows, cols = eng.index["model.shared.weight"]
+        same = plain_grads == rccl_grads
+        same[off: off + rows * cols] = True
+        assert bool(same.all())
+        assert torch.allclose(plain_grads[off: off + rows * cols], rccl_grads[off: off + rows * cols], rtol=0, atol=1e-6)
+        for a, b_ in zip(plain_losses, rccl_losses):
+            assert abs(a - b_) <= 1e-4 * abs(a)
+    finally:
+        dist.destroy_process_group()
