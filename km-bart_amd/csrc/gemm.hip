@@ -955,7 +955,19 @@ bool writes_an_input(const KmbGemm& p) {
 // speed: the first launch of a new shape times the eligible variants on the real operands (measure, don't guess).
 hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   static int forced = -1, autotune = 1, verbose = 0;
+  static const char* tune_file = nullptr;   // KMB_GEMM_TUNE_FILE: choices are appended here and preloaded from here, so a
+                                            // profiled run (rocprofv3 --pmc) contains no tuning launches
   if (forced < 0) {
+    tune_file = getenv("KMB_GEMM_TUNE_FILE");
+    if (tune_file) {
+      if (FILE* f = fopen(tune_file, "r")) {
+        TuneKey k;
+        int best;
+        while (fscanf(f, "%d %d %d %d %d %d %d %d", &k.akc, &k.bkc, &k.M, &k.N, &k.K, &k.split, &k.act, &best) == 8)
+          g_best[k] = best;
+        fclose(f);
+      }
+    }
     const char* ev = getenv("KMB_GEMM_VARIANT");
     forced = ev ? atoi(ev) : 0;
     const char* ea = getenv("KMB_GEMM_AUTOTUNE");
@@ -1008,6 +1020,12 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     it = g_best.emplace(key, best).first;
+    if (tune_file) {
+      if (FILE* f = fopen(tune_file, "a")) {
+        fprintf(f, "%d %d %d %d %d %d %d %d\n", key.akc, key.bkc, key.M, key.N, key.K, key.split, key.act, best);
+        fclose(f);
+      }
+    }
   }
   KmbGemm q = p;
   q.tile_order = it->second >> 4;

@@ -82,8 +82,18 @@ class DevicePrefetcher:
         except StopIteration:
             return
         while nxt is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self.stream)
             cur = nxt
+            # the tensors were allocated on the copy stream: tell the caching allocator that the compute stream uses
+            # them too, or their memory is handed to the NEXT staging copy while kernels of this step still read it
+            # (seen as HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION at batch 512: offsets overwritten by features)
+            for v in cur.values():
+                if isinstance(v, PackedFeatures):
+                    v.packed.record_stream(main)
+                    v.offsets.record_stream(main)
+                elif torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
             try:
                 nxt = self._stage(next(it))
             except StopIteration:

@@ -1,8 +1,21 @@
-# Evidence run for profiles/: default bench JSON, rocprofv3 kernel stats of the product configuration, and a --serial
-# trace (weight-gradient GEMMs not overlapped) for stand-alone kernel durations.  Run through gpurun from the repo root.
+# Evidence run for profiles/ (run through gpurun from the repo root):
+#   1. default bench (JSON line incl. roofline + cpu_baseline); writes the GEMM tuning choices to a file
+#   2. rocprofv3 --kernel-trace --stats of the product configuration (tuning preloaded: no tuning launches)
+#   3. the same with --serial (weight-gradient GEMMs not overlapped): stand-alone kernel durations
+#   4. two PMC passes (FETCH_SIZE, WRITE_SIZE; --pmc with --kernel-trace only) for HBM traffic per launch
+#   5. per-shape GEMM table, generation benchmark
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 500 python bench.py > gpurun_out/r2_bench_default.log 2> gpurun_out/r2_bench_default.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2 -o r2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-pcie > gpurun_out/r2_prof.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2s -o r2s -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-pcie --serial > gpurun_out/r2s_prof.log 2>&1
-tail -2 gpurun_out/r2_bench_default.log
+export KMB_GEMM_TUNE_FILE=$GRAFT_REPO_ROOT/gpurun_out/gemm_tune.txt
+rm -f $KMB_GEMM_TUNE_FILE
+timeout 600 python bench.py > gpurun_out/r3_bench_default.log 2> gpurun_out/r3_bench_default.err
+B="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-pcie"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r3 -o r3 -- $B > gpurun_out/r3_prof.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r3s -o r3s -- $B --serial > gpurun_out/r3s_prof.log 2>&1
+P="python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-pcie --serial"
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- $P > gpurun_out/r3_pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- $P > gpurun_out/r3_pmc_write.log 2>&1
+timeout 300 python tools/gemm_shape_table.py 512 2>&1 | grep -v amdgpu > gpurun_out/r3_gemm_shapes_b512.txt
+timeout 300 python tools/gen_bench.py 2>&1 | grep -v amdgpu > gpurun_out/r3_gen_bench.log
+tail -1 gpurun_out/r3_bench_default.log | cut -c1-300
+ls gpurun_out/pmc_fetch gpurun_out/pmc_write
