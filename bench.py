@@ -256,15 +256,37 @@ def main():
                 a[0] += n.value
                 a[1] += ms.value
                 a[2] += fl.value
+            if _ == n_prof - 1:   # minimal bytes of the same launches: A and B read once, C written once
+                import tempfile
+                dump = os.path.join(tempfile.gettempdir(), "kmb_gemm_launches_%d.txt" % os.getpid())
+                _lib.check(lib.kmb_profile_dump(dump.encode()))
+                alg_bytes, alg_n = 0.0, 0
+                for line in open(dump):
+                    v, M, N, K, sp, act, us = line.split()
+                    v, M, N, K, act = int(v), int(M), int(N), int(K), int(act)
+                    out_b = 4 if (v == 0 or N >= 50000) else 2          # weight gradients and logits are fp32
+                    extra = M * N * 2 if act in (1, 2) else 0            # pre-activation written / read (GeLU, GeLU')
+                    alg_bytes += 2.0 * (M * K + N * K) + out_b * M * N + extra
+                    alg_n += 1
+                os.remove(dump)
             lib.kmb_profile_gemm(0)
         lib.kmb_set_side_stream(model._engine.h, 1)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):   # HBM bytes come from rocprofv3 --pmc passes of this workload (tools/r2_profile.sh)
+            rec = json.load(open(pmc))
+            if rec.get("per_gpu_batch") == args.batch:
+                traffic = rec["gemm_hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_traffic.json: " + rec["method"]
         tot_ms = sum(a[1] for a in agg.values())
         tot_fl = sum(a[2] for a in agg.values())
         launches = sum(a[0] for a in agg.values())
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per GEMM launch",
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_n, 1)),
             "kernel": "gemm_kernel_v7/v8<A_KC,B_KC> (all GEMM launches of a step, timed serially)",
             "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
             "gemm_ms_per_step": round(tot_ms / n_prof, 3),

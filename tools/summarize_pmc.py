@@ -1,10 +1,12 @@
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), gfx950 corrections applied
 (MI355X_MICROARCH.md section HBM: counters are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x).
 
-    python tools/summarize_pmc.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
+    python tools/summarize_pmc.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv \
+        [--json profiles/r01_pmc_traffic.json --batch 512]
 """
 import collections
 import csv
+import json
 import sys
 
 
@@ -37,3 +39,16 @@ for tot, k, n, fe, wr in sorted(rows, reverse=True)[:16]:
         gemm_bytes += tot
         gemm_n += n
 print(f"\nGEMM kernels: {gemm_n} launches, {gemm_bytes / max(gemm_n, 1):.1f} MB of HBM traffic per launch on average")
+
+if "--json" in sys.argv:
+    out = sys.argv[sys.argv.index("--json") + 1]
+    batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else None
+    json.dump({"per_gpu_batch": batch, "gemm_launches": gemm_n,
+               "gemm_hbm_bytes_per_launch": round(gemm_bytes / max(gemm_n, 1) * 1e6),
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (each with --kernel-trace "
+                         "only) over `bench.py --steps 2 --warmup 2 --serial` with the GEMM tuning preloaded; counters "
+                         "in KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md "
+                         "section HBM); calibration: adamw_kernel measures 4231 MB = 141.04 M params x 30 B exactly",
+               "kernels": {k: {"launches": n, "fetch_mb": round(fe, 1), "write_mb": round(wr, 1)}
+                           for _, k, n, fe, wr in sorted(rows, reverse=True)[:16]}},
+              open(out, "w"), indent=1)
