@@ -44,8 +44,9 @@ class SyntheticLoader:
             yield b
 
 
-def build_vcg_loader(args, rank, device):
-    """VCGDataset -> DistributedSampler -> DataLoader(Collator) -> DevicePrefetcher (vcg_train.py:115-142)"""
+def build_vcg_loader(args, rank, device, split="train"):
+    """VCGDataset -> DistributedSampler -> DataLoader(Collator) -> DevicePrefetcher (vcg_train.py:115-142); the
+    validation split is not sharded (vcg_train.py:144-160: rank 0 validates alone)"""
     from torch.utils.data import DataLoader
     from torch.utils.data.distributed import DistributedSampler
     from src.data.collation import Collator
@@ -54,8 +55,8 @@ def build_vcg_loader(args, rank, device):
     from src.data.tokenization import ConditionTokenizer
     base = load_base_tokenizer(args.tokenizer_json or "facebook/bart-large")
     tokenizer = ConditionTokenizer(base_tokenizer=base)
-    dataset = VCGDataset(args.data_dir, split="train", use_image=args.use_image, use_event=args.use_event)
-    sampler = DistributedSampler(dataset, num_replicas=args.gpu_num, rank=rank)
+    dataset = VCGDataset(args.data_dir, split=split, use_image=args.use_image, use_event=args.use_event)
+    sampler = DistributedSampler(dataset, num_replicas=args.gpu_num, rank=rank) if split == "train" else None
     loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
                         sampler=sampler, collate_fn=Collator(tokenizer, has_label=True, pin_memory=args.num_workers == 0))
     return DevicePrefetcher(loader, device)
@@ -97,6 +98,10 @@ def main(rank, args):
         fine_tune(epoch, model, loader, optimizer, device, args, logger=logger, log_interval=args.log_interval)
         if rank == 0:
             inner = model.module if distributed else model
+            if args.validate_loss and args.synthetic <= 0:
+                from src.validation import validate_fine_tune_loss
+                validate_fine_tune_loss(epoch, inner, build_vcg_loader(args, rank, device, split="val"), device, args,
+                                        logger=logger, log_interval=args.log_interval)
             out = os.path.join(args.checkpoint_dir, "epoch{}".format(epoch + 1))
             inner.save_pretrained(out)
             save_training_data(out, optimizer=optimizer, epoch=epoch)

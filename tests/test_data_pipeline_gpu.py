@@ -64,6 +64,12 @@ def test_fine_tune_from_files(tmp_path):
                     attention_mask=b["attention_mask"].to(DEV), decoder_input_ids=b["decoder_input_ids"].to(DEV),
                     decoder_attention_mask=b["decoder_attention_mask"].to(DEV), labels=b["labels"].to(DEV))[0]
         assert abs(float(got) - float(ref)) <= 2e-3 * abs(float(ref)), (float(got), float(ref))
+    # validation loop (reference src/validation.py:62-121): mean of the per-batch losses, eval mode
+    from src.validation import validate_fine_tune_loss
+    refs = [float(O.forward(sd, ocfg, b["input_ids"], b["image_features"].as_list(), b["attention_mask"],
+                            b["decoder_input_ids"], b["decoder_attention_mask"], b["labels"])[0]) for b in batches]
+    val = validate_fine_tune_loss(0, model, loader, DEV, types.SimpleNamespace(amp=False))
+    assert abs(val - sum(refs) / len(refs)) <= 2e-3 * abs(val)
     # the training loop over the prefetcher (copies of batch i+1 overlap step i)
     args = types.SimpleNamespace(epochs=1, amp=False)
     model.train()
