@@ -1,0 +1,63 @@
+"""Multi-task pre-training throughput (BASELINE.json config 4): pretrain_base-shaped model (= vcg_base + MRM / attribute /
+relation heads, reference config/pretrain_base.json), synthetic batches with 50 regions, 80 encoder / 48 decoder tokens,
+MRM probability 0.2.  A step = forward of all four losses + backward + fused AdamW.  Prints one JSON line.
+
+    python tools/pretrain_bench.py [--batch 256] [--steps 10] [--warmup 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "km-bart_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+from kmbart.optim import AdamW  # noqa: E402
+from src.data.synthetic import make_pretrain_batch  # noqa: E402
+from src.model import MultiModalBartConfig, MultiModalBartForPreTraining  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=3)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+cfg = MultiModalBartConfig.from_dict(dict(bench.VCG_BASE, num_labels=1601, num_attributes=129, num_relations=129))
+model = MultiModalBartForPreTraining(cfg).to(dev).train()
+opt = AdamW(model.parameters(), lr=1e-5)
+S, T, R = 80, 48, 50
+b = make_pretrain_batch(args.batch, enc_len=S, dec_len=T, num_regions=R, seed=1234)
+dv = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+dv["image_features"] = [f.to(dev) for f in b["image_features"]]
+dv["mrm_labels"] = [t.to(dev) for t in b["mrm_labels"]]
+dv["attribute_labels"] = [t.to(dev) for t in b["attribute_labels"]]
+keys = ("input_ids", "image_features", "attention_mask", "decoder_input_ids", "decoder_attention_mask", "labels",
+        "mrm_labels", "mrm_mask", "attribute_labels", "attribute_mask", "relation_labels")
+
+
+def step():
+    losses = model(**{k: dv[k] for k in keys})[0]
+    losses["loss"].backward()
+    opt.step()
+    return losses
+
+
+for _ in range(args.warmup):
+    losses = step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    losses = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+tok = args.batch * (S + T)
+print(json.dumps({"metric": "pretrain_tokens_per_sec", "value": round(tok / dt, 1), "unit": "tokens/s",
+                  "ms_per_step": round(dt * 1e3, 3), "samples_per_sec": round(args.batch / dt, 1),
+                  "config": {"workload": "pretrain_base multitask step (LM + MRM + attribute + relation), synthetic, "
+                                         "%d regions, %d enc / %d dec tokens" % (R, S, T), "per_gpu_batch": args.batch},
+                  "losses": {k: round(float(v), 4) for k, v in losses.items()}, "dtype": "bf16", "data": "synthetic",
+                  "n_gpus": 1}))
