@@ -380,8 +380,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const KmbAttnDecode p)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float acc = 0.f;
-  for (int t = 0; t < p.Tk; ++t) acc += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
+  // four independent partial sums, eight value rows in flight: a single dependent chain over Tk rows made this
+  // launch-sized kernel latency-bound (21 us for 64 keys)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int t = 0;
+#pragma unroll 2
+  for (; t + 4 <= p.Tk; t += 4) {
+    a0 += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
+    a1 += sc[t + 1] * bf2f(Vc[(size_t)(t + 1) * HDm + lane]);
+    a2 += sc[t + 2] * bf2f(Vc[(size_t)(t + 2) * HDm + lane]);
+    a3 += sc[t + 3] * bf2f(Vc[(size_t)(t + 3) * HDm + lane]);
+  }
+  for (; t < p.Tk; ++t) a0 += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
+  const float acc = (a0 + a1) + (a2 + a3);
   p.O[(size_t)row * p.ldo + h * HD + lane] = f2bf(acc * inv);
 }
 

@@ -866,6 +866,137 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Narrow tile for the generation path.  A decode step multiplies M = batch x beams rows (320 at the benchmark
+// setting) by every weight matrix: with 128x128 tiles that is 18-72 workgroups on 256 CUs and each launch costs a
+// full tile latency (23 us measured, 56 GFLOP/step at 67 TFLOP/s).  Here a workgroup takes a 128 x 32 slice
+// (72-288 workgroups for the same layers), four waves of 32 x 32, a four-deep LDS-DMA ring, same LDS images / swizzles /
+// accumulation order as v7 (bit-identical results).  Forward layout only (X . W^T), epilogue = bias, q-scale, GeLU,
+// residual, bf16 / fp32 store; everything else stays on v7.
+constexpr int BNS = 32;
+constexpr int STAGE_S = (BM + BNS) * BK * 2;            // 20 KiB
+constexpr int EPI_LD_S = 36;                            // fp32 staging row stride (32 + 4: conflict-free b128 reads)
+constexpr int NST_S = 4;                                // ring depth: three stages in flight (the K loop is pure latency)
+constexpr int LDS_S = NST_S * STAGE_S;                  // 80 KiB: two workgroups per CU
+static_assert(LDS_S >= BM * EPI_LD_S * 4, "epilogue staging must fit");
+
+__global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int tiles_n = (p.N + BNS - 1) / BNS;
+  const int tm = (int)blockIdx.x / tiles_n, tn = (int)blockIdx.x % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BNS;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / BK;
+  uint32_t offA[4], offB;
+  dma_offsets<true>(offA, p.lda, row0, p.M, wave, lane);
+  {  // B: 32 rows x 128 B = 4 pieces, one per wave (rows 8 * wave ...), same swizzle as the 128-row image
+    const int row = wave * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int grow = col0 + row;
+    grow = grow < p.N ? grow : p.N - 1;
+    offB = (uint32_t)(((grow - col0) * p.ldb + c * 8) * 2);
+  }
+  const char* gA = reinterpret_cast<const char*>(p.A) + (size_t)row0 * p.lda * 2;
+  const char* gB = reinterpret_cast<const char*>(p.B) + (size_t)col0 * p.ldb * 2;
+  constexpr int A_TILE = BM * BK * 2;
+  auto dma_stage = [&](int ks, int buf) {
+    char* da = smem + buf * STAGE_S + wave * 4096;
+    char* db = smem + buf * STAGE_S + A_TILE + wave * 1024;
+    const char* ga = gA + (size_t)ks * (BK * 2);
+    const char* gb = gB + (size_t)ks * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(ga, offA[i], da + i * 1024);
+    dma_piece(gb, offB, db);
+  };
+  for (int ks = 0; ks < NST_S - 1 && ks < nt; ++ks) dma_stage(ks, ks);
+  for (int t = 0; t < nt; ++t) {
+    // stage t has landed when at most the (<= 2) younger stages' pieces (5 per stage and wave) are still in flight
+    const int younger = (nt - 1 - t) < (NST_S - 2) ? (nt - 1 - t) : (NST_S - 2);
+    if (younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // also: every wave is done with the buffer the next DMA overwrites (read in step t - 1)
+    if (t + NST_S - 1 < nt) dma_stage(t + NST_S - 1, (t + NST_S - 1) & (NST_S - 1));
+    const char* cur = smem + (t & (NST_S - 1)) * STAGE_S;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = read_frag<true>(cur, wave * 2 + i, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag<true>(cur + A_TILE, j, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // ---- epilogue: accumulators -> fp32 LDS [128][36] -> row-major math, 16-byte stores (4 lanes per row) ----
+  float* ef = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ef[(wave * 32 + i * 16 + g * 4 + q) * EPI_LD_S + j * 16 + r] = acc[i][j][q];
+  __syncthreads();
+  const int c8 = (tid & 3) * 8;
+  const int gcol = col0 + c8;
+  if (gcol >= p.N) return;
+  const int nvalid = (p.N - gcol) < 8 ? (p.N - gcol) : 8;
+  float bias8[8], scale8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias8[e] = (p.bias != nullptr && e < nvalid) ? p.bias[gcol + e] : 0.f;
+    scale8[e] = (gcol + e < p.col_scale_n) ? p.col_scale : 1.0f;
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int lrow = (tid >> 2) + 64 * it;
+    const int grow = row0 + lrow;
+    if (grow >= p.M) break;
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD_S + c8);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD_S + c8 + 4);
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * scale8[e];
+    if (p.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const kmb_f32x2 y = gelu2(kmb_f32x2{v[e], v[e + 1]});
+        v[e] = y[0]; v[e + 1] = y[1];
+      }
+    }
+    if (p.residual != nullptr) {
+      for (int e = 0; e < nvalid; ++e) v[e] += bf2f(p.residual[(size_t)grow * p.ld_res + gcol + e]);
+    }
+    if (p.out_bf16 != nullptr) {
+      if (nvalid == 8) {
+        *reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol) = pack8(v);
+      } else {
+        for (int e = 0; e < nvalid; ++e) p.out_bf16[(size_t)grow * p.ld_out_bf16 + gcol + e] = f2bf(v[e]);
+      }
+    }
+    if (p.out_f32 != nullptr) {
+      float* o = p.out_f32 + (size_t)grow * p.ld_out_f32 + gcol;
+      for (int e = 0; e < nvalid; ++e) o[e] = v[e] + (p.beta != 0.f ? p.beta * o[e] : 0.f);
+    }
+  }
+}
+
+
 // Variants that were built, verified bit-identical and then REMOVED because they measured slower on every training
 // shape (MI355X, b=256): a 256x128 three-stage ring with counted vmcnt (one workgroup per CU: -10..25 %), a
 // transposed-block MFMA with a register epilogue and 8-byte stores (-20 %), several tiles per workgroup with the
@@ -986,6 +1117,22 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   const bool dma_ok = (p.K % BK) == 0;           // LDS-DMA variants have no K-edge zero fill
   const bool big = dma_ok && p.M > 128;
   if (!dma_ok) return launch_variant(1, p, stream);
+  // generation path: few rows, forward layout, plain epilogue -> narrow tiles (more, shorter workgroups)
+  {
+    static int narrow_ok = -1;
+    if (narrow_ok < 0) {
+      const char* e = getenv("KMB_GEMM_NARROW");
+      narrow_ok = !(e && e[0] == '0');
+      (void)hipFuncSetAttribute((const void*)gemm_kernel_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
+    }
+    const int tiles128 = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (narrow_ok && !forced && p.a_kc && p.b_kc && p.M <= 512 && tiles128 < 128 && p.split_k <= 1 && p.act <= 1 &&
+        p.preact == nullptr && p.colsum == nullptr && p.drop_thr16 == 0u && (p.act == 0 || p.aux == nullptr)) {
+      dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BNS - 1) / BNS)), block(256);
+      hipLaunchKernelGGL(gemm_kernel_narrow, grid, block, LDS_S, stream, p);
+      return hipGetLastError();
+    }
+  }
   if (forced) {
     int v = forced;
     if (v == 8 && !(big && p.N > 128)) v = 7;
