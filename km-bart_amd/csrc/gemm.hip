@@ -1006,6 +1006,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
 // a four-deep ring of 32-wide K stages for the 256x256 tile (DMA issued three steps ahead): bit-identical, same speed
 // -- so DMA latency is not what parks v8's waves at the per-step barrier.  4096^3 runs at 1.29 PFLOP/s, within 3 % of
 // the CDNA4 guide's 8-phase 256^2 template (1.32-1.34 on random operands).
+// A register epilogue without LDS staging was built too: MFMA operands swapped so that a lane holds four consecutive
+// columns (C^T blocks), one v_permlane16_swap_b32 per dword between neighbouring column blocks to make that eight
+// (tools/permlane_probe.hip; note hipcc folds four __builtin_amdgcn_permlane16_swap of a vector's elements into one
+// -- inline asm is required), math and 16-byte stores straight from registers.  Bit-identical, v7 +-0 %, v8 -13 %:
+// the staging round trip is not what the epilogue waits for.  Removed again.
 // What did pay: LDS-DMA staging, the software-pipelined K loop, one uniform branch into a class-specialised epilogue
 // (instruction fetch, not the stores, bounded the generic one), hoisted epilogue loads, hardware bf16 conversion,
 // split-K for the weight gradients, per-shape choice between the 128x128 and 256x256 tiles and the XCD tile order.
