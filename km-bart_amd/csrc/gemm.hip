@@ -1010,7 +1010,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
 // columns (C^T blocks), one v_permlane16_swap_b32 per dword between neighbouring column blocks to make that eight
 // (tools/permlane_probe.hip; note hipcc folds four __builtin_amdgcn_permlane16_swap of a vector's elements into one
 // -- inline asm is required), math and 16-byte stores straight from registers.  Bit-identical, v7 +-0 %, v8 -13 %:
-// the staging round trip is not what the epilogue waits for.  Removed again.
+// the staging round trip is not what the epilogue waits for.  With that epilogue the stage buffers are free during it,
+// so a PERSISTENT v7 was built as well (a workgroup walks tiles b, b + 512, ...; the next tile's first two stages are
+// requested before the epilogue starts, hiding the 2.4 us prologue wait): bit-identical, 0..-20 % -- slower, not
+// faster.  Time per tile round stays ~15 us however the phases are arranged; tools/gemm_ksweep.py puts it as
+// T(K) = 25 us + K / (1.13 PFLOP/s-equivalent) for (16384, 3072, K).  Both removed again.
 // What did pay: LDS-DMA staging, the software-pipelined K loop, one uniform branch into a class-specialised epilogue
 // (instruction fetch, not the stores, bounded the generic one), hoisted epilogue loads, hardware bf16 conversion,
 // split-K for the weight gradients, per-shape choice between the 128x128 and 256x256 tiles and the XCD tile order.
