@@ -1,0 +1,119 @@
+"""vcg_base at full size on the GPU: properties that hold whatever the numbers are (the CPU oracle cannot run these
+batch sizes in test time): batch-mean consistency, duplicate-batch gradient invariance, linearity of the loss in the
+labels mask, generation modes.  Complements the oracle comparisons at b=2 / tiny sizes in test_model_gpu.py."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "km-bart_amd"), os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def model():
+    import bench
+    from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration
+    torch.manual_seed(0)
+    m = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(dict(bench.VCG_BASE, dropout=0.0)))
+    return m.to(DEV)
+
+
+def _dev(b, rows=None):
+    sel = (lambda t: t if rows is None else t[rows])
+    out = {k: sel(v).to(DEV) for k, v in b.items() if torch.is_tensor(v)}
+    feats = b["image_features"] if rows is None else [b["image_features"][i] for i in rows]
+    out["image_features"] = [f.to(DEV) for f in feats]
+    return out
+
+
+def _loss(model, d):
+    return model(input_ids=d["input_ids"], image_features=d["image_features"], attention_mask=d["attention_mask"],
+                 decoder_input_ids=d["decoder_input_ids"], decoder_attention_mask=d["decoder_attention_mask"],
+                 labels=d["labels"])[0]
+
+
+def test_batch_loss_is_the_token_weighted_mean_of_sample_losses(model):
+    """CrossEntropyLoss(mean over labels != -100) of a batch == sum_i n_i loss_i / sum_i n_i (model.py:400-402), with
+    ragged region counts / event lengths / label lengths so every sample has a different n_i."""
+    from src.data.synthetic import make_batch
+    model.eval()
+    regions, ev, lab = [36, 20, 0, 7, 36, 1, 30, 12], [23, 7, 30, 1, 15, 23, 9, 4], [32, 5, 17, 2, 32, 9, 1, 25]
+    b = make_batch(8, seed=11, regions=regions, event_lens=ev, label_lens=lab)
+    with torch.no_grad():
+        whole = float(_loss(model, _dev(b)))
+        parts = [float(_loss(model, _dev(b, [i]))) for i in range(8)]
+    n = [(b["labels"][i] != -100).sum().item() for i in range(8)]
+    expect = sum(p * k for p, k in zip(parts, n)) / sum(n)
+    assert abs(whole - expect) <= 2e-4 * abs(expect), (whole, expect)
+
+
+def test_duplicating_the_batch_leaves_loss_and_gradients_unchanged(model):
+    """mean loss of [X; X] == mean loss of X, and so are all gradients: a size-independent check of every reduction
+    in backward (bias / LayerNorm partial sums, split-K weight gradients, embedding scatter-adds) at 64 x the tiny sizes"""
+    from src.data.synthetic import make_batch
+    model.train()   # dropout is 0 in this fixture
+    b = make_batch(32, seed=5)
+    one = _dev(b)
+    two = {k: (torch.cat([v, v], 0) if torch.is_tensor(v) else v + v) for k, v in one.items()}
+    eng = model._engine
+    l1 = _loss(model, one)
+    l1.backward()
+    torch.cuda.synchronize()
+    g1 = eng.grads.clone()
+    l2 = _loss(model, two)
+    l2.backward()
+    torch.cuda.synchronize()
+    g2 = eng.grads.clone()
+    assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l1))
+    errs = []
+    for name, (off, rows, cols) in eng.index.items():
+        a, c = g1[off: off + rows * cols], g2[off: off + rows * cols]
+        errs.append((float((a - c).norm() / (a.norm() + 1e-30)), float(a.norm()), name))
+    errs.sort(reverse=True)
+    print(errs[:8])
+    # k_proj.bias has a zero true gradient (softmax is shift-invariant): what is there is rounding noise
+    worst = max(e for e, n, name in errs if "k_proj.bias" not in name)
+    assert worst < 2e-2, errs[:5]      # the two batches round identically row by row; only the sums reorder
+
+
+def test_ignored_labels_do_not_contribute(model):
+    """rows whose labels are all -100 change neither the loss nor (after scaling) anything else: compare a batch with
+    its padded twin (extra sample, every label ignored)"""
+    from src.data.synthetic import make_batch
+    model.eval()
+    b = make_batch(5, seed=21)
+    with torch.no_grad():
+        base = float(_loss(model, _dev(b, [0, 1, 2, 3])))
+        b["labels"][4] = -100
+        padded = float(_loss(model, _dev(b)))
+    assert abs(base - padded) <= 1e-5 * abs(base)
+
+
+def test_generation_modes(model):
+    from src.data.synthetic import make_batch
+    model.eval()
+    b = make_batch(6, seed=3)
+    d = _dev(b)
+    kw = dict(input_ids=d["input_ids"], image_features=d["image_features"], attention_mask=d["attention_mask"])
+    greedy = model.generate(max_length=12, **kw)
+    assert greedy.shape[0] == 6 and greedy.shape[1] <= 12 and int(greedy[:, 0].min()) == int(greedy[:, 0].max())
+    beams = model.generate(max_length=12, num_beams=4, num_return_sequences=3, early_stopping=True, **kw)
+    assert beams.shape[0] == 18 and beams.shape[1] <= 12
+    # beam search with one return sequence: the best hypothesis is the first of the three returned above
+    best = model.generate(max_length=12, num_beams=4, num_return_sequences=1, early_stopping=True, **kw)
+    n = min(best.shape[1], beams.shape[1])
+    assert torch.equal(best[:, :n], beams[0::3, :n])
+    torch.manual_seed(7)
+    s1 = model.generate(max_length=12, do_sample=True, top_k=50, top_p=0.9, **kw)
+    torch.manual_seed(7)
+    s2 = model.generate(max_length=12, do_sample=True, top_k=50, top_p=0.9, **kw)
+    assert torch.equal(s1, s2) and s1.shape[0] == 6
+    with pytest.raises((ValueError, AssertionError)):
+        model.generate(max_length=12, num_beams=2, num_return_sequences=3, **kw)   # mixins.py:196-208
