@@ -244,6 +244,7 @@ def main():
         agg = {}
         n_prof = 3
         lib.kmb_set_side_stream(model._engine.h, 0)  # kernels timed one at a time, not overlapped with each other
+        model._post_backward = None   # rank 0 only from here on: no collectives (the other ranks are at the final barrier)
         step()
         for _ in range(n_prof):
             lib.kmb_profile_gemm(1)
