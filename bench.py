@@ -127,6 +127,11 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.set_num_threads(usable_cores())
+    # test hooks for a one-GPU box: KMB_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and KMB_BENCH_BACKEND=gloo carries
+    # the collectives (RCCL refuses two ranks on one device), so the N > 1 control flow can be run end to end
+    if os.environ.get("KMB_BENCH_ONE_DEVICE", "0") == "1":
+        local = 0
+    backend = os.environ.get("KMB_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # KMB_BENCH_FORCE_DIST=1: take the multi-GPU code path (process group, bucketed RCCL all-reduce on the side stream,
@@ -136,7 +141,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from kmbart import _lib
     from kmbart.optim import AdamW
