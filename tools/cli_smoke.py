@@ -1,0 +1,70 @@
+"""End-to-end smoke of the three drivers on files in the reference's dataset format (run on a GPU box):
+write a tiny VCG / COCO / Visual Genome corpus + a tiny model config + a small BPE vocabulary under a temp dir, then
+    vcg_train.py --data_dir ... --validate_loss      (fine-tuning from files, checkpoint written)
+    pretrain.py --dataset coco_train ... --dataset vg_train ...   (multi-task pre-training from files)
+    vcg_generate.py --data_dir ... --checkpoint <fine-tuned>      (beam generation, decoded text written)
+Exit code 0 and the three artefacts present = pass."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "km-bart_amd")
+sys.path.insert(0, PKG)
+from src.data.dataset import write_synthetic_split, write_synthetic_vg  # noqa: E402
+from src.data.offline_tokenizer import load_base_tokenizer, train_byte_level_bpe  # noqa: E402
+from src.data.tokenization import ConditionTokenizer  # noqa: E402
+
+work = tempfile.mkdtemp(prefix="kmb_cli_")
+tok_json = os.path.join(work, "vocab.json")
+train_byte_level_bpe(vocab_size=600, save_to=tok_json)
+tok = ConditionTokenizer(base_tokenizer=load_base_tokenizer(tok_json))
+vcg, coco, vg = (os.path.join(work, n) for n in ("vcg", "coco", "vg"))
+for split in ("train", "val"):
+    write_synthetic_split(vcg, split, n_images=6, records_per_image=2, regions=[12, 7, 0, 20, 5, 9], seed=1)
+write_synthetic_split(coco, "train", n_images=5, records_per_image=1, regions=10, seed=2)
+for r in json.load(open(os.path.join(coco, "train.json"))):
+    pass
+# COCO records are captions: task_type caption, no event
+recs = json.load(open(os.path.join(coco, "train.json")))
+for r in recs:
+    r["task_type"] = "caption"
+    r.pop("event", None)
+json.dump(recs, open(os.path.join(coco, "train.json"), "w"))
+write_synthetic_vg(vg, "train", n_images=3, objects=4, regions_per_image=2, seed=3)
+cfg = dict(vocab_size=((len(tok) + 63) // 64) * 64, d_model=128, encoder_layers=2, decoder_layers=2,
+           encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+           max_position_embeddings=128, image_feature_size=2052, img_feat_id=tok.img_feat_id,
+           cls_token_id=tok.cls_token_id, dropout=0.1, attention_dropout=0.0, activation_dropout=0.0, init_std=0.02,
+           num_labels=1601, num_attributes=129, num_relations=201, lm_loss_factor=5, mrm_loss_factor=1,
+           attribute_loss_factor=1, relation_loss_factor=1)
+cfg_path = os.path.join(work, "tiny.json")
+json.dump(cfg, open(cfg_path, "w"))
+
+
+def run(args):
+    print("+", " ".join(args), flush=True)
+    r = subprocess.run([sys.executable] + args, cwd=PKG, capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr).strip().splitlines()[-6:]
+    print("\n".join("    " + t[:200] for t in tail), flush=True)
+    if r.returncode != 0:
+        sys.exit("FAILED: " + " ".join(args))
+
+
+ck = os.path.join(work, "ckpt")
+run(["vcg_train.py", "--model_config", cfg_path, "--checkpoint_dir", ck, "--data_dir", vcg, "--tokenizer_json", tok_json,
+     "--epochs", "2", "--batch_size", "4", "--lr", "1e-3", "--validate_loss"])
+assert os.path.exists(os.path.join(ck, "epoch2", "pytorch_model.bin")) and os.path.exists(os.path.join(ck, "epoch2", "training_data.pt"))
+pk = os.path.join(work, "pre")
+run(["pretrain.py", "--model_config", cfg_path, "--checkpoint_dir", pk, "--dataset", "coco_train", coco, "--dataset",
+     "vg_train", vg, "--dataset", "vcg_train", vcg, "--tokenizer_json", tok_json, "--epochs", "1", "--batch_size", "4",
+     "--max_img_num", "16"])
+assert os.path.exists(os.path.join(pk, "model0", "pytorch_model.bin"))
+out = os.path.join(work, "gen.json")
+run(["vcg_generate.py", "--checkpoint", os.path.join(ck, "epoch2"), "--data_dir", vcg, "--split", "val", "--output_file", out,
+     "--tokenizer_json", tok_json, "--num_beams", "3", "--num_gen", "2", "--batch_size", "4"])
+gen = json.load(open(out))
+assert len(gen) == 6 and all(len(g["generations"]) == 2 and isinstance(g["generations"][0], str) for g in gen), gen[:2]
+print("CLI smoke OK:", work)
