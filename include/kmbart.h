@@ -99,6 +99,11 @@ typedef struct KmbAttnDecode {
   const int32_t* mask_row;
   int32_t R, H, Tk;
   kmb_bf16* O; int32_t ldo;
+  /* self-attention of a decode step: key / value row Tk-1 is NOT in the cache yet -- it is read from new_k / new_v
+   * (row r at new_k + r*ld_new + h*64) and written into caches Kw / Vw at position Tk-1 by the same launch (NULL: plain
+   * attention over the cache) */
+  const kmb_bf16* new_k; const kmb_bf16* new_v; int32_t ld_new;
+  kmb_bf16* Kw; kmb_bf16* Vw;
 } KmbAttnDecode;
 
 typedef struct KmbDrop { uint32_t thr16; uint32_t seed; float scale; } KmbDrop;

@@ -353,10 +353,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const KmbAttnDecode p)
 #pragma unroll
     for (int c = 0; c < 8; ++c) unpack8(*reinterpret_cast<const u32x4*>(qrow + c * 8), q + c * 8);
   }
+  // decode self-attention: the newest key / value (position Tk - 1) comes from the projection output, not the cache;
+  // this wave also appends it (one element per lane) -- the separate append launches are gone
+  const int t_new = p.new_k != nullptr ? p.Tk - 1 : -1;
+  const bf16_t* knew = p.new_k != nullptr ? p.new_k + (size_t)row * p.ld_new + h * HD : nullptr;
+  const bf16_t* vnew = p.new_k != nullptr ? p.new_v + (size_t)row * p.ld_new + h * HD : nullptr;
+  if (t_new >= 0) {
+    p.Kw[((size_t)crow * p.Tmax + t_new) * HDm + h * HD + lane] = knew[lane];
+    p.Vw[((size_t)crow * p.Tmax + t_new) * HDm + h * HD + lane] = vnew[lane];
+  }
   float mx = -INFINITY;
   for (int t = lane; t < p.Tk; t += 64) {
     float s = 0.f;
-    const bf16_t* krow = Kc + (size_t)t * HDm;
+    const bf16_t* krow = (t == t_new) ? knew : Kc + (size_t)t * HDm;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float k8[8];
@@ -383,15 +392,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const KmbAttnDecode p)
   // four independent partial sums, eight value rows in flight: a single dependent chain over Tk rows made this
   // launch-sized kernel latency-bound (21 us for 64 keys)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int Tc = t_new >= 0 ? p.Tk - 1 : p.Tk;   // rows that live in the cache
   int t = 0;
 #pragma unroll 2
-  for (; t + 4 <= p.Tk; t += 4) {
+  for (; t + 4 <= Tc; t += 4) {
     a0 += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
     a1 += sc[t + 1] * bf2f(Vc[(size_t)(t + 1) * HDm + lane]);
     a2 += sc[t + 2] * bf2f(Vc[(size_t)(t + 2) * HDm + lane]);
     a3 += sc[t + 3] * bf2f(Vc[(size_t)(t + 3) * HDm + lane]);
   }
-  for (; t < p.Tk; ++t) a0 += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
+  for (; t < Tc; ++t) a0 += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
+  if (t_new >= 0) a1 += sc[t_new] * bf2f(vnew[lane]);
   const float acc = (a0 + a1) + (a2 + a3);
   p.O[(size_t)row * p.ldo + h * HD + lane] = f2bf(acc * inv);
 }

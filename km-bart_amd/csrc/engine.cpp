@@ -1205,11 +1205,11 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     KmbGemm g = lin_fwd(x, d, h->wb(L.sa.qkv_w), h->pf(L.sa.qkv_b), R, 3 * d, d);
     g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = G.qkv; g.ld_out_bf16 = 3 * d;
     KCHK(run_gemm(g, s));
-    HIPCHK(kmb_kv_append_launch(G.qkv + d, 3 * d, G.kc[G.cur][l], G.Tmax, d, step, R, s));
-    HIPCHK(kmb_kv_append_launch(G.qkv + 2 * d, 3 * d, G.vc[G.cur][l], G.Tmax, d, step, R, s));
     KmbAttnDecode a; memset(&a, 0, sizeof(a));
     a.Q = G.qkv; a.ldq = 3 * d; a.Kc = G.kc[G.cur][l]; a.Vc = G.vc[G.cur][l]; a.Tmax = G.Tmax; a.ldc = d;
     a.R = R; a.H = h->Hd; a.Tk = step + 1; a.O = G.o; a.ldo = d;
+    // this step's key / value: attended to from the projection output and appended to the cache by the same launch
+    a.new_k = G.qkv + d; a.new_v = G.qkv + 2 * d; a.ld_new = 3 * d; a.Kw = G.kc[G.cur][l]; a.Vw = G.vc[G.cur][l];
     HIPCHK(kmb_attn_decode_launch(a, s));
     g = lin_fwd(G.o, d, h->wb(L.sa.o_w), h->pf(L.sa.o_b), R, d, d);
     g.residual = x; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
@@ -1253,10 +1253,21 @@ int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stre
   const int d = h->d;
   const int row_bytes = (step + 1) * d * (int)sizeof(bf16_t);
   const size_t stride = (size_t)G.Tmax * d * sizeof(bf16_t);
+  // every layer's K and V cache in one launch per 16 buffers (12 launches -> 1 for a 6-layer decoder)
+  const void* src[16];
+  void* dst[16];
+  int n = 0;
   for (int l = 0; l < h->cfg.decoder_layers; ++l) {
-    HIPCHK(kmb_gather_rows_launch(G.kc[G.cur][l], beam_idx, G.kc[G.cur ^ 1][l], G.R, row_bytes, stride, s));
-    HIPCHK(kmb_gather_rows_launch(G.vc[G.cur][l], beam_idx, G.vc[G.cur ^ 1][l], G.R, row_bytes, stride, s));
+    for (int kv = 0; kv < 2; ++kv) {
+      src[n] = kv ? (const void*)G.vc[G.cur][l] : (const void*)G.kc[G.cur][l];
+      dst[n] = kv ? (void*)G.vc[G.cur ^ 1][l] : (void*)G.kc[G.cur ^ 1][l];
+      if (++n == 16) {
+        HIPCHK(kmb_gather_rows_multi_launch(src, dst, n, beam_idx, G.R, row_bytes, stride, s));
+        n = 0;
+      }
+    }
   }
+  if (n) HIPCHK(kmb_gather_rows_multi_launch(src, dst, n, beam_idx, G.R, row_bytes, stride, s));
   G.cur ^= 1;
   return 0;
 }

@@ -88,6 +88,8 @@ hipError_t kmb_cast_rows_launch(const float* x, int ldx, bf16_t* y, int ldy, int
 hipError_t kmb_kv_append_launch(const bf16_t* src, int ld_src, bf16_t* cache, int Tmax, int HD, int t, int R,
                                 hipStream_t stream);
 // gather rows: dst[i] = src[idx[i]]  (16-byte chunks, row_bytes % 16 == 0; rows are `stride_bytes` apart)
+hipError_t kmb_gather_rows_multi_launch(const void* const* src, void* const* dst, int n, const int32_t* idx, int rows,
+                                        int row_bytes, size_t stride_bytes, hipStream_t stream);
 hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst, int rows, int row_bytes,
                                   size_t stride_bytes, hipStream_t stream);
 

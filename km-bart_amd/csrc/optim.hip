@@ -101,6 +101,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
   }
 }
 
+// the same row gather over up to 16 (src, dst) buffer pairs in ONE launch (beam reorder of every layer's K and V cache)
+struct GatherSet { const char* src[16]; char* dst[16]; };
+__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet gs, const int32_t* __restrict__ idx, int rows,
+                                                                int row_bytes, size_t stride) {
+  const char* __restrict__ src = gs.src[blockIdx.y];
+  char* __restrict__ dst = gs.dst[blockIdx.y];
+  const int chunks = row_bytes >> 4;
+  const size_t total = (size_t)rows * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / chunks), c = (int)(i % chunks);
+    *reinterpret_cast<u32x4*>(dst + (size_t)r * stride + c * 16) =
+        *reinterpret_cast<const u32x4*>(src + (size_t)idx[r] * stride + c * 16);
+  }
+}
+
 inline int grid_for(size_t work, int cap = 4096) {
   size_t b = (work + 255) / 256;
   if (b > (size_t)cap) b = cap;
@@ -157,6 +172,17 @@ hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst
   if ((row_bytes & 15) || (stride_bytes & 15)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)rows * (row_bytes >> 4))), dim3(256), 0, stream,
                      (const char*)src, idx, (char*)dst, rows, row_bytes, stride_bytes);
+  return hipGetLastError();
+}
+
+hipError_t kmb_gather_rows_multi_launch(const void* const* src, void* const* dst, int n, const int32_t* idx, int rows,
+                                        int row_bytes, size_t stride_bytes, hipStream_t stream) {
+  if (rows <= 0 || n <= 0) return hipSuccess;
+  if ((row_bytes & 15) || (stride_bytes & 15) || n > 16) return hipErrorInvalidValue;
+  GatherSet gs;
+  for (int i = 0; i < 16; ++i) { gs.src[i] = (const char*)src[i < n ? i : 0]; gs.dst[i] = (char*)dst[i < n ? i : 0]; }
+  dim3 grid(grid_for((size_t)rows * (row_bytes >> 4), 256), n);
+  hipLaunchKernelGGL(gather_rows_multi_kernel, grid, dim3(256), 0, stream, gs, idx, rows, row_bytes, stride_bytes);
   return hipGetLastError();
 }
 

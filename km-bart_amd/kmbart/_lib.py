@@ -57,7 +57,7 @@ class KmbAttn(C.Structure):
 class KmbAttnDecode(C.Structure):
     _fields_ = [("Q", c_p), ("ldq", i32), ("Kc", c_p), ("Vc", c_p), ("Tmax", i32), ("ldc", i32), ("kv_row", c_p),
                 ("key_mask", c_p), ("mask_ld", i32), ("mask_row", c_p), ("R", i32), ("H", i32), ("Tk", i32),
-                ("O", c_p), ("ldo", i32)]
+                ("O", c_p), ("ldo", i32), ("new_k", c_p), ("new_v", c_p), ("ld_new", i32), ("Kw", c_p), ("Vw", c_p)]
 
 
 class KmbDrop(C.Structure):
