@@ -182,6 +182,9 @@ int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stre
  * (adjust_logits_during_generation, src/model/mixins.py:400-417) */
 int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int k,
                         float* out_val, int32_t* out_idx, void* stream);
+/* one beam-search step's candidate selection (mixins.py beam loop: topk over num_beams * V): per batch item the best k of
+ * its beams' top-k lists; out[B][k][2] int32 = {fp32 score bits, beam * V + token} */
+int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream);
 int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
 
 /* ================= measurement ================= */

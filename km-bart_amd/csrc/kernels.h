@@ -72,6 +72,8 @@ hipError_t kmb_ce_launch(const float* logits, int ldv, int V, const int64_t* lab
 hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
                                   hipStream_t stream);
 // generation: per row log_softmax over V then top-k of (logp + add[row]); writes k (value, index) pairs
+hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out,
+                                 hipStream_t stream);
 hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
                                       int force_token, int k, float* out_val, int32_t* out_idx,
                                       hipStream_t stream);

@@ -265,6 +265,41 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
   }
 }
 
+// Beam search, per batch item: the best `k` of the nb * k candidates its beams produced (val / idx from
+// logsoftmax_topk_kernel, rows b*nb .. b*nb + nb - 1), ordered by (value desc, candidate position asc) -- what
+// torch.topk over the [nb * V] scores of mixins.py's beam step returns, restricted to each beam's own top k (enough:
+// the best k overall contain at most k from any beam).  Output, packed for ONE device-to-host copy:
+// out[(b*k + j)*2] = score bits (fp32), out[(b*k + j)*2 + 1] = beam * V + token.
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx,
+                                                        int nb, int k, int V, int32_t* __restrict__ out) {
+  __shared__ float sv[256];
+  __shared__ unsigned char taken[256];
+  const int b = blockIdx.x, lane = threadIdx.x, n = nb * k;   // n <= 256
+  for (int i = lane; i < n; i += 64) { sv[i] = val[(size_t)b * n + i]; taken[i] = 0; }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+      const float x = sv[i];
+      if (!taken[i] && (bi == 0x7fffffff || x > bv)) { bv = x; bi = i; }   // ascending i: first of equal values wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(bv, o, 64);
+      const int i2 = __shfl_xor(bi, o, 64);
+      if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
+    }
+    if (lane == 0) {
+      const int beam = bi / k;
+      out[((size_t)b * k + j) * 2] = __float_as_int(bv);
+      out[((size_t)b * k + j) * 2 + 1] = beam * V + idx[(size_t)b * n + bi];
+      taken[bi] = 1;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, hipStream_t stream) {
@@ -293,5 +328,13 @@ hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int r
                                       int force_token, int k, float* out_val, int32_t* out_idx, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, add, force_token, k, out_val, out_idx);
+  return hipGetLastError();
+}
+
+hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out,
+                                 hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  if (nb * k > 256 || k <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, stream, val, idx, nb, k, V, out);
   return hipGetLastError();
 }

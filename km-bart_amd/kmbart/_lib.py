@@ -97,6 +97,7 @@ PROTOTYPES = {
     "kmb_gen_begin": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p]),
     "kmb_gen_step": (C.c_int, [c_p, c_p, C.c_int, c_p, c_p]),
     "kmb_gen_reorder": (C.c_int, [c_p, c_p, C.c_int, c_p]),
+    "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kmb_set_side_stream": (C.c_int, [c_p, C.c_int]),

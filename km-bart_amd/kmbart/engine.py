@@ -263,6 +263,17 @@ class Engine:
             check(self.lib.kmb_gen_reorder(self.h, ptr(beam_idx), int(step), _stream()))
             self._keep_idx = beam_idx
 
+    def beam_candidates(self, logits, num_beams, k, add=None, force_token=-1):
+        """log_softmax(+beam score) top-k per beam row, merged per batch item: int32 [B, k, 2] on the device,
+        [..., 0] = fp32 score bits, [..., 1] = beam * V + token (one small D2H copy per decode step)."""
+        R = logits.shape[0]
+        val, idx = self.logsoftmax_topk(logits, k, add=add, force_token=force_token)
+        out = torch.empty((R // num_beams, k, 2), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_beam_merge(ptr(val), ptr(idx), R // num_beams, int(num_beams), int(k),
+                                          int(self.config.vocab_size), ptr(out), _stream()))
+        return out
+
     def logsoftmax_topk(self, logits, k, add=None, force_token=-1):
         R = logits.shape[0]
         val = torch.empty((R, k), dtype=torch.float32, device=self.device)

@@ -436,7 +436,6 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         seqs = [[int(decoder_start_token_id)] for _ in range(R)]   # decoder inputs of every beam row
         done = [False] * B
         k = 2 * num_beams
-        beam_off = (torch.arange(num_beams, device=dev) * V).view(1, -1, 1)
         last_tokens = torch.full((R,), decoder_start_token_id, dtype=torch.long, device=dev)
         while cur_len < max_length:
             logits = eng.gen_step(last_tokens, cur_len - 1)
@@ -448,14 +447,11 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             if eos_token_id is not None and cur_len < min_length:
                 logits[:, eos_token_id] = -float("inf")
             add = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
-            val, idx = eng.logsoftmax_topk(logits, k, add=add, force_token=force)
-            # top 2*num_beams of the union == top 2*num_beams over num_beams * V (each row contributed its best 2*num_beams)
-            val = val.view(B, num_beams * k)
-            idx = (idx.view(B, num_beams, k).long() + beam_off).view(B, num_beams * k)
-            order = torch.sort(val, dim=1, descending=True, stable=True)[1][:, :k]
-            packed = torch.stack([torch.gather(val, 1, order).double(), torch.gather(idx, 1, order).double()], 0).cpu()
-            next_scores = packed[0].tolist()
-            next_tokens = packed[1].long().tolist()
+            # per beam row: log_softmax + beam score, top 2*num_beams; per batch item: the best 2*num_beams of the union
+            # (== top 2*num_beams over num_beams * V: each row contributed its own best 2*num_beams); one D2H copy
+            cand = eng.beam_candidates(logits, num_beams, k, add=add, force_token=force).cpu()
+            next_scores = cand[:, :, 0].contiguous().view(torch.float32).tolist()
+            next_tokens = cand[:, :, 1].tolist()
             new_scores, new_tokens, new_idx = [], [], []
             for b in range(B):
                 if done[b]:

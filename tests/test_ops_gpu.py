@@ -432,3 +432,37 @@ def test_adamw_matches_hf_form():
         opt.step()
     assert torch.allclose(p.cpu(), ref_p.detach(), atol=2e-7, rtol=1e-6)
     assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+def test_beam_merge_matches_torch_topk_over_all_beams():
+    """kmb_beam_merge: per batch item the best k of its beams' top-k lists == torch.topk over the num_beams * V scores
+    (ties: the earlier candidate position first), including forced-token steps where most candidates are -inf."""
+    lib = _lib.load()
+    B, nb, V, ld = 7, 5, 50320, 50432
+    k = 2 * nb
+    logits = torch.zeros((B * nb, ld), device=DEV)
+    logits[:, :V] = rnd(B * nb, V, seed=91) * 3
+    logits[3, 100] = logits[3, 7]                    # an exact tie inside one row
+    add = rnd(B * nb, seed=92)
+    for force in (-1, 2):
+        val = torch.empty((B * nb, k), device=DEV)
+        idx = torch.empty((B * nb, k), dtype=torch.int32, device=DEV)
+        check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, B * nb, ptr(add), force, k, ptr(val), ptr(idx), stream()))
+        out = torch.empty((B, k, 2), dtype=torch.int32, device=DEV)
+        check(lib.kmb_beam_merge(ptr(val), ptr(idx), B, nb, k, V, ptr(out), stream()))
+        got_scores = out[:, :, 0].contiguous().view(torch.float32)
+        got_ids = out[:, :, 1].long()
+        if force < 0:
+            lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
+        else:
+            lp = torch.full((B * nb, V), -float("inf"), device=DEV)
+            lp[:, force] = add
+        flat = lp.view(B, nb * V)
+        order = torch.sort(flat, dim=1, descending=True, stable=True)[1][:, :k]
+        n_finite = int(torch.isfinite(torch.gather(flat, 1, order)).sum(1).min())
+        assert torch.equal(got_ids[:, :n_finite], order[:, :n_finite])
+        assert torch.allclose(got_scores[:, :n_finite], torch.gather(flat, 1, order)[:, :n_finite], atol=1e-4)
+        assert bool(torch.isinf(got_scores[:, n_finite:]).all())
+        # every candidate is distinct
+        for b in range(B):
+            assert len(set(got_ids[b].tolist())) == k
