@@ -166,13 +166,18 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
 // heads); RES: residual add; CS: column sums) and entered through ONE uniform branch: with every option tested per
 // element inside the 8x-unrolled row loop the epilogue was ~90 KB of code walked once per tile -- instruction fetch,
 // not the stores, made it 4.4 us of a 17 us tile (in-kernel stamps, tools/gemm_stamps.py).
-template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS, int ACT, bool RES, bool CS, bool FAST>
+// WAVE: one wave runs the body on its private 16-row staging chunk (v11); the column sums are carried across chunks
+// in csum_io and finished by the caller.
+template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS, int ACT, bool RES, bool CS, bool FAST,
+          bool WAVE = false>
 __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
-                                                   int col0) {
+                                                   int col0, float* csum_io = nullptr) {
   constexpr int RPP = NT / 16;  // rows per pass
   constexpr int NH = HOIST ? NIT : 1;
   constexpr bool AUX = (ACT == 2 || ACT < 0);
-  auto eoff = [&](int lrow, int c) { return lrow * LD + (SWZ ? (c ^ (((lrow >> 2) & 1) << 4)) : c); };
+  auto eoff = [&](int lrow, int c) {
+    return lrow * LD + (WAVE ? (c ^ ((lrow & 7) << 3)) : SWZ ? (c ^ (((lrow >> 2) & 1) << 4)) : c);
+  };
   const int act = ACT < 0 ? p.act : ACT;
   const bool res_on = RES && (ACT >= 0 || p.residual != nullptr);  // the run-time class checks its pointers
   const bool cs_on = CS && (ACT >= 0 || p.colsum != nullptr);
@@ -185,7 +190,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
   float csum[8], bias8[8], scale8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    csum[e] = 0.f;
+    csum[e] = WAVE ? csum_io[e] : 0.f;
     bias8[e] = (p.bias != nullptr && e < nvalid) ? p.bias[gcol + e] : 0.f;
     scale8[e] = (gcol + e < p.col_scale_n) ? p.col_scale : 1.0f;  // (v + bias) * scale, the reference's order
   }
@@ -281,7 +286,9 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
     }
     if (p.out_bf16 != nullptr) {
       if (full8) {
-        *reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol) = pack8(v);
+        u32x4* const dst = reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol);
+        if (WAVE) __builtin_nontemporal_store(pack8(v), dst);   // streaming: C must not evict the A / B panels from L2
+        else *dst = pack8(v);
       } else {
         for (int e = 0; e < nvalid; ++e) p.out_bf16[(size_t)grow * p.ld_out_bf16 + gcol + e] = f2bf(v[e]);
       }
@@ -312,7 +319,10 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
       if (!process(it0, 0)) break;
     }
   }
-  if (cs_on) {
+  if (WAVE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum_io[e] = csum[e];
+  } else if (cs_on) {
     // column sums of this tile's stored values: reduce the row-lanes through LDS, one partial row per 128 rows
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[(tid >> 4) * 128 + c8 + e] = csum[e];
@@ -867,6 +877,489 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 
 
 // ------------------------------------------------------------------------------------------
+// v11: persistent 256x256 tile.  One workgroup per CU (grid = 256), four waves (2x2), each wave a 128x128 block of C
+// (8x8 MFMA tiles, 256 accumulator registers -- the whole AGPR file; one wave per SIMD).  Why:
+//   * LDS bandwidth.  v8's 128x64 wave block reads 24 fragments per 64 MFMAs: 192 KB of ds_reads + 64 KB of LDS-DMA
+//     writes per K step against 128 B/clk is as long as the step's MFMA time.  A 128x128 block reads 16 fragments
+//     per 64 MFMAs (128 KB per step).
+//   * the per-tile fixed cost.  A workgroup walks its tiles as ONE linear sequence of K steps: the DMA cursor runs two
+//     steps ahead of the MFMAs straight across tile boundaries, so only the first tile pays a cold prologue, and the
+//     epilogue goes through a wave-private 8 KB staging image (no workgroup barrier, the two pipeline stages stay
+//     free for the next tile's operands that are landing meanwhile).
+// Tiles are dealt per XCD in contiguous ranges (neighbours share A/B panels in that XCD's L2).  Same LDS images,
+// swizzles and per-element accumulation order as v7/v8: bit-identical sums.  No split-K (the weight gradients stay
+// on v7/v8).
+template <bool KC>
+__device__ __forceinline__ void dma_offsets256w4(uint32_t (&off)[8], int ld, int r0, int R, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int piece = wave * 8 + i;  // 32 pieces of 1 KiB per 256-row tile
+    if (KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      int grow = r0 + row;
+      grow = grow < R ? grow : R - 1;
+      off[i] = (uint32_t)(((grow - r0) * ld + c * 8) * 2);
+    } else {
+      const int krow = piece * 2 + (lane >> 5);
+      const int ps = lane & 31;
+      const int c32 = (ps >> 1) ^ swz_nkc(krow);
+      int m = r0 + c32 * 16 + (ps & 1) * 8;
+      const int mlast = ((R - 1) >> 3) << 3;
+      m = m < R ? m : mlast;
+      off[i] = (uint32_t)((krow * ld + (m - r0)) * 2);
+    }
+  }
+}
+
+constexpr int EPW_BYTES = 16 * 128 * 4;            // wave-private fp32 staging: 16 rows x 128 columns, XOR-swizzled
+constexpr int LDS11 = 2 * ST4 + 4 * EPW_BYTES;     // 160 KB: the whole CU
+constexpr int LDS12 = 2 * (BM4 + 128) * BK * 2 + 4 * EPW_BYTES;   // 256x128 tiles: 128 KB
+
+template <int ACT, bool RES, bool CS, bool FAST, int WROWS>
+__device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][8], float* ef, int lane, int r, int g,
+                                             int row0w, int col0w) {
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+  // transposed accumulators (see the MFMA operand order in the K loop): lane (r, g) holds C[16 i + r][16 j + 4 g .. +3],
+  // one ds_write_b128 per MFMA tile; 16-byte groups XOR-swizzled by the row so that the 16 row-lanes spread over banks
+  float* const wbase = ef + r * 128;
+  const int sw = (r & 7) << 3;
+  auto stage = [&](const f32x4 (&a)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
+    asm volatile("" ::: "memory");   // keep the stores inside their switch arm (no select tree over the accumulators)
+  };
+#pragma unroll 1
+  for (int i = 0; i < WROWS / 16; ++i) {
+    switch (i) {   // static accumulator indices in every arm (a run-time index would put acc in scratch)
+      case 0: stage(acc[0]); break;
+      case 1: stage(acc[1]); break;
+      case 2: stage(acc[2]); break;
+      case 3: stage(acc[3]); break;
+      case 4: stage(acc[4]); break;
+      case 5: stage(acc[5]); break;
+      case 6: stage(acc[6]); break;
+      default: stage(acc[7]); break;
+    }
+    gemm_epilogue_body<64, true, 4, 128, true, 128, ACT, RES, CS, FAST, true>(p, ef, nullptr, lane, row0w + i * 16, col0w,
+                                                                             csum);
+  }
+  if (CS && (ACT >= 0 || p.colsum != nullptr)) {
+    // column sums over this wave's 128 rows: fold the four row-lanes, one partial row per 64 rows of C (first filled,
+    // second zeroed)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      csum[e] += __shfl_xor(csum[e], 16);
+      csum[e] += __shfl_xor(csum[e], 32);
+    }
+    if (lane < 16) {
+      const int prow = row0w >> 6;
+      const int c8 = lane * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (FAST || col0w + c8 + e < p.N) {
+          p.colsum[(size_t)prow * p.N + col0w + c8 + e] = csum[e];
+          if (WROWS == 128 && (FAST || row0w + 64 < p.M)) p.colsum[(size_t)(prow + 1) * p.N + col0w + c8 + e] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+// The hot epilogue classes of v11, everything decided at compile time.  With ONE wave per SIMD nothing hides an
+// instruction: the general body (run-time option tests, edge handling, spilled-SGPR reloads) costs ~450 instructions
+// per 16-row chunk = 7 us per 256x256 tile (in-kernel stamps), as long as the tile's MFMAs at K = 256.  Interior wave
+// blocks with a bf16 output only; same operation order as gemm_epilogue_body (bit-identical results).
+//   BIAS: + bias[col];  SCALE: * col_scale (the whole wave block lies in the scaled columns);  ACT 1: GeLU (+ optional
+//   pre-activation store), 2: * GeLU'(aux);  DROP: dropout mask;  RES: + residual;  CS: column sums.
+template <bool BIAS, bool SCALE, int ACT, bool RES, bool DROP, bool CS, int WROWS>
+__device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)[8][8], float* ef, int lane, int r, int g,
+                                                  int row0w, int col0w) {
+  const int lr = lane >> 4, c8 = (lane & 15) * 8;
+  const int gcol = col0w + c8;
+  kmb_f32x2 bias2[4], csum2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bias2[e] = BIAS ? kmb_f32x2{p.bias[gcol + 2 * e], p.bias[gcol + 2 * e + 1]} : kmb_f32x2{0.f, 0.f};
+    csum2[e] = kmb_f32x2{0.f, 0.f};
+  }
+  const kmb_f32x2 scale2 = {p.col_scale, p.col_scale};
+  const kmb_f32x2 dscale2 = {p.drop_scale, p.drop_scale};
+  // staging write (transposed accumulators: lane (r, g) holds C[16 i + r][16 j + 4 g .. +3]) and read addresses
+  float* const wbase = ef + r * 128;
+  const int sw = (r & 7) << 3;
+  auto stage = [&](const f32x4 (&a)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
+    asm volatile("" ::: "memory");
+  };
+  const float* rd[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) rd[it] = ef + (lr + 4 * it) * 128 + (c8 ^ (((lr + 4 * it) & 7) << 3));
+  // row pointers of this lane's first row; a row-iteration is 4 rows further, a chunk 16
+  bf16_t* out = p.out_bf16 + (size_t)(row0w + lr) * p.ld_out_bf16 + gcol;
+  bf16_t* pre = (ACT == 1 && p.preact != nullptr) ? p.preact + (size_t)(row0w + lr) * p.ld_preact + gcol : nullptr;
+  const bf16_t* side = nullptr;   // residual (RES) or GeLU' argument (ACT 2): one 16-byte load per row
+  size_t ld_side = 0;
+  if (RES) { side = p.residual + (size_t)(row0w + lr) * p.ld_res + gcol; ld_side = (size_t)p.ld_res; }
+  if (ACT == 2) { side = p.aux + (size_t)(row0w + lr) * p.ld_aux + gcol; ld_side = (size_t)p.ld_aux; }
+  constexpr bool SIDE = RES || ACT == 2;
+  static_assert(!(RES && ACT == 2), "one side stream");
+  // side loads run two chunks ahead of their use (a chunk is ~0.3 us, an HBM miss longer)
+  u32x4 s0[4], s1[4], s2[4];
+  if (SIDE) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      s0[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(4 * it) * ld_side);
+      s1[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 + 4 * it) * ld_side);
+    }
+  }
+#pragma unroll 1
+  for (int i = 0; i < WROWS / 16; ++i) {
+    switch (i) {
+      case 0: stage(acc[0]); break;
+      case 1: stage(acc[1]); break;
+      case 2: stage(acc[2]); break;
+      case 3: stage(acc[3]); break;
+      case 4: stage(acc[4]); break;
+      case 5: stage(acc[5]); break;
+      case 6: stage(acc[6]); break;
+      default: stage(acc[7]); break;
+    }
+    if (SIDE) {
+      const int ahead = i + 2 < WROWS / 16 ? i + 2 : WROWS / 16 - 1;   // the last two chunks re-read rows that are in cache (never used)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) s2[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 * ahead + 4 * it) * ld_side);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(rd[it]);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(rd[it] + 4);
+      kmb_f32x2 v[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (BIAS) v[e] = v[e] + bias2[e];
+        if (SCALE) v[e] = v[e] * scale2;
+      }
+      const size_t roff = (size_t)(16 * i + 4 * it);
+      if (ACT == 1) {
+        if (pre != nullptr) {
+          const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
+          __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(pre + roff * p.ld_preact));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu2(v[e]);
+      } else if (ACT == 2) {
+        float u[8];
+        unpack8(s0[it], u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_grad2(kmb_f32x2{u[2 * e], u[2 * e + 1]});
+      }
+      if (DROP) {
+        const uint32_t grow = (uint32_t)(row0w + lr + 16 * i + 4 * it);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const kmb_f32x2 kept = v[e] * dscale2;
+          v[e][0] = drop_keep(p.drop_seed, grow, (uint32_t)(gcol + 2 * e), p.drop_thr16) ? kept[0] : 0.f;
+          v[e][1] = drop_keep(p.drop_seed, grow, (uint32_t)(gcol + 2 * e + 1), p.drop_thr16) ? kept[1] : 0.f;
+        }
+      }
+      if (RES) {
+        float rr[8];
+        unpack8(s0[it], rr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] + kmb_f32x2{rr[2 * e], rr[2 * e + 1]};
+      }
+      if (CS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum2[e] = csum2[e] + v[e];
+      }
+      const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
+      __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16));
+    }
+    if (SIDE) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) { s0[it] = s1[it]; s1[it] = s2[it]; }
+    }
+  }
+  if (CS) {
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { csum[2 * e] = csum2[e][0]; csum[2 * e + 1] = csum2[e][1]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      csum[e] += __shfl_xor(csum[e], 16);
+      csum[e] += __shfl_xor(csum[e], 32);
+    }
+    if (lane < 16) {
+      const int prow = row0w >> 6;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        p.colsum[(size_t)prow * p.N + gcol + e] = csum[e];
+        if (WROWS == 128) p.colsum[(size_t)(prow + 1) * p.N + gcol + e] = 0.f;
+      }
+    }
+  }
+}
+
+// BNT = 256: waves 2x2, each 128x128.  BNT = 128 (variant 12): waves 4x1, each 64x128 -- twice as many tiles, for shapes
+// whose 256x256 tile count is not a multiple of the 256 workgroups (N = 768: 1.5 tiles per workgroup -> 3).
+template <bool A_KC, bool B_KC, int BNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_kernel_v11(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  KMB_STAMP(0);
+  KMB_STAMP_ID();
+  [[maybe_unused]] uint64_t kmb_loop_ticks = 0, kmb_epi_ticks = 0, kmb_wait_ticks = 0, kmb_drain_ticks = 0;  // diagnostic build
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int WN = BNT / 128, WM = 4 / WN, WROWS = BM4 / WM, MH = WROWS / 64;   // 2,2,128,2  or  1,4,64,1
+  constexpr int NPB = BNT / 32;                        // 1 KiB LDS-DMA pieces of B per wave and stage
+  constexpr int STG = (BM4 + BNT) * BK * 2;            // one pipeline stage
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 15, g = lane >> 4;
+  const int tiles_n = (p.N + BNT - 1) / BNT;
+  const int ntiles = ((p.M + BM4 - 1) / BM4) * tiles_n;
+  // this workgroup's tiles: XCD x owns a contiguous range, its workgroups take every (grid/8)-th tile of it
+  const int per = (int)gridDim.x >> 3;
+  const int xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
+  const int tq = ntiles >> 3, trem = ntiles & 7;
+  const int range0 = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
+  const int range1 = range0 + tq + (xcd < trem ? 1 : 0);
+  const int first = range0 + loc;
+  if (first >= range1) return;
+  {  // experiment knob (tile_order bits 12-15): start the workgroups of an XCD in 8 phases, 0.24 us x knob apart
+    const int stag = (p.tile_order >> 12) & 15;
+    for (int i = 0; i < stag * (loc & 7); ++i) __builtin_amdgcn_s_sleep(9);
+  }
+
+  const int nt = p.K / BK;   // >= 2 (launcher)
+  constexpr int A_BYTES = BM4 * BK * 2;
+  const size_t stepA = A_KC ? (size_t)BK * 2 : (size_t)BK * p.lda * 2;
+  const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
+  auto uniform_ptr = [](const char* ptr) {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+
+  // ---- DMA cursor: (tile, K step) of the next stage to fetch; runs two steps ahead of the MFMAs ----
+  uint32_t offA[8], offB[NPB];
+  const char *gA_d, *gB_d;
+  int tile_d = first, td = 0;
+  auto set_dma_tile = [&](int tile) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int row0 = tm * BM4, col0 = tn * BNT;
+    dma_offsets256w4<A_KC>(offA, p.lda, row0, p.M, wave, lane);
+    if constexpr (BNT == 256) dma_offsets256w4<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
+    else dma_offsets<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
+    gA_d = uniform_ptr(reinterpret_cast<const char*>(p.A) + (A_KC ? (size_t)row0 * p.lda * 2 : (size_t)row0 * 2));
+    gB_d = uniform_ptr(reinterpret_cast<const char*>(p.B) + (B_KC ? (size_t)col0 * p.ldb * 2 : (size_t)col0 * 2));
+  };
+  auto advance_cursor = [&]() {   // before a fetch: step to the next tile when this one's K steps are all issued
+    if (td == nt) {
+      td = 0;
+      if (tile_d + per < range1) tile_d += per;   // past the last tile: fetch its first steps again (never read)
+      set_dma_tile(tile_d);
+    }
+  };
+  char* const dstA = smem + wave * 8192;
+  char* const dstB = smem + A_BYTES + wave * (NPB * 1024);
+  auto dma_stage = [&](int buf) {
+    char* da = dstA + buf * STG;
+    char* db = dstB + buf * STG;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(gA_d, offA[i], da + i * 1024);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) dma_piece(gB_d, offB[i], db + i * 1024);
+    gA_d = uniform_ptr(gA_d + stepA);
+    gB_d = uniform_ptr(gB_d + stepB);
+    ++td;
+  };
+
+  constexpr int NDA = A_KC ? 4 : 8;    // ds_read instructions per 4 A fragments
+  constexpr int NDB = B_KC ? 8 : 16;   // ... per 8 B fragments
+  bf16x8 fa[2][4], fb[2][8];
+  f32x4 acc[8][8];
+  auto read_a = [&](const char* stage, int kk, int half, bf16x8 (&dst)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * (MH * 4) + half * 4 + i, kk, r, g);
+  };
+  auto read_b = [&](const char* stage, int kk, bf16x8 (&dst)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = read_frag3<B_KC, BNT>(stage + A_BYTES, wn * 8 + j, kk, r, g);
+  };
+  auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);  // C^T tile
+  };
+
+  set_dma_tile(tile_d);
+  dma_stage(0);
+  advance_cursor();
+  dma_stage(1);
+  __builtin_amdgcn_s_waitcnt(BNT == 256 ? 0x4F70 : 0x0F7C);  // vmcnt(16 | 12) = the pieces of stage 1: stage 0 has landed
+  __syncthreads();
+  read_b(smem, 0, fb[0]);
+  read_a(smem, 0, 0, fa[0]);
+  KMB_STAMP(1);
+
+  float* const ef = reinterpret_cast<float*>(smem + 2 * STG + wave * EPW_BYTES);
+  int it = 0;   // linear K-step counter: stage buffer = it & 1
+  for (int tile = first; tile < range1; tile += per) {
+#pragma unroll
+    for (int i = 0; i < MH * 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] const uint64_t kmb_t_loop = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < nt; ++t, ++it) {
+      advance_cursor();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): k0 fragments of this stage (needed now anyway; a known-empty
+                                           // LDS queue here lets the compiler count the waits below exactly)
+      const char* cur = smem + (it & 1) * STG;
+      const char* nxt = smem + ((it + 1) & 1) * STG;
+      if constexpr (MH == 2) {
+      // ---- sub-phase 0: A(k0, rows 0-63) x B(k0)  ||  read A(k0, rows 64-127) ----
+      read_a(cur, 0, 1, fa[1]);
+      mma(0, fa[0], fb[0]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NDA / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- sub-phase 1: A(k0, rows 64-127) x B(k0)  ||  read B(k1), A(k1, rows 0-63) ----
+      read_b(cur, 1, fb[1]);
+      read_a(cur, 1, 0, fa[0]);
+      mma(1, fa[1], fb[0]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);   // MFMAs first: their operands were read a sub-phase ago
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- sub-phase 2: A(k1, rows 0-63) x B(k1)  ||  read A(k1, rows 64-127); stage it+1 landed, barrier ----
+      read_a(cur, 1, 1, fa[1]);
+      mma(0, fa[0], fb[1]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA, 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, 24, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        KMB_WAIT_BEGIN();
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        KMB_WAIT_END(kmb_wait_ticks);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- sub-phase 3: A(k1, rows 64-127) x B(k1)  ||  read k0 of stage it+1, fetch stage it+2 into this buffer ----
+      read_b(nxt, 0, fb[0]);
+      read_a(nxt, 0, 0, fa[0]);
+      dma_stage(it & 1);
+      mma(1, fa[1], fb[1]);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB, 3);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 3);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA, 3);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 3);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 3);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      } else {
+      // 64-row wave block: two sub-phases of 32 MFMAs (fa[0] / fa[1] are the two K halves)
+      // ---- sub-phase a: A(k0) x B(k0)  ||  read B(k1), A(k1) ----
+      read_b(cur, 1, fb[1]);
+      read_a(cur, 1, 0, fa[1]);
+      mma(0, fa[0], fb[0]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        KMB_WAIT_BEGIN();
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        KMB_WAIT_END(kmb_wait_ticks);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- sub-phase b: A(k1) x B(k1)  ||  read k0 of stage it+1, fetch stage it+2 into this buffer ----
+      read_b(nxt, 0, fb[0]);
+      read_a(nxt, 0, 0, fa[0]);
+      dma_stage(it & 1);
+      mma(0, fa[1], fb[1]);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA): 8 + 4 pieces
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- epilogue of this tile (the next tile's first two stages are in flight / resident meanwhile) ----
+    [[maybe_unused]] const uint64_t kmb_t_epi = __builtin_amdgcn_s_memrealtime();
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int row0w = tm * BM4 + wm * WROWS, col0w = tn * BNT + wn * 128;
+    if (row0w < p.M && col0w < p.N) {
+      const bool interior = (row0w + WROWS <= p.M) && (col0w + 128 <= p.N);
+      const bool hb = p.bias != nullptr, hr = p.residual != nullptr, hd = p.drop_thr16 != 0u, hc = p.colsum != nullptr;
+      const bool hs = col0w < p.col_scale_n;   // wave-uniform when col_scale_n is a multiple of 128 (checked below)
+      const bool lean_ok = interior && p.out_bf16 != nullptr && p.out_f32 == nullptr && (p.tile_order & 256) == 0 &&
+                           (p.col_scale_n <= 0 || (p.col_scale_n & 127) == 0);
+#define KMB_LEAN(B, S, A, R, D, C) v11_epilogue_lean<B, S, A, R, D, C, WROWS>(p, acc, ef, lane, r, g, row0w, col0w)
+      if (lean_ok && p.act == 0 && hb && !hr && !hd && !hc) {
+        if (hs) KMB_LEAN(true, true, 0, false, false, false);
+        else KMB_LEAN(true, false, 0, false, false, false);
+      } else if (lean_ok && p.act == 0 && hb && hr && !hc && !hs) {
+        if (hd) KMB_LEAN(true, false, 0, true, true, false);
+        else KMB_LEAN(true, false, 0, true, false, false);
+      } else if (lean_ok && p.act == 0 && !hb && !hd && !hc && !hs) {
+        if (hr) KMB_LEAN(false, false, 0, true, false, false);
+        else KMB_LEAN(false, false, 0, false, false, false);
+      } else if (lean_ok && p.act == 1 && hb && !hr && !hd && !hc && !hs) {
+        KMB_LEAN(true, false, 1, false, false, false);
+      } else if (lean_ok && p.act == 2 && !hb && !hr && !hd && hc && !hs) {
+        KMB_LEAN(false, false, 2, false, false, true);
+      } else {
+        v11_epilogue<-1, true, true, false, WROWS>(p, acc, ef, lane, r, g, row0w, col0w);   // edges and rare classes
+      }
+#undef KMB_LEAN
+    }
+    [[maybe_unused]] const uint64_t kmb_t_drain = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): keeps the epilogue's pending loads out of the K loop's wait state
+#ifdef KMB_GEMM_STAMP
+    {
+      const uint64_t now = __builtin_amdgcn_s_memrealtime();
+      kmb_loop_ticks += kmb_t_epi - kmb_t_loop; kmb_epi_ticks += kmb_t_drain - kmb_t_epi; kmb_drain_ticks += now - kmb_t_drain;
+    }
+#endif
+  }
+  KMB_STAMP_VALUE(2, kmb_loop_ticks);
+  KMB_STAMP_VALUE(3, kmb_epi_ticks);
+  KMB_STAMP_VALUE(5, kmb_wait_ticks);
+  KMB_STAMP_VALUE(6, kmb_drain_ticks);
+  KMB_STAMP(4);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the two look-ahead fetches past the last tile target this LDS
+}
+
+// ------------------------------------------------------------------------------------------
 // Narrow tile for the generation path.  A decode step multiplies M = batch x beams rows (320 at the benchmark
 // setting) by every weight matrix: with 128x128 tiles that is 18-72 workgroups on 256 CUs and each launch costs a
 // full tile latency (23 us measured, 56 GFLOP/step at 67 TFLOP/s).  Here a workgroup takes a 128 x 32 slice
@@ -1049,7 +1542,17 @@ namespace {
 // variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  if (variant == 8) {
+  if (variant == 11) {
+    dim3 grid(256), block(256);
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 256>), grid, block, LDS11, stream, p);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 256>), grid, block, LDS11, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 256>), grid, block, LDS11, stream, p);
+  } else if (variant == 12) {
+    dim3 grid(256), block(256);
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 128>), grid, block, LDS12, stream, p);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 128>), grid, block, LDS12, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 128>), grid, block, LDS12, stream, p);
+  } else if (variant == 8) {
     const int tiles = ((p.M + BM4 - 1) / BM4) * ((p.N + BN4 - 1) / BN4);
     dim3 grid(tiles * nsl), block(512);
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v8<true, true>), grid, block, LDS4, stream, p);
@@ -1078,6 +1581,12 @@ struct TuneKey {
   }
 };
 std::map<TuneKey, int> g_best;
+
+// v11 (persistent, one workgroup per CU): at least one 256x256 tile per CU, two K steps, no split-K
+bool v11_ok(const KmbGemm& p, int bn = BN4) {
+  const long tiles = (long)((p.M + BM4 - 1) / BM4) * ((p.N + bn - 1) / bn);
+  return p.split_k <= 1 && (p.K % BK) == 0 && p.K >= 2 * BK && tiles >= 256;
+}
 
 bool writes_an_input(const KmbGemm& p) {
   const void* outs[3] = {p.out_bf16, p.out_f32, p.preact};
@@ -1122,6 +1631,12 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS12);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS12);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS12);
   }
   const bool dma_ok = (p.K % BK) == 0;           // LDS-DMA variants have no K-edge zero fill
   const bool big = dma_ok && p.M > 128;
@@ -1144,8 +1659,10 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   }
   if (forced) {
     int v = forced;
+    if (v == 11 && !v11_ok(p)) v = 8;
+    if (v == 12 && !v11_ok(p, 128)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
-    if (v != 1 && v != 7 && v != 8) v = 7;
+    if (v != 1 && v != 7 && v != 8 && v != 11 && v != 12) v = 7;
     return launch_variant(v, p, stream);
   }
   if (!big || p.N <= 128) return launch_variant(7, p, stream);
@@ -1153,12 +1670,14 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
-    const int cands[4] = {7, 7 + 16, 8, 8 + 16};   // variant | (tile_order << 4)
+    const int cands[6] = {7, 7 + 16, 8, 8 + 16, 11, 12};   // variant | (tile_order << 4)
     float best_ms = 1e30f;
     int best = 7;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_variant(7, p, stream);
     for (int c : cands) {
+      if ((c & 15) == 11 && !v11_ok(p)) continue;
+      if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;
       hipError_t e = launch_variant(c & 15, q, stream);  // warm

@@ -61,6 +61,16 @@ def main():
     lib.kmb_debug_set_stamps(None)
     s = stamps.cpu().numpy().astype(np.int64)
     s = s[s[:, 0] != 0]  # the 256x256 variants launch a quarter of the workgroups
+    if os.environ["KMB_GEMM_VARIANT"] == "11":   # persistent kernel: totals per workgroup over its tiles
+        tick = 0.01
+        ntile = ((M + 255) // 256) * ((N + 255) // 256)
+        print(f"v11 M={M} N={N} K={K} workgroups={len(s)} tiles={ntile} ({ntile / len(s):.2f} per workgroup) "
+              f"kernel span {(s[:, 4].max() - s[:, 0].min()) * tick:.1f} us")
+        for name, v in (("prologue", s[:, 1] - s[:, 0]), ("k_loops (sum)", s[:, 2]), ("  of which wait+barrier", s[:, 5]),
+                        ("epilogues (sum)", s[:, 3]), ("store drain (sum)", s[:, 6]), ("whole workgroup", s[:, 4] - s[:, 0])):
+            v = v * tick
+            print(f"  {name:24s} median {np.median(v):7.2f}  p10 {np.percentile(v, 10):7.2f}  p90 {np.percentile(v, 90):7.2f} us")
+        return
     tiles = len(s)
     t0 = s[:, 0].min()
     tick = 0.01  # us

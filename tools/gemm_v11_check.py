@@ -1,0 +1,118 @@
+"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128) against the 128x128 variant 7 on every epilogue class and operand layout:
+outputs must be bit-identical (same per-element accumulation order), column sums equal after folding their partial
+rows.  Also prints the time of each variant per case.  Re-runs itself once per variant (the variant is a per-process
+environment choice).
+
+    python tools/gemm_v11_check.py            # compare 7 and 11 (and time 8)
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "km-bart_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = [
+    # name, M, N, K, a_kc, b_kc, options
+    ("fwd_bias", 8192, 2304, 768, True, True, dict(bias=True, qscale=True)),
+    ("fwd_gelu_preact", 8192, 3072, 768, True, True, dict(bias=True, act=1, preact=True)),
+    ("fwd_res_drop", 32768, 768, 3072, True, True, dict(bias=True, residual=True, drop=0.1)),
+    ("dgrad_gelugrad_cs", 8192, 3072, 768, True, False, dict(act=2, aux=True, colsum=True)),
+    ("dgrad_gelugrad", 8192, 3072, 768, True, False, dict(act=2, aux=True)),
+    ("dgrad_cs", 16384, 1536, 768, True, False, dict(colsum=True)),
+    ("dgrad_res_cs", 16384, 1536, 768, True, False, dict(colsum=True, residual=True)),
+    ("wgrad_layout_edges", 20000, 1000, 256, False, False, dict(f32=True)),
+    ("lm_head_f32_edges", 8192, 50320, 768, True, True, dict(bias=True, f32=True, ld_f32=50432)),
+    ("fwd_edges_rows", 16300, 1024, 512, True, True, dict(bias=True, residual=True)),
+    ("tanh_generic", 8192, 2048, 768, True, True, dict(bias=True, act=3)),
+    ("k128", 8192, 2048, 128, True, True, dict(bias=True)),
+]
+
+
+def run_variant():
+    import torch
+    from gpu_util import DEV, bf, gemm
+    out = {}
+    for ci, (name, M, N, K, akc, bkc, o) in enumerate(CASES):
+        g = torch.Generator(device=DEV).manual_seed(100 + ci)
+        rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+        A = bf(rn(M, K) if akc else rn(K, ((M + 7) // 8) * 8)) * 0.5
+        B = bf(rn(N, K) if bkc else rn(K, ((N + 7) // 8) * 8)) * 0.5
+        kw = dict(a_kc=akc, b_kc=bkc, M=M, N=N, K=K)
+        if o.get("bias"):
+            kw["bias"] = rn(N)
+        if o.get("qscale"):
+            kw["col_scale"], kw["col_scale_n"] = 0.125, 768
+        kw["act"] = o.get("act", 0)
+        Np = ((N + 7) // 8) * 8
+        if o.get("preact"):
+            kw["preact"] = torch.zeros(M, Np, dtype=torch.bfloat16, device=DEV)
+        if o.get("aux"):
+            kw["aux"] = bf(rn(M, Np))
+        if o.get("residual"):
+            kw["residual"] = bf(rn(M, Np))
+        if o.get("drop"):
+            kw["drop_p"], kw["drop_seed"] = o["drop"], 1234
+        nparts = (M + 63) // 64
+        if o.get("colsum"):
+            kw["colsum"] = torch.full((nparts, N), 7.0, dtype=torch.float32, device=DEV)
+        if o.get("f32"):
+            ld = o.get("ld_f32", ((N + 3) // 4) * 4)
+            kw["out_f32"] = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
+        else:
+            kw["out_bf16"] = torch.zeros(M, Np, dtype=torch.bfloat16, device=DEV)
+        gemm(A, B, **kw)
+        torch.cuda.synchronize()
+        rec = {}
+        for k in ("out_bf16", "out_f32", "preact"):
+            if kw.get(k) is not None:
+                rec[k] = hashlib.md5(kw[k].cpu().view(torch.uint8).numpy().tobytes()).hexdigest()[:16]
+        if kw.get("colsum") is not None:
+            rec["colsum"] = kw["colsum"].sum(0).cpu().tolist()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            gemm(A, B, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        rec["us"] = e0.elapsed_time(e1) * 100.0
+        rec["tflops"] = 2.0 * M * N * K / rec["us"] * 1e-6
+        out[name] = rec
+        del A, B, kw
+    print("JSON" + json.dumps(out))
+
+
+def main():
+    if os.environ.get("KMB_V11_CHILD"):
+        return run_variant()
+    res = {}
+    for v in ("7", "8", "11", "12"):
+        env = dict(os.environ, KMB_GEMM_VARIANT=v, KMB_V11_CHILD="1")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("JSON")]
+        if r.returncode != 0 or not line:
+            print("variant", v, "failed:\n", r.stdout[-2000:], r.stderr[-3000:])
+            sys.exit(1)
+        res[v] = json.loads(line[0][4:])
+    bad = 0
+    for name, *_ in CASES:
+        a, c = res["7"][name], res["8"][name]
+        line = f"{name:20s} v7 {a['us']:7.1f} us {a['tflops']:5.0f} TF | v8 {c['us']:7.1f} us {c['tflops']:5.0f} TF"
+        for v in ("11", "12"):
+            b = res[v][name]
+            ok = all(a[k] == b[k] for k in a if k not in ("us", "tflops", "colsum"))
+            d = 0.0
+            if "colsum" in a:
+                d = max(abs(x - y) / (abs(x) + 1.0) for x, y in zip(a["colsum"], b["colsum"]))
+                ok = ok and d < 1e-3
+            bad += not ok
+            line += f" | v{v} {b['us']:7.1f} us {b['tflops']:5.0f} TF {'same bits' if ok else 'MISMATCH'}" + (f" (colsum rel {d:.1e})" if d else "")
+        print(line, flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
