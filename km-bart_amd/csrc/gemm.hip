@@ -974,7 +974,7 @@ __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][8
 // blocks with a bf16 output only; same operation order as gemm_epilogue_body (bit-identical results).
 //   BIAS: + bias[col];  SCALE: * col_scale (the whole wave block lies in the scaled columns);  ACT 1: GeLU (+ optional
 //   pre-activation store), 2: * GeLU'(aux);  DROP: dropout mask;  RES: + residual;  CS: column sums.
-template <bool BIAS, bool SCALE, int ACT, bool RES, bool DROP, bool CS, int WROWS>
+template <bool BIAS, bool SCALE, int ACT, bool RES, bool DROP, bool CS, int WROWS, bool F32 = false>
 __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)[8][8], float* ef, int lane, int r, int g,
                                                   int row0w, int col0w) {
   const int lr = lane >> 4, c8 = (lane & 15) * 8;
@@ -999,7 +999,8 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 #pragma unroll
   for (int it = 0; it < 4; ++it) rd[it] = ef + (lr + 4 * it) * 128 + (c8 ^ (((lr + 4 * it) & 7) << 3));
   // row pointers of this lane's first row; a row-iteration is 4 rows further, a chunk 16
-  bf16_t* out = p.out_bf16 + (size_t)(row0w + lr) * p.ld_out_bf16 + gcol;
+  bf16_t* out = F32 ? nullptr : p.out_bf16 + (size_t)(row0w + lr) * p.ld_out_bf16 + gcol;
+  float* out32 = F32 ? p.out_f32 + (size_t)(row0w + lr) * p.ld_out_f32 + gcol : nullptr;   // fp32 logits (ld % 4 == 0)
   bf16_t* pre = (ACT == 1 && p.preact != nullptr) ? p.preact + (size_t)(row0w + lr) * p.ld_preact + gcol : nullptr;
   const bf16_t* side = nullptr;   // residual (RES) or GeLU' argument (ACT 2): one 16-byte load per row
   size_t ld_side = 0;
@@ -1016,9 +1017,8 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
       s1[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 + 4 * it) * ld_side);
     }
   }
-#pragma unroll 1
-  for (int i = 0; i < WROWS / 16; ++i) {
-    switch (i) {
+  auto stage_chunk = [&](int i) {
+    switch (i) {   // static accumulator indices in every arm (a run-time index would put acc in scratch)
       case 0: stage(acc[0]); break;
       case 1: stage(acc[1]); break;
       case 2: stage(acc[2]); break;
@@ -1028,6 +1028,20 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
       case 6: stage(acc[6]); break;
       default: stage(acc[7]); break;
     }
+  };
+  stage_chunk(0);
+#pragma unroll 1
+  for (int i = 0; i < WROWS / 16; ++i) {
+    // this chunk's rows out of LDS first, then the next chunk's accumulators into the same image: the LDS executes
+    // a wave's accesses in order, so the writes queue behind the reads and their latency hides under this chunk's math
+    f32x4 lo4[4], hi4[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      lo4[it] = *reinterpret_cast<const f32x4*>(rd[it]);
+      hi4[it] = *reinterpret_cast<const f32x4*>(rd[it] + 4);
+    }
+    asm volatile("" ::: "memory");
+    if (i + 1 < WROWS / 16) stage_chunk(i + 1);
     if (SIDE) {
       const int ahead = i + 2 < WROWS / 16 ? i + 2 : WROWS / 16 - 1;   // the last two chunks re-read rows that are in cache (never used)
 #pragma unroll
@@ -1035,8 +1049,8 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(rd[it]);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(rd[it] + 4);
+      const f32x4 lo = lo4[it];
+      const f32x4 hi = hi4[it];
       kmb_f32x2 v[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1076,8 +1090,14 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 #pragma unroll
         for (int e = 0; e < 4; ++e) csum2[e] = csum2[e] + v[e];
       }
-      const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
-      __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16));
+      if (F32) {
+        float* o = out32 + roff * p.ld_out_f32;
+        __builtin_nontemporal_store(f32x4{v[0][0], v[0][1], v[1][0], v[1][1]}, reinterpret_cast<f32x4*>(o));
+        __builtin_nontemporal_store(f32x4{v[2][0], v[2][1], v[3][0], v[3][1]}, reinterpret_cast<f32x4*>(o + 4));
+      } else {
+        const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
+        __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16));
+      }
     }
     if (SIDE) {
 #pragma unroll
@@ -1122,12 +1142,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tiles_n = (p.N + BNT - 1) / BNT;
   const int ntiles = ((p.M + BM4 - 1) / BM4) * tiles_n;
   // this workgroup's tiles: XCD x owns a contiguous range, its workgroups take every (grid/8)-th tile of it
-  const int per = (int)gridDim.x >> 3;
+  // (tile_order bit 0; without it workgroup b simply takes tiles b, b + grid, ...: better when C dominates the traffic)
+  const bool xcd_ranges = (p.tile_order & 1) != 0;
+  const int per = xcd_ranges ? (int)gridDim.x >> 3 : (int)gridDim.x;
   const int xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
   const int tq = ntiles >> 3, trem = ntiles & 7;
-  const int range0 = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
-  const int range1 = range0 + tq + (xcd < trem ? 1 : 0);
-  const int first = range0 + loc;
+  const int range0 = !xcd_ranges ? 0 : xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
+  const int range1 = !xcd_ranges ? ntiles : range0 + tq + (xcd < trem ? 1 : 0);
+  const int first = xcd_ranges ? range0 + loc : (int)blockIdx.x;
   if (first >= range1) return;
   {  // experiment knob (tile_order bits 12-15): start the workgroups of an XCD in 8 phases, 0.24 us x knob apart
     const int stag = (p.tile_order >> 12) & 15;
@@ -1324,7 +1346,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const bool lean_ok = interior && p.out_bf16 != nullptr && p.out_f32 == nullptr && (p.tile_order & 256) == 0 &&
                            (p.col_scale_n <= 0 || (p.col_scale_n & 127) == 0);
 #define KMB_LEAN(B, S, A, R, D, C) v11_epilogue_lean<B, S, A, R, D, C, WROWS>(p, acc, ef, lane, r, g, row0w, col0w)
-      if (lean_ok && p.act == 0 && hb && !hr && !hd && !hc) {
+      if (interior && p.out_f32 != nullptr && p.out_bf16 == nullptr && p.beta == 0.f && (p.ld_out_f32 & 3) == 0 &&
+          (p.tile_order & 256) == 0 && p.act == 0 && hb && !hr && !hd && !hc && p.col_scale_n <= 0) {
+        v11_epilogue_lean<true, false, 0, false, false, false, WROWS, true>(p, acc, ef, lane, r, g, row0w, col0w);   // logits
+      } else if (lean_ok && p.act == 0 && hb && !hr && !hd && !hc) {
         if (hs) KMB_LEAN(true, true, 0, false, false, false);
         else KMB_LEAN(true, false, 0, false, false, false);
       } else if (lean_ok && p.act == 0 && hb && hr && !hc && !hs) {
@@ -1670,7 +1695,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
-    const int cands[6] = {7, 7 + 16, 8, 8 + 16, 11, 12};   // variant | (tile_order << 4)
+    const int cands[8] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16};   // variant | (tile_order << 4)
     float best_ms = 1e30f;
     int best = 7;
     hipEvent_t e0, e1;
