@@ -296,7 +296,7 @@ def main():
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per GEMM launch",
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_n, 1)),
-            "kernel": "gemm_kernel_v7/v8<A_KC,B_KC> (all GEMM launches of a step, timed serially)",
+            "kernel": "gemm_kernel_v7 / v8 / v11<A_KC,B_KC[,256|128]> (all GEMM launches of a step, timed serially)",
             "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
             "gemm_ms_per_step": round(tot_ms / n_prof, 3),
             "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),

@@ -889,6 +889,14 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 // Tiles are dealt per XCD in contiguous ranges (neighbours share A/B panels in that XCD's L2).  Same LDS images,
 // swizzles and per-element accumulation order as v7/v8: bit-identical sums.  No split-K (the weight gradients stay
 // on v7/v8).
+// Measured (tools/gemm_stamps.py, 16384 x 3072 x 768, three tiles per workgroup): prologue 2.7 us once, K loop
+// 1.62 us per 64-deep step = 1.33 PFLOP/s (the same as v8: the LDS-bandwidth argument did not move it; what the step
+// pays beside its 128 x 16 MFMA cycles is the issue cost of its 16 LDS-DMA pieces and 32 ds_reads, which one wave per
+// SIMD cannot hide behind a 16-cycle MFMA), epilogue 3.75 us per tile = 128 KB at ~14 B/clk/CU -- the CU's store-issue
+// rate for 16-byte stores, unchanged by skipping the LDS round trip latency (software-pipelined staging), by
+// non-temporal stores or by starting the workgroups of an XCD up to 12 us apart (no HBM burst limit at this size).
+// Whole kernel 77 us against 90 us for v8; the vendor library's stream-K kernel (256 workgroups x 256 threads,
+// 256x256x64, tools/gemm_yardstick.py) takes 70.5 us per call in a back-to-back loop on this shape.
 template <bool KC>
 __device__ __forceinline__ void dma_offsets256w4(uint32_t (&off)[8], int ld, int r0, int R, int wave, int lane) {
 #pragma unroll
@@ -1151,10 +1159,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int range1 = !xcd_ranges ? ntiles : range0 + tq + (xcd < trem ? 1 : 0);
   const int first = xcd_ranges ? range0 + loc : (int)blockIdx.x;
   if (first >= range1) return;
-  {  // experiment knob (tile_order bits 12-15): start the workgroups of an XCD in 8 phases, 0.24 us x knob apart
-    const int stag = (p.tile_order >> 12) & 15;
-    for (int i = 0; i < stag * (loc & 7); ++i) __builtin_amdgcn_s_sleep(9);
-  }
 
   const int nt = p.K / BK;   // >= 2 (launcher)
   constexpr int A_BYTES = BM4 * BK * 2;
@@ -1707,12 +1711,16 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       q.tile_order = c >> 4;
       hipError_t e = launch_variant(c & 15, q, stream);  // warm
       if (e != hipSuccess) return e;
-      (void)hipEventRecord(e0, stream);
-      for (int rep = 0; rep < 3; ++rep) (void)launch_variant(c & 15, q, stream);
-      (void)hipEventRecord(e1, stream);
-      if (hipEventSynchronize(e1) != hipSuccess) return hipGetLastError();
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, e0, e1);
+      float ms = 1e30f;
+      for (int round = 0; round < 2; ++round) {   // best of two timed rounds of three launches (one noisy round used
+        (void)hipEventRecord(e0, stream);         // to flip close choices from run to run)
+        for (int rep = 0; rep < 3; ++rep) (void)launch_variant(c & 15, q, stream);
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess) return hipGetLastError();
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        ms = t < ms ? t : ms;
+      }
       if (verbose) fprintf(stderr, "[kmb gemm tune] akc=%d bkc=%d M=%d N=%d K=%d split=%d act=%d v%d order%d %.1f us\n",
                            p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act, c & 15, c >> 4, ms / 3 * 1e3);
       if (ms < best_ms) { best_ms = ms; best = c; }

@@ -19,3 +19,8 @@ timeout 300 python tools/gemm_shape_table.py 512 2>&1 | grep -v amdgpu > gpurun_
 timeout 300 python tools/gen_bench.py 2>&1 | grep -v amdgpu > gpurun_out/r3_gen_bench.log
 tail -1 gpurun_out/r3_bench_default.log | cut -c1-300
 ls gpurun_out/pmc_fetch gpurun_out/pmc_write
+#   6. in-kernel GEMM timelines (diagnostic library, built beforehand with `python tools/gemm_stamps.py --build`),
+#      library yardstick on the measured shape table
+( for v in 7 8 11; do echo "== KMB_GEMM_VARIANT=$v"; for shp in "16384 3072 768" "4096 4096 4096"; do KMB_GEMM_VARIANT=$v timeout 100 python tools/gemm_stamps.py $shp 2>&1 | grep -v amdgpu; done; done ) > gpurun_out/r3_gemm_stamps.txt
+timeout 300 python tools/gemm_yardstick.py gpurun_out/r3_gemm_shapes_b512.txt 2>/dev/null > gpurun_out/r3_yardstick.txt
+timeout 200 python tools/pretrain_bench.py --batch 384 2>&1 | grep -v amdgpu | tail -3 > gpurun_out/r3_pretrain.log
