@@ -187,6 +187,12 @@ int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const floa
 int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream);
 int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
 
+/* Data-parallel runs share the GPU between the GEMMs and RCCL's all-reduce kernel (reference: torch DDP's NCCL streams,
+ * vcg_train.py:98).  The persistent GEMM variants keep one workgroup per CU; with on != 0 they hand out EVERY tile through
+ * an atomic counter, so workgroups that cannot be placed while the communication kernel holds CUs leave no work behind.
+ * Process-wide; results do not depend on it. */
+int kmb_gemm_shared_device(int on);
+
 /* ================= measurement ================= */
 /* time every GEMM launch of the following calls with HIP events on its own stream (bench.py roofline leg);
  * variant = a_kc*2 + b_kc: 3 forward (X W^T), 2 dgrad (dY W), 0 wgrad (dY^T X) */

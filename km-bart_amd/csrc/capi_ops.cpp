@@ -106,6 +106,10 @@ int kmb_op_dropout_mask(uint32_t seed, float p, int rows, int cols, uint8_t* kee
   if (thr > 65535u) thr = 65535u;
   return hipfail(kmb_dropout_mask_launch(seed, thr, rows, cols, keep, (hipStream_t)stream), "dropout_mask");
 }
+int kmb_gemm_shared_device(int on) {
+  kmb_gemm_set_shared_device(on);
+  return 0;
+}
 int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream) {
   return hipfail(kmb_beam_merge_launch(val, idx, B, num_beams, k, V, out, (hipStream_t)stream), "beam_merge");
 }

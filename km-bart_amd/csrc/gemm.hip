@@ -58,6 +58,8 @@ extern "C" int kmb_debug_set_stamps(void* p) {
 
 namespace {
 
+int g_shared_device = 0;   // kmb_gemm_shared_device(): other kernels (RCCL) hold CUs while the GEMMs run
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;  // 32 KB
 constexpr int EPI_LD = BN + 4;                        // fp32 staging row stride
@@ -1135,7 +1137,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 // BNT = 256: waves 2x2, each 128x128.  BNT = 128 (variant 12): waves 4x1, each 64x128 -- twice as many tiles, for shapes
 // whose 256x256 tile count is not a multiple of the 256 workgroups (N = 768: 1.5 tiles per workgroup -> 3).
 template <bool A_KC, bool B_KC, int BNT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_kernel_v11(const KmbGemm p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KMB_STAMP(0);
   KMB_STAMP_ID();
@@ -1158,7 +1160,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int range0 = !xcd_ranges ? 0 : xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
   const int range1 = !xcd_ranges ? ntiles : range0 + tq + (xcd < trem ? 1 : 0);
   const int first = xcd_ranges ? range0 + loc : (int)blockIdx.x;
-  if (first >= range1) return;
+  // Tiles after the first are handed out by an atomic counter (per XCD range, or one for the whole grid): a workgroup
+  // that gets its CU late -- another kernel's workgroups, e.g. an RCCL all-reduce on the communication stream, hold
+  // some CUs -- simply takes fewer tiles instead of leaving its fixed share to a second round.  sched[0..7] tile
+  // counters, sched[8] finished workgroups; the last one to finish zeroes them for the next launch using this slot.
+  const bool dyn = sched != nullptr;
+  uint32_t* const my_ctr = sched + (xcd_ranges ? xcd : 0);
+  auto retire = [&]() {
+    if (dyn && tid == 0) {
+      if (atomicAdd(sched + 8, 1u) == gridDim.x - 1u) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sched[i] = 0u;
+      }
+    }
+  };
+  int* const next_slot = reinterpret_cast<int*>(smem + 2 * STG);   // word 0 of wave 0's epilogue staging (idle in the K loop)
+  uint32_t fetched = 0u;
+  // dyn_first (the GPU is shared with a communication kernel: kmb_gemm_shared_device): the first tile comes from the
+  // counter too, so a workgroup that is placed late finds nothing left and exits instead of holding the launch open
+  // for its fixed first tile; costs one atomic round trip (~2 us) before the prologue.
+  const int dyn_base = (dyn && dyn_first) ? range0 : range0 + per;
+  int first_tile = first;
+  if (dyn && dyn_first) {
+    if (tid == 0) *next_slot = range0 + (int)atomicAdd(my_ctr, 1u);
+    __syncthreads();
+    first_tile = __builtin_amdgcn_readfirstlane(*next_slot);
+    __syncthreads();
+  }
+  if (first_tile >= range1) { retire(); return; }
 
   const int nt = p.K / BK;   // >= 2 (launcher)
   constexpr int A_BYTES = BM4 * BK * 2;
@@ -1174,7 +1203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- DMA cursor: (tile, K step) of the next stage to fetch; runs two steps ahead of the MFMAs ----
   uint32_t offA[8], offB[NPB];
   const char *gA_d, *gB_d;
-  int tile_d = first, td = 0;
+  int tile_d = first_tile, td = 0;
   auto set_dma_tile = [&](int tile) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int row0 = tm * BM4, col0 = tn * BNT;
@@ -1184,10 +1213,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     gA_d = uniform_ptr(reinterpret_cast<const char*>(p.A) + (A_KC ? (size_t)row0 * p.lda * 2 : (size_t)row0 * 2));
     gB_d = uniform_ptr(reinterpret_cast<const char*>(p.B) + (B_KC ? (size_t)col0 * p.ldb * 2 : (size_t)col0 * 2));
   };
+  int tile_next = first_tile;   // the tile after the one being multiplied; known once the DMA cursor reaches it
   auto advance_cursor = [&]() {   // before a fetch: step to the next tile when this one's K steps are all issued
     if (td == nt) {
       td = 0;
-      if (tile_d + per < range1) tile_d += per;   // past the last tile: fetch its first steps again (never read)
+      tile_next = dyn ? __builtin_amdgcn_readfirstlane(*next_slot) : tile_d + per;
+      if (tile_next < range1) tile_d = tile_next;   // past the last tile: fetch its first steps again (never read)
       set_dma_tile(tile_d);
     }
   };
@@ -1237,13 +1268,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   float* const ef = reinterpret_cast<float*>(smem + 2 * STG + wave * EPW_BYTES);
   int it = 0;   // linear K-step counter: stage buffer = it & 1
-  for (int tile = first; tile < range1; tile += per) {
+  for (int tile = first_tile; tile < range1; tile = tile_next) {
+    if (dyn && tid == 0) fetched = atomicAdd(my_ctr, 1u);   // lands by the first K step's vmcnt(0)
 #pragma unroll
     for (int i = 0; i < MH * 4; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] const uint64_t kmb_t_loop = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < nt; ++t, ++it) {
+      // publish the next tile to the other waves: written in step 1, behind step 1's barrier when the cursor reads it
+      // in step nt - 2 >= 2 (the launcher hands out a counter only when nt >= 4)
+      if (dyn && t == 1 && tid == 0) *next_slot = dyn_base + (int)fetched;
       advance_cursor();
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): k0 fragments of this stage (needed now anyway; a known-empty
                                            // LDS queue here lets the compiler count the waits below exactly)
@@ -1386,6 +1421,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   KMB_STAMP_VALUE(6, kmb_drain_ticks);
   KMB_STAMP(4);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the two look-ahead fetches past the last tile target this LDS
+  retire();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1543,6 +1579,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
 
 }  // namespace
 
+void kmb_gemm_set_shared_device(int on) { g_shared_device = on ? 1 : 0; }
+
 const char* kmb_gemm_check(const KmbGemm& p) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return "gemm: empty problem";
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return "gemm: operand not 16-byte aligned";
@@ -1568,19 +1606,37 @@ const char* kmb_gemm_check(const KmbGemm& p) {
 
 namespace {
 
-// variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256
+// Tile counters of the persistent variants: 64 slots of 16 words per device, zeroed once; a launch takes the next slot
+// and its last workgroup leaves it zeroed again (kernels of one stream are ordered, a handful overlap across streams).
+uint32_t* v11_sched_slot() {
+  constexpr int NSLOT = 64, MAXDEV = 16;
+  static uint32_t* base[MAXDEV] = {};
+  static unsigned seq[MAXDEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  if (!base[dev]) {
+    if (hipMalloc(&base[dev], NSLOT * 16 * sizeof(uint32_t)) != hipSuccess) { base[dev] = nullptr; return nullptr; }
+    if (hipMemset(base[dev], 0, NSLOT * 16 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+  }
+  return base[dev] + (size_t)(seq[dev]++ % NSLOT) * 16;
+}
+
+// variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256;
+// 11 / 12: persistent 256x256 / 256x128
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   if (variant == 11) {
     dim3 grid(256), block(256);
-    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 256>), grid, block, LDS11, stream, p);
-    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 256>), grid, block, LDS11, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 256>), grid, block, LDS11, stream, p);
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
   } else if (variant == 12) {
     dim3 grid(256), block(256);
-    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 128>), grid, block, LDS12, stream, p);
-    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 128>), grid, block, LDS12, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 128>), grid, block, LDS12, stream, p);
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
+    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
   } else if (variant == 8) {
     const int tiles = ((p.M + BM4 - 1) / BM4) * ((p.N + BN4 - 1) / BN4);
     dim3 grid(tiles * nsl), block(512);

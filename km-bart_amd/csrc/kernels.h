@@ -10,6 +10,7 @@ typedef uint16_t bf16_t;
 // ------------------------------------------------------------------ gemm.hip
 const char* kmb_gemm_check(const KmbGemm& p);
 hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream);
+void kmb_gemm_set_shared_device(int on);   // persistent variants: hand out every tile dynamically
 
 // ------------------------------------------------------------- attention.hip
 hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream);

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "kmb_gemm_shared_device": (C.c_int, [C.c_int]),
     "kmb_set_side_stream": (C.c_int, [c_p, C.c_int]),
     "kmb_profile_gemm": (C.c_int, [C.c_int]),
     "kmb_profile_read": (C.c_int, [C.c_int, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),

@@ -104,8 +104,17 @@ class DistributedDataParallel(torch.nn.Module):
                 wait_ready=lambda i, stream: eng.stream_wait_bucket(i, stream), comm_stream=comm,
                 max_bucket_elems=max_bucket_mb * (1 << 20) // 4, always=reduce_single_rank)
             module._post_backward = self._reduce
+            # RCCL's kernel holds CUs while backward runs: the persistent GEMMs hand out every tile dynamically
+            from . import _lib
+            _lib.load().kmb_gemm_shared_device(1)
+            self._first_reduce = True
 
     def _reduce(self):
+        if self._first_reduce:
+            # the first backward times the GEMM variants of every shape (autotune): keep the all-reduces out of it
+            self._first_reduce = False
+            if self.reducer.comm_stream is not None:
+                self.reducer.comm_stream.wait_stream(torch.cuda.current_stream())
         self.reducer.launch()
         self.reducer.finish()
 
