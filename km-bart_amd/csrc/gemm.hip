@@ -748,13 +748,17 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
   };
-  auto dma_stage = [&](int ks, int stage_buf) {
+  // a stage is fetched in two halves one sub-phase apart: an LDS-DMA piece costs the issuing wave 60-180 cycles, and all
+  // of a stage's pieces in sub-phase 3 made that sub-phase as long as two others (measured on v11: K loop -11 %)
+  auto dma_a = [&](int ks, int stage_buf) {
     char* da = dstA + stage_buf * ST4;
-    char* db = dstB + stage_buf * ST4;
     const char* ga = uniform_ptr(gA + (size_t)ks * stepA);
-    const char* gb = uniform_ptr(gB + (size_t)ks * stepB);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_piece(ga, offA[i], da + i * 1024);
+  };
+  auto dma_b = [&](int ks, int stage_buf) {
+    char* db = dstB + stage_buf * ST4;
+    const char* gb = uniform_ptr(gB + (size_t)ks * stepB);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_piece(gb, offB[i], db + i * 1024);
   };
@@ -779,10 +783,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
         acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[half * 4 + i][j], 0, 0, 0);
   };
 
-  dma_stage(0, 0);
+  dma_a(0, 0);
+  dma_b(0, 0);
   if (nt > 1) {
-    dma_stage(1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): stage 0 has landed
+    dma_a(1, 1);                         // its B half goes out in the first K step's sub-phase 0
+    __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4): stage 0 has landed
   } else {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   }
@@ -796,12 +801,27 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
     const char* nxt = smem + ((t + 1) & 1) * ST4;
     // ---- sub-phase 0 ----
     read_a(cur, 0, 1, fa[1]);
+    if (decltype(do_next)::value) dma_b(t + 1, (t + 1) & 1);   // B half of stage t+1 (its A half: previous sub-phase 3)
     mma(0, fa[0], fb[0]);
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if (decltype(do_next)::value) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x100, NDA / 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NDA / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NDA / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- sub-phase 1 ----
@@ -832,7 +852,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
       read_b(nxt, 0, fb[0]);
       read_a(nxt, 0, 0, fa[0]);
     }
-    if (decltype(do_dma)::value) dma_stage(t + 2, t & 1);
+    if (decltype(do_dma)::value) dma_a(t + 2, t & 1);
     mma(1, fa[1], fb[1]);
     if (decltype(do_next)::value && decltype(do_dma)::value) {
       __builtin_amdgcn_sched_group_barrier(0x100, NDB, 3);
@@ -840,9 +860,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 3);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 3);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 2; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 3);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 3);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 3);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1224,17 +1244,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   char* const dstA = smem + wave * 8192;
   char* const dstB = smem + A_BYTES + wave * (NPB * 1024);
-  auto dma_stage = [&](int buf) {
+  // A stage's fetch is issued in two halves, one sub-phase apart (an LDS-DMA piece costs the issuing wave 60-180
+  // cycles; sixteen of them in one 32-MFMA sub-phase made that sub-phase as long as the other three together)
+  // (128-row wave blocks) where the 8 A and 8 B pieces of a stage go: A pieces [0, NA3) in sub-phase 3, the rest in the
+  // next step's sub-phase 0; B pieces [0, NB3) in sub-phase 3, [NB3, NB3 + NB0) in sub-phase 0, the rest in sub-phase 1
+#ifndef KMB_V11_SPLIT
+#define KMB_V11_SPLIT 1
+#endif
+  constexpr int NA3 = KMB_V11_SPLIT == 3 ? 4 : 8;
+  constexpr int NB3 = KMB_V11_SPLIT == 0 ? 8 : 0;
+  constexpr int NB0 = KMB_V11_SPLIT == 0 ? 0 : KMB_V11_SPLIT == 2 ? 4 : 8;
+  constexpr int NB1 = 8 - NB3 - NB0;
+  constexpr int P3 = (NA3 + NB3) / 2, P0 = (8 - NA3 + NB0) / 2, P1 = NB1 / 2;   // pairs of pieces per sub-phase
+  auto dma_a = [&](int buf, int lo, int hi) {
     char* da = dstA + buf * STG;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i >= lo && i < hi) dma_piece(gA_d, offA[i], da + i * 1024);
+    if (hi == 8 && lo < hi) gA_d = uniform_ptr(gA_d + stepA);
+  };
+  auto dma_b = [&](int buf, int lo, int hi) {
     char* db = dstB + buf * STG;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(gA_d, offA[i], da + i * 1024);
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) dma_piece(gB_d, offB[i], db + i * 1024);
-    gA_d = uniform_ptr(gA_d + stepA);
-    gB_d = uniform_ptr(gB_d + stepB);
-    ++td;
+    for (int i = 0; i < NPB; ++i)
+      if (i >= lo && i < hi) dma_piece(gB_d, offB[i], db + i * 1024);
+    if (hi == NPB && lo < hi) {
+      gB_d = uniform_ptr(gB_d + stepB);
+      ++td;
+    }
   };
+  auto dma_stage_a = [&](int buf) { dma_a(buf, 0, 8); };
+  auto dma_stage_b = [&](int buf, int) { dma_b(buf, 0, NPB); };
 
   constexpr int NDA = A_KC ? 4 : 8;    // ds_read instructions per 4 A fragments
   constexpr int NDB = B_KC ? 8 : 16;   // ... per 8 B fragments
@@ -1257,10 +1297,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   set_dma_tile(tile_d);
-  dma_stage(0);
+  dma_stage_a(0);
+  dma_stage_b(0, 2);
   advance_cursor();
-  dma_stage(1);
-  __builtin_amdgcn_s_waitcnt(BNT == 256 ? 0x4F70 : 0x0F7C);  // vmcnt(16 | 12) = the pieces of stage 1: stage 0 has landed
+  // (128-row wave blocks) stage 1's sub-phase-3 share now, the rest in the first K step's sub-phases 0 and 1
+  if constexpr (MH == 1) {
+    dma_stage_a(1);
+    dma_stage_b(1, 2);
+    __builtin_amdgcn_s_waitcnt(0x0F7C);   // vmcnt(12) = the pieces of stage 1: stage 0 has landed
+  } else {
+    dma_a(1, 0, NA3);
+    dma_b(1, 0, NB3);
+    __builtin_amdgcn_s_waitcnt(NA3 + NB3 == 16 ? 0x4F70 : NA3 + NB3 == 8 ? 0x0F78 : 0x0F74);   // vmcnt(16 | 8 | 4)
+  }
   __syncthreads();
   read_b(smem, 0, fb[0]);
   read_a(smem, 0, 0, fa[0]);
@@ -1279,7 +1328,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // publish the next tile to the other waves: written in step 1, behind step 1's barrier when the cursor reads it
       // in step nt - 2 >= 2 (the launcher hands out a counter only when nt >= 4)
       if (dyn && t == 1 && tid == 0) *next_slot = dyn_base + (int)fetched;
-      advance_cursor();
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): k0 fragments of this stage (needed now anyway; a known-empty
                                            // LDS queue here lets the compiler count the waits below exactly)
       const char* cur = smem + (it & 1) * STG;
@@ -1287,26 +1335,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (MH == 2) {
       // ---- sub-phase 0: A(k0, rows 0-63) x B(k0)  ||  read A(k0, rows 64-127) ----
       read_a(cur, 0, 1, fa[1]);
+      dma_a((it + 1) & 1, NA3, 8);            // the rest of the stage whose first pieces went out in the previous
+      dma_b((it + 1) & 1, NB3, NB3 + NB0);    // sub-phase 3
       mma(0, fa[0], fb[0]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x100, NDA / 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < P0; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 20 / (P0 > 0 ? P0 : 1), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- sub-phase 1: A(k0, rows 64-127) x B(k0)  ||  read B(k1), A(k1, rows 0-63) ----
       read_b(cur, 1, fb[1]);
       read_a(cur, 1, 0, fa[0]);
+      dma_b((it + 1) & 1, NB3 + NB0, 8);
       mma(1, fa[1], fb[0]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);   // MFMAs first: their operands were read a sub-phase ago
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);   // MFMAs first: their operands were read a sub-phase ago
       __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 5, 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 5, 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+#pragma unroll
+      for (int q = 0; q < P1; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 12 / (P1 > 0 ? P1 : 1), 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
+      advance_cursor();
       // ---- sub-phase 2: A(k1, rows 0-63) x B(k1)  ||  read A(k1, rows 64-127); stage it+1 landed, barrier ----
       read_a(cur, 1, 1, fa[1]);
       mma(0, fa[0], fb[1]);
@@ -1324,20 +1386,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // ---- sub-phase 3: A(k1, rows 64-127) x B(k1)  ||  read k0 of stage it+1, fetch stage it+2 into this buffer ----
       read_b(nxt, 0, fb[0]);
       read_a(nxt, 0, 0, fa[0]);
-      dma_stage(it & 1);
+      dma_a(it & 1, 0, NA3);
+      dma_b(it & 1, 0, NB3);
       mma(1, fa[1], fb[1]);
       __builtin_amdgcn_sched_group_barrier(0x100, NDB, 3);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 3);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 3);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 3);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < P3; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 3);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 3);
+        __builtin_amdgcn_sched_group_barrier(0x008, 24 / P3, 3);
       }
       __builtin_amdgcn_sched_barrier(0);
       } else {
       // 64-row wave block: two sub-phases of 32 MFMAs (fa[0] / fa[1] are the two K halves)
+      advance_cursor();
       // ---- sub-phase a: A(k0) x B(k0)  ||  read B(k1), A(k1) ----
       read_b(cur, 1, fb[1]);
       read_a(cur, 1, 0, fa[1]);
@@ -1360,7 +1424,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // ---- sub-phase b: A(k1) x B(k1)  ||  read k0 of stage it+1, fetch stage it+2 into this buffer ----
       read_b(nxt, 0, fb[0]);
       read_a(nxt, 0, 0, fa[0]);
-      dma_stage(it & 1);
+      dma_stage_a(it & 1);            // (the wait sits between this block's two sub-phases: one issue point only)
+      dma_stage_b(it & 1, 2);
       mma(0, fa[1], fb[1]);
       __builtin_amdgcn_sched_group_barrier(0x100, NDB, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
@@ -1368,7 +1433,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA): 8 + 4 pieces
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA): 4 + 8 pieces
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
       }
       __builtin_amdgcn_sched_barrier(0);

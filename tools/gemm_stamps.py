@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "km-bart_amd")
-STAMP_LIB = os.path.join(PKG, "lib", "libkmbart_hip_stamp.so")
+STAMP_LIB = os.environ.get("KMB_STAMP_LIB", os.path.join(PKG, "lib", "libkmbart_hip_stamp.so"))
 
 
 def build():

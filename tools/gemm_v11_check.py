@@ -117,7 +117,7 @@ def main():
     for name, *_ in CASES:
         a, c = res["7"][name], res["8"][name]
         line = f"{name:20s} v7 {a['us']:7.1f} us {a['tflops']:5.0f} TF | v8 {c['us']:7.1f} us {c['tflops']:5.0f} TF"
-        for v in ("11", "12", "11o1", "12o1", "11s", "12o1s"):
+        for v in ("8", "11", "12", "11o1", "12o1", "11s", "12o1s"):
             b = res[v][name]
             ok = all(a[k] == b[k] for k in a if k not in ("us", "tflops", "colsum"))
             d = 0.0
