@@ -234,7 +234,8 @@ KmbGemm lin_wgrad(const bf16_t* dy, int lddy, const bf16_t* x, int ldx, float* d
 int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
   const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
   const int nt = (g.K + 63) / 64;
-  int S = (384 + tiles - 1) / tiles;
+  int S = 512 / tiles;   // two 128x128 workgroups per CU; floor: a partial last round costs more than it fills
+                         // (tools/wgrad_split_sweep.py: 36 tiles S14 59 us vs S11 70 us, 72 tiles S7 97 vs S6 104)
   if (S > 16) S = 16;
   if (S > nt / 2) S = nt / 2;
   while (S > 1 && (size_t)S * g.M * g.N > h->slab_floats) --S;
@@ -355,7 +356,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   const size_t CH = Md < (size_t)h->lm_chunk ? Md : (size_t)h->lm_chunk;
   float* logits_c = bp.take<float>(CH * h->Vpad);
   bf16_t* dlogits_c = bp.take<bf16_t>(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
-  const size_t slab_floats = (size_t)8 << 20;           // split-K partial slabs of the weight-gradient GEMMs
+  const size_t slab_floats = (size_t)16 << 20;          // split-K partial slabs of the weight-gradient GEMMs
   float* slab = bp.take<float>(slab_floats);
   float* loss_rows = bp.take<float>(Md);
   bf16_t* dhdec = bp.take<bf16_t>(Md * d);
