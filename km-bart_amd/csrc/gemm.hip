@@ -911,14 +911,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 // Tiles are dealt per XCD in contiguous ranges (neighbours share A/B panels in that XCD's L2).  Same LDS images,
 // swizzles and per-element accumulation order as v7/v8: bit-identical sums.  No split-K (the weight gradients stay
 // on v7/v8).
-// Measured (tools/gemm_stamps.py, 16384 x 3072 x 768, three tiles per workgroup): prologue 2.7 us once, K loop
-// 1.62 us per 64-deep step = 1.33 PFLOP/s (the same as v8: the LDS-bandwidth argument did not move it; what the step
-// pays beside its 128 x 16 MFMA cycles is the issue cost of its 16 LDS-DMA pieces and 32 ds_reads, which one wave per
-// SIMD cannot hide behind a 16-cycle MFMA), epilogue 3.75 us per tile = 128 KB at ~14 B/clk/CU -- the CU's store-issue
-// rate for 16-byte stores, unchanged by skipping the LDS round trip latency (software-pipelined staging), by
-// non-temporal stores or by starting the workgroups of an XCD up to 12 us apart (no HBM burst limit at this size).
-// Whole kernel 77 us against 90 us for v8; the vendor library's stream-K kernel (256 workgroups x 256 threads,
-// 256x256x64, tools/gemm_yardstick.py) takes 70.5 us per call in a back-to-back loop on this shape.
+// Measured (tools/gemm_stamps.py, 16384 x 3072 x 768, three tiles per workgroup): prologue 2.7 us once; K loop
+// 1.62 us per 64-deep step with all 16 LDS-DMA pieces of a stage issued behind the barrier (the same 1.33 PFLOP/s as
+// v8: the LDS-bandwidth argument did not move it) and 1.51 us = 1.43 PFLOP/s with the stage issued in two halves a
+// sub-phase apart -- an LDS-DMA piece costs the issuing wave 60-180 cycles, which one wave per SIMD cannot hide behind
+// 16-cycle MFMAs; epilogue 3.75 us per tile = 128 KB at ~14 B/clk/CU -- the CU's store-issue rate for 16-byte stores,
+// unchanged by hiding the LDS round trip (software-pipelined staging), by non-temporal stores or by starting the
+// workgroups of an XCD up to 12 us apart (no HBM burst limit at this size).  Whole kernel 76-77 us against 90 us for
+// v8; the vendor library's stream-K kernel (256 workgroups x 256 threads, 256x256x64, tools/gemm_yardstick.py) takes
+// 70.5 us per call in a back-to-back loop on this shape.
 template <bool KC>
 __device__ __forceinline__ void dma_offsets256w4(uint32_t (&off)[8], int ld, int r0, int R, int wave, int lane) {
 #pragma unroll
@@ -1671,6 +1672,12 @@ const char* kmb_gemm_check(const KmbGemm& p) {
 
 namespace {
 
+// one workgroup per CU; fewer when there are fewer tiles (a multiple of 8: the per-XCD tile ranges)
+unsigned v11_grid(const KmbGemm& p, int bn) {
+  const long tiles = (long)((p.M + BM4 - 1) / BM4) * ((p.N + bn - 1) / bn);
+  return tiles >= 256 ? 256u : (unsigned)(tiles & ~7L);
+}
+
 // Tile counters of the persistent variants: 64 slots of 16 words per device, zeroed once; a launch takes the next slot
 // and its last workgroup leaves it zeroed again (kernels of one stream are ordered, a handful overlap across streams).
 uint32_t* v11_sched_slot() {
@@ -1691,13 +1698,13 @@ uint32_t* v11_sched_slot() {
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   if (variant == 11) {
-    dim3 grid(256), block(256);
+    dim3 grid(v11_grid(p, BN4)), block(256);
     uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
   } else if (variant == 12) {
-    dim3 grid(256), block(256);
+    dim3 grid(v11_grid(p, 128)), block(256);
     uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
@@ -1732,10 +1739,10 @@ struct TuneKey {
 };
 std::map<TuneKey, int> g_best;
 
-// v11 (persistent, one workgroup per CU): at least one 256x256 tile per CU, two K steps, no split-K
+// v11 (persistent, one workgroup per CU): enough tiles for half the CUs, two K steps, no split-K
 bool v11_ok(const KmbGemm& p, int bn = BN4) {
   const long tiles = (long)((p.M + BM4 - 1) / BM4) * ((p.N + bn - 1) / bn);
-  return p.split_k <= 1 && (p.K % BK) == 0 && p.K >= 2 * BK && tiles >= 256;
+  return p.split_k <= 1 && (p.K % BK) == 0 && p.K >= 2 * BK && tiles >= 128;   // at least half the CUs get a tile
 }
 
 bool writes_an_input(const KmbGemm& p) {

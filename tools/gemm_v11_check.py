@@ -29,6 +29,9 @@ CASES = [
     ("fwd_edges_rows", 16300, 1024, 512, True, True, dict(bias=True, residual=True)),
     ("tanh_generic", 8192, 2048, 768, True, True, dict(bias=True, act=3)),
     ("k128", 8192, 2048, 128, True, True, dict(bias=True)),
+    ("tiles192", 16384, 768, 768, True, True, dict(bias=True, residual=True, drop=0.1)),   # fewer tiles than CUs
+    ("tiles200_edges", 12800, 1000, 256, True, False, dict(residual=True)),               # 50 x 4 = 200 tiles, edge columns
+    ("tiles147", 12500, 768, 320, True, True, dict(bias=True)),                           # 49 x 3 = 147 tiles -> grid 144
 ]
 
 
