@@ -1289,6 +1289,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < 8; ++j) dst[j] = read_frag3<B_KC, BNT>(stage + A_BYTES, wn * 8 + j, kk, r, g);
   };
+#ifdef KMB_V11_MFMA32_TIMING
+  // TIMING EXPERIMENT ONLY (diagnostic builds): the same fragments fed to 32x32x16 MFMAs -- half as many instructions,
+  // 32 cycles each, 8 of them holding the issue port.  Results are meaningless; the K loop's duration is the point.
+  f32x16 acc32[4][4];
+  auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[8]) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc32[half * 2 + ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[jj * 2 + ks], a[ii * 2 + ks], acc32[half * 2 + ii][jj], 0, 0, 0);
+  };
+#define KMB_MF(n) ((n) / 2)
+#else
   auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1296,6 +1311,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < 8; ++j)
         acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);  // C^T tile
   };
+#define KMB_MF(n) (n)
+#endif
 
   set_dma_tile(tile_d);
   dma_stage_a(0);
@@ -1324,6 +1341,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < MH * 4; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef KMB_V11_MFMA32_TIMING
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+#endif
     [[maybe_unused]] const uint64_t kmb_t_loop = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < nt; ++t, ++it) {
       // publish the next tile to the other waves: written in step 1, behind step 1's barrier when the cursor reads it
@@ -1339,16 +1364,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       dma_a((it + 1) & 1, NA3, 8);            // the rest of the stage whose first pieces went out in the previous
       dma_b((it + 1) & 1, NB3, NB3 + NB0);    // sub-phase 3
       mma(0, fa[0], fb[0]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 0);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x100, NDA / 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 0);
       }
 #pragma unroll
       for (int q = 0; q < P0; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, 20 / (P0 > 0 ? P0 : 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(20 / (P0 > 0 ? P0 : 1)), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- sub-phase 1: A(k0, rows 64-127) x B(k0)  ||  read B(k1), A(k1, rows 0-63) ----
@@ -1356,26 +1381,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       read_a(cur, 1, 0, fa[0]);
       dma_b((it + 1) & 1, NB3 + NB0, 8);
       mma(1, fa[1], fb[0]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);   // MFMAs first: their operands were read a sub-phase ago
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(6), 1);   // MFMAs first: their operands were read a sub-phase ago
       __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 5, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(5), 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 5, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(5), 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
 #pragma unroll
       for (int q = 0; q < P1; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, 12 / (P1 > 0 ? P1 : 1), 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(12 / (P1 > 0 ? P1 : 1)), 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       advance_cursor();
       // ---- sub-phase 2: A(k1, rows 0-63) x B(k1)  ||  read A(k1, rows 64-127); stage it+1 landed, barrier ----
       read_a(cur, 1, 1, fa[1]);
       mma(0, fa[0], fb[1]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(8), 2);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 2);
-      __builtin_amdgcn_sched_group_barrier(0x008, 24, 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(24), 2);
       __builtin_amdgcn_sched_barrier(0);
       {
         KMB_WAIT_BEGIN();
@@ -1391,13 +1416,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       dma_b(it & 1, 0, NB3);
       mma(1, fa[1], fb[1]);
       __builtin_amdgcn_sched_group_barrier(0x100, NDB, 3);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 3);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 3);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 3);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 3);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 3);
 #pragma unroll
       for (int q = 0; q < P3; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 3);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, 24 / P3, 3);
+        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(24 / P3), 3);
       }
       __builtin_amdgcn_sched_barrier(0);
       } else {
@@ -1440,6 +1465,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef KMB_V11_MFMA32_TIMING
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = acc32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + e];
+#endif
     // ---- epilogue of this tile (the next tile's first two stages are in flight / resident meanwhile) ----
     [[maybe_unused]] const uint64_t kmb_t_epi = __builtin_amdgcn_s_memrealtime();
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
