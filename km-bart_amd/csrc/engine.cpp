@@ -126,7 +126,7 @@ struct kmb_handle {
     std::vector<bf16_t*> kc[2], vc[2];     // per layer self caches, double buffered [R, Tmax, d]
     int cur = 0;
     int32_t *kv_row = nullptr;             // [R] -> batch item
-    bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd;
+    bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd; float* slab;
   } gen;
 
   KmbDrop drop_site(int site, bool train) const {
@@ -1104,7 +1104,9 @@ struct GenLayout {
   int32_t* status; bf16_t* xf; float* img_emb; int32_t* img_src; bf16_t* xe[2]; EncAct ea;
   std::vector<bf16_t*> ckv, kc[2], vc[2];
   int32_t* kv_row; bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd;
+  float* slab;   // split-K partial sums of the residual projections of a decode step
 };
+constexpr int GEN_MAX_SPLIT = 12;
 
 size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int nb, int Tmax, int Ntot, GenLayout* out) {
   const int d = h->d, Fe = h->Fe, Fd = h->Fd, Ld = h->cfg.decoder_layers;
@@ -1132,6 +1134,7 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
   g.o = bp.take<bf16_t>(R * d); g.z = bp.take<bf16_t>(R * d); g.y = bp.take<bf16_t>(R * d); g.cq = bp.take<bf16_t>(R * d);
   g.u = bp.take<bf16_t>(R * Fd); g.hh = bp.take<bf16_t>(R * Fd);
   g.mean = bp.take<float>(R); g.rstd = bp.take<float>(R);
+  g.slab = bp.take<float>((size_t)GEN_MAX_SPLIT * R * d);
   if (out) *out = g;
   return bp.used();
 }
@@ -1172,7 +1175,7 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.active = true; G.B = B; G.S = S; G.nb = num_beams; G.R = B * num_beams; G.Tmax = max_length; G.bt = bt; G.cur = 0;
   G.ckv = g.ckv; G.kc[0] = g.kc[0]; G.kc[1] = g.kc[1]; G.vc[0] = g.vc[0]; G.vc[1] = g.vc[1];
   G.kv_row = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
-  G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd;
+  G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab;
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam)
   for (int l = 0; l < Ld; ++l) {
     const LayerP& L = h->dec[l];
@@ -1201,6 +1204,31 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
                                  h->cfg.extra_pos_embeddings + step, 1, scale, h->pf(h->dec_lne_g),
                                  h->pf(h->dec_lne_b), nullptr, G.x0, nullptr, nullptr, R, d, eps, nodrop, s));
   bf16_t* x = G.x0; bf16_t* xn = G.x1;
+  // residual projection + LayerNorm (BartDecoderLayer: x = LN(residual + dropout(proj(x)))).  With R = batch x beams rows
+  // the projection has 18 output tiles of 128 x 128 and a serial K loop: split K over workgroups and let ONE kernel sum
+  // the slabs, add bias and residual and normalise (no GEMM epilogue, no separate LayerNorm launch).
+  auto proj_ln = [&](const bf16_t* in, int K, size_t w_off, size_t b_off, const bf16_t* res, size_t g_off, size_t be_off,
+                     bf16_t* out) -> int {
+    const int nt = K / 64;
+    static const int s_small = getenv("KMB_GEN_SPLIT_SMALL") ? atoi(getenv("KMB_GEN_SPLIT_SMALL")) : 3;   // tuning knobs
+    static const int s_large = getenv("KMB_GEN_SPLIT_LARGE") ? atoi(getenv("KMB_GEN_SPLIT_LARGE")) : 6;
+    int S = K >= 2048 ? s_large : s_small;
+    if (S > nt / 2) S = nt / 2;
+    if (S > GEN_MAX_SPLIT) S = GEN_MAX_SPLIT;
+    if (S > 1 && (K % 64) == 0 && (d & 7) == 0 && d <= 1024) {
+      KmbGemm g = lin_fwd(in, K, h->wb(w_off), nullptr, R, d, K);
+      g.split_k = S; g.slab = G.slab; g.out_bf16 = nullptr; g.out_f32 = nullptr;
+      KCHK(run_gemm(g, s));
+      HIPCHK(kmb_ln_fwd_slabs_launch(G.slab, S, (size_t)R * d, h->pf(b_off), res, d, h->pf(g_off), h->pf(be_off), out, R, d,
+                                     eps, s));
+      return 0;
+    }
+    KmbGemm g = lin_fwd(in, K, h->wb(w_off), h->pf(b_off), R, d, K);
+    g.residual = res; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(g_off), h->pf(be_off), out, G.mean, G.rstd, R, d, eps, s));
+    return 0;
+  };
   for (int l = 0; l < h->cfg.decoder_layers; ++l) {
     const LayerP& L = h->dec[l];
     KmbGemm g = lin_fwd(x, d, h->wb(L.sa.qkv_w), h->pf(L.sa.qkv_b), R, 3 * d, d);
@@ -1212,10 +1240,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     // this step's key / value: attended to from the projection output and appended to the cache by the same launch
     a.new_k = G.qkv + d; a.new_v = G.qkv + 2 * d; a.ld_new = 3 * d; a.Kw = G.kc[G.cur][l]; a.Vw = G.vc[G.cur][l];
     HIPCHK(kmb_attn_decode_launch(a, s));
-    g = lin_fwd(G.o, d, h->wb(L.sa.o_w), h->pf(L.sa.o_b), R, d, d);
-    g.residual = x; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
-    KCHK(run_gemm(g, s));
-    HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(L.sa.ln_g), h->pf(L.sa.ln_b), G.y, G.mean, G.rstd, R, d, eps, s));
+    KCHK(proj_ln(G.o, d, L.sa.o_w, L.sa.o_b, x, L.sa.ln_g, L.sa.ln_b, G.y));
     // cross attention over the cached encoder K|V of the row's batch item
     g = lin_fwd(G.y, d, h->wb(L.ca.qkv_w), h->pf(L.ca.qkv_b), R, d, d);
     g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = G.cq; g.ld_out_bf16 = d;
@@ -1225,18 +1250,12 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     a.key_mask = G.bt.attention_mask; a.mask_ld = G.S; a.mask_row = G.kv_row;
     a.R = R; a.H = h->Hd; a.Tk = G.S; a.O = G.o; a.ldo = d;
     HIPCHK(kmb_attn_decode_launch(a, s));
-    g = lin_fwd(G.o, d, h->wb(L.ca.o_w), h->pf(L.ca.o_b), R, d, d);
-    g.residual = G.y; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
-    KCHK(run_gemm(g, s));
-    HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(L.ca.ln_g), h->pf(L.ca.ln_b), G.y, G.mean, G.rstd, R, d, eps, s));
+    KCHK(proj_ln(G.o, d, L.ca.o_w, L.ca.o_b, G.y, L.ca.ln_g, L.ca.ln_b, G.y));   // in place: a lane rewrites only the chunks it read
     // FFN
     g = lin_fwd(G.y, d, h->wb(L.fc1_w), h->pf(L.fc1_b), R, F, d);
     g.act = 1; g.out_bf16 = G.hh; g.ld_out_bf16 = F;
     KCHK(run_gemm(g, s));
-    g = lin_fwd(G.hh, F, h->wb(L.fc2_w), h->pf(L.fc2_b), R, d, F);
-    g.residual = G.y; g.ld_res = d; g.out_bf16 = G.z; g.ld_out_bf16 = d;
-    KCHK(run_gemm(g, s));
-    HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(L.ln_g), h->pf(L.ln_b), xn, G.mean, G.rstd, R, d, eps, s));
+    KCHK(proj_ln(G.hh, F, L.fc2_w, L.fc2_b, G.y, L.ln_g, L.ln_b, xn));
     bf16_t* t = x; x = xn; xn = t;
   }
   if (logits_out) {

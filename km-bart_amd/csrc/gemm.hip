@@ -1543,7 +1543,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BNS - 1) / BNS;
-  const int tm = (int)blockIdx.x / tiles_n, tn = (int)blockIdx.x % tiles_n;
+  const int nsl = p.split_k > 1 ? p.split_k : 1;   // split-K: slice s of a tile writes raw sums to slab[s][M][N]
+  const int tile = (int)blockIdx.x / nsl, slice = (int)blockIdx.x % nsl;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BNS;
 
   f32x4 acc[2][2];
@@ -1552,7 +1554,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.K / BK;
+  const int nt_all = p.K / BK;
+  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
+  const int nt = t_end - t_begin;
   uint32_t offA[4], offB;
   dma_offsets<true>(offA, p.lda, row0, p.M, wave, lane);
   {  // B: 32 rows x 128 B = 4 pieces, one per wave (rows 8 * wave ...), same swizzle as the 128-row image
@@ -1562,8 +1566,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
     grow = grow < p.N ? grow : p.N - 1;
     offB = (uint32_t)(((grow - col0) * p.ldb + c * 8) * 2);
   }
-  const char* gA = reinterpret_cast<const char*>(p.A) + (size_t)row0 * p.lda * 2;
-  const char* gB = reinterpret_cast<const char*>(p.B) + (size_t)col0 * p.ldb * 2;
+  const char* gA = reinterpret_cast<const char*>(p.A) + (size_t)row0 * p.lda * 2 + (size_t)t_begin * (BK * 2);
+  const char* gB = reinterpret_cast<const char*>(p.B) + (size_t)col0 * p.ldb * 2 + (size_t)t_begin * (BK * 2);
   constexpr int A_TILE = BM * BK * 2;
   auto dma_stage = [&](int ks, int buf) {
     char* da = smem + buf * STAGE_S + wave * 4096;
@@ -1612,6 +1616,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
   const int gcol = col0 + c8;
   if (gcol >= p.N) return;
   const int nvalid = (p.N - gcol) < 8 ? (p.N - gcol) : 8;
+  if (p.split_k > 1) {   // raw partial sums (the launcher requires N % 8 == 0)
+    float* slab = p.slab + (size_t)slice * p.M * p.N;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int lrow = (tid >> 2) + 64 * it;
+      const int grow = row0 + lrow;
+      if (grow >= p.M) break;
+      float* o = slab + (size_t)grow * p.N + gcol;
+      *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD_S + c8);
+      *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(ef + lrow * EPI_LD_S + c8 + 4);
+    }
+    return;
+  }
   float bias8[8], scale8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -1840,9 +1857,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       (void)hipFuncSetAttribute((const void*)gemm_kernel_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
     }
     const int tiles128 = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    if (narrow_ok && !forced && p.a_kc && p.b_kc && p.M <= 512 && tiles128 < 128 && p.split_k <= 1 && p.act <= 1 &&
-        p.preact == nullptr && p.colsum == nullptr && p.drop_thr16 == 0u && (p.act == 0 || p.aux == nullptr)) {
-      dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BNS - 1) / BNS)), block(256);
+    if (narrow_ok && !forced && p.a_kc && p.b_kc && p.M <= 512 && tiles128 < 128 && (p.split_k <= 1 || (p.N & 7) == 0) &&
+        p.act <= 1 && p.preact == nullptr && p.colsum == nullptr && p.drop_thr16 == 0u && (p.act == 0 || p.aux == nullptr)) {
+      dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BNS - 1) / BNS) * (p.split_k > 1 ? p.split_k : 1)), block(256);
       hipLaunchKernelGGL(gemm_kernel_narrow, grid, block, LDS_S, stream, p);
       return hipGetLastError();
     }

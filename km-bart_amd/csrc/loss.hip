@@ -265,6 +265,116 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
   }
 }
 
+// Register-resident form (rows of up to NV * 4096 columns): 1024 threads hold the fp32 row, so the logits are read
+// from memory ONCE -- max, sum-exp, every thread's candidate and the owner's rescans all come from registers (the
+// 256-thread form above sweeps the row three times and rescans from L2; 102 us -> per decode step at 320 rows).
+// Thread t owns the float4 chunks t, t + 1024, ...; same (value desc, index asc) order.
+template <int NV>
+__global__ __launch_bounds__(1024) void logsoftmax_topk_reg_kernel(const float* __restrict__ logits, int ldv, int V,
+                                                                   const float* __restrict__ add, int force_token, int k,
+                                                                   float* __restrict__ out_val,
+                                                                   int32_t* __restrict__ out_idx) {
+  __shared__ float sh[32];
+  __shared__ float shv[16];
+  __shared__ int shi[16];
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* row = logits + (size_t)r * ldv;
+  const float a = add != nullptr ? add[r] : 0.f;
+  if (force_token >= 0) {
+    for (int j = tid; j < k; j += 1024) {
+      out_val[(size_t)r * k + j] = j == 0 ? a : -INFINITY;
+      out_idx[(size_t)r * k + j] = j == 0 ? force_token : (j - 1 < force_token ? j - 1 : j);
+    }
+    return;
+  }
+  f32x4 x[NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = (tid + 1024 * j) * 4;
+    if (i < ldv) {
+      x[j] = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (i + e >= V) x[j][e] = -INFINITY;
+        m = fmaxf(m, x[j][e]);
+      }
+    } else {
+      x[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) sh[wave] = m;
+  __syncthreads();
+  m = sh[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, sh[w]);
+  float s = 0.f;
+  if (m != -INFINITY) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += __expf(x[j][e] - m);
+  }
+  s = wave_sum(s);
+  if (lane == 0) sh[16 + wave] = s;
+  __syncthreads();
+  s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += sh[16 + w];
+  const float lse = m + __logf(s);
+  // this thread's best element (ascending index order inside the thread: the first of equal values wins)
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = (tid + 1024 * j) * 4 + e;
+      if (i < V && (x[j][e] > bv || bi == 0x7fffffff)) { bv = x[j][e]; bi = i; }
+    }
+  for (int jr = 0; jr < k; ++jr) {
+    float wv = bv;
+    int wi = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(wv, o, 64);
+      const int i2 = __shfl_xor(wi, o, 64);
+      if (i2 != 0x7fffffff && (wi == 0x7fffffff || v2 > wv || (v2 == wv && i2 < wi))) { wv = v2; wi = i2; }
+    }
+    if (lane == 0) { shv[wave] = wv; shi[wave] = wi; }
+    __syncthreads();
+    wv = shv[0]; wi = shi[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+      const float v2 = shv[w];
+      const int i2 = shi[w];
+      if (i2 != 0x7fffffff && (wi == 0x7fffffff || v2 > wv || (v2 == wv && i2 < wi))) { wv = v2; wi = i2; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      out_val[(size_t)r * k + jr] = (wv - lse) + a;
+      out_idx[(size_t)r * k + jr] = wi;
+    }
+    if (wi == 0x7fffffff) continue;  // fewer than k elements in the row
+    const int owner = (wi >> 2) & 1023;
+    if (wave == (owner >> 6)) {   // wave-uniform: the owner's next candidate, out of its registers
+      float nv = -INFINITY;
+      int ni = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = (tid + 1024 * j) * 4 + e;
+          const float xv = x[j][e];
+          const bool after = (xv < wv) || (xv == wv && i > wi);
+          if (i < V && after && (xv > nv || ni == 0x7fffffff)) { nv = xv; ni = i; }
+        }
+      if (tid == owner) { bv = nv; bi = ni; }
+    }
+  }
+}
+
 // Beam search, per batch item: the best `k` of the nb * k candidates its beams produced (val / idx from
 // logsoftmax_topk_kernel, rows b*nb .. b*nb + nb - 1), ordered by (value desc, candidate position asc) -- what
 // torch.topk over the [nb * V] scores of mixins.py's beam step returns, restricted to each beam's own top k (enough:
@@ -327,7 +437,10 @@ hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_
 hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
                                       int force_token, int k, float* out_val, int32_t* out_idx, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, add, force_token, k, out_val, out_idx);
+  if (ldv <= 13 * 4096 && (ldv & 3) == 0 && ((uintptr_t)logits & 15) == 0)
+    hipLaunchKernelGGL((logsoftmax_topk_reg_kernel<13>), dim3(rows), dim3(1024), 0, stream, logits, ldv, V, add, force_token, k, out_val, out_idx);
+  else
+    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, add, force_token, k, out_val, out_idx);
   return hipGetLastError();
 }
 

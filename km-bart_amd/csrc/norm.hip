@@ -52,6 +52,68 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// Decode path: the split-K slabs of a residual projection are summed, bias and residual added, the sum rounded to
+// bf16 (what the un-split GEMM epilogue stores and ln_fwd_kernel reads) and normalised -- one launch instead of the
+// GEMM epilogue + LayerNorm pair, and the 320-row GEMM in front of it gets nslabs times as many workgroups.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_slabs_kernel(const float* __restrict__ slabs, int nslabs, size_t stride,
+                                                           const float* __restrict__ bias,
+                                                           const bf16_t* __restrict__ residual, int ld_res,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           bf16_t* __restrict__ y, int M, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nch = D >> 3;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float* src = slabs + (size_t)row * D + c * 8;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+      for (int k = 1; k < nslabs; ++k) {
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+        const f32x4 h2 = *reinterpret_cast<const f32x4*>(src + (size_t)k * stride + 4);
+        lo[0] += l2[0]; lo[1] += l2[1]; lo[2] += l2[2]; lo[3] += l2[3];
+        hi[0] += h2[0]; hi[1] += h2[1]; hi[2] += h2[2]; hi[3] += h2[3];
+      }
+      float rr[8];
+      unpack8(*reinterpret_cast<const u32x4*>(residual + (size_t)row * ld_res + c * 8), rr);
+      float t[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (t[e] + (bias != nullptr ? bias[c * 8 + e] : 0.f)) + rr[e];
+      unpack8(pack8(t), v[i]);   // bf16 rounding of the pre-LayerNorm sum, as the two-kernel path stores it
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * gamma[c * 8 + e] + beta[c * 8 + e];
+      *reinterpret_cast<u32x4*>(y + (size_t)row * D + c * 8) = pack8(o);
+    }
+  }
+}
+
 // Each block owns rows [blockIdx.x * rows_per_block, ...); its 4 waves take them round-robin.
 // One wave per row, lane l owns the 4-column groups l, l+64, ... (NQ of them: D = 768 is covered exactly by NQ = 3, no
 // idle lanes), and the next row's dy / z are already in flight while the current one is reduced: the kernel is a pure
@@ -271,6 +333,17 @@ hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* b
   if (D <= 512) hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
   else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
   else hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
+  return hipGetLastError();
+}
+
+hipError_t kmb_ln_fwd_slabs_launch(const float* slabs, int nslabs, size_t stride, const float* bias, const bf16_t* residual,
+                                   int ld_res, const float* gamma, const float* beta, bf16_t* y, int M, int D, float eps,
+                                   hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if ((D & 7) || D > 1024 || nslabs < 1 || (stride & 3)) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+  if (D <= 512) hipLaunchKernelGGL((ln_fwd_slabs_kernel<1>), grid, block, 0, stream, slabs, nslabs, stride, bias, residual, ld_res, gamma, beta, y, M, D, eps);
+  else hipLaunchKernelGGL((ln_fwd_slabs_kernel<2>), grid, block, 0, stream, slabs, nslabs, stride, bias, residual, ld_res, gamma, beta, y, M, D, eps);
   return hipGetLastError();
 }
 

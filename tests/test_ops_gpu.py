@@ -383,9 +383,10 @@ def test_cross_entropy_and_grad():
     assert float(dl[:, V:].float().abs().sum()) == 0.0
 
 
-def test_logsoftmax_topk():
+@pytest.mark.parametrize("V,ld", [(50320, 50432), (60000, 60032)])   # register-resident kernel / 256-thread kernel
+def test_logsoftmax_topk(V, ld):
     lib = _lib.load()
-    rows, V, ld, k = 10, 50320, 50432, 10
+    rows, k = 10, 10
     logits = torch.zeros((rows, ld), device=DEV)
     logits[:, :V] = rnd(rows, V, seed=61) * 4
     add = rnd(rows, seed=62)
@@ -406,6 +407,19 @@ def test_logsoftmax_topk():
     logits[:, 7000] = logits[:, 5 + 256 * 11]
     logits[:, 300] = logits[:, 5 + 256 * 11]
     logits[:, 5 + 256 * 10] = -float("inf")
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, k, ptr(val), ptr(idx), stream()))
+    lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
+    order = torch.sort(lp, dim=1, descending=True, stable=True)[1][:, :k]
+    assert torch.equal(idx.long(), order)
+    assert torch.allclose(val, torch.gather(lp, 1, order), atol=1e-4)
+    # the same for the register-resident kernel's ownership (thread t holds the float4 chunks t, t + 1024, ...):
+    # twelve winners inside ONE thread's chunks, two exact ties elsewhere, a masked winner
+    logits[:, :V] = rnd(rows, V, seed=64)
+    own = torch.tensor([4 * (5 + 1024 * j) + (j % 4) for j in range(12)], device=DEV)
+    logits[:, own] = 9.0 + torch.arange(12, device=DEV).float()
+    logits[:, 7001] = logits[:, own[11]]
+    logits[:, 301] = logits[:, own[11]]
+    logits[:, own[10]] = -float("inf")
     check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, k, ptr(val), ptr(idx), stream()))
     lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
     order = torch.sort(lp, dim=1, descending=True, stable=True)[1][:, :k]
