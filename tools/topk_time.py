@@ -1,0 +1,20 @@
+"""Time of the log-softmax top-k kernel at the decode shape (320 rows x 50320) for several k."""
+import os, sys
+ROOT = "/root/repo"
+sys.path.insert(0, os.path.join(ROOT, "km-bart_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from gpu_util import DEV, ptr, stream, check
+from kmbart import _lib
+lib = _lib.load()
+rows, V, ld = 320, 50320, 50432
+logits = torch.randn(rows, ld, device=DEV) * 4
+add = torch.randn(rows, device=DEV)
+for k, ft in ((1, -1), (2, -1), (5, -1), (10, -1)):
+    val = torch.empty((rows, k), device=DEV); idx = torch.empty((rows, k), dtype=torch.int32, device=DEV)
+    for _ in range(3): check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), ft, k, ptr(val), ptr(idx), stream()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), ft, k, ptr(val), ptr(idx), stream()))
+    e1.record(); torch.cuda.synchronize()
+    print("k", k, "probe", ft, round(e0.elapsed_time(e1) / 20 * 1e3, 1), "us")
