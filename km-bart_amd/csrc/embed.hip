@@ -128,18 +128,41 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict
   }
 }
 
-// grid (P_rows, ceil(D/256)): rows outside [pos_base, pos_base+S) are zeroed
-__global__ __launch_bounds__(256) void pos_bwd_kernel(const bf16_t* __restrict__ dz, int B, int S, int D,
-                                                      float* __restrict__ dP, int pos_base) {
-  const int prow = blockIdx.x;
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= D) return;
+// One block per position row; rows outside [pos_base, pos_base+S) are zeroed.  A position's gradient is the sum over
+// the batch of rows b*S + s: 1024 threads = (D/8 column chunks) x (1024 / (D/8) batch lanes), 16-byte loads, the batch
+// lanes folded through LDS in a fixed order (deterministic).  The first version gave one thread a column and walked
+// the batch serially with 2-byte loads: 145 us for 50 MB.
+__global__ __launch_bounds__(1024) void pos_bwd_kernel(const bf16_t* __restrict__ dz, int B, int S, int D,
+                                                       float* __restrict__ dP, int pos_base) {
+  extern __shared__ float red[];   // [batch lanes][D]
+  const int prow = blockIdx.x, tid = threadIdx.x;
   const int s = prow - pos_base;
-  float a = 0.f;
-  if (s >= 0 && s < S) {
-    for (int b = 0; b < B; ++b) a += bf2f(dz[((size_t)b * S + s) * D + c]);
+  if (s < 0 || s >= S) {
+    for (int i = tid; i < D; i += 1024) dP[(size_t)prow * D + i] = 0.f;
+    return;
   }
-  dP[(size_t)prow * D + c] = a;
+  const int nch = D >> 3;
+  const int nbl = 1024 / nch;
+  const int c = tid % nch, bl = tid / nch;
+  if (bl < nbl) {
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int b = bl; b < B; b += nbl) {
+      float v[8];
+      unpack8(*reinterpret_cast<const u32x4*>(dz + ((size_t)b * S + s) * D + c * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[bl * D + c * 8 + e] = a[e];
+  }
+  __syncthreads();
+  for (int i = tid; i < D; i += 1024) {
+    float t = 0.f;
+    for (int k = 0; k < nbl; ++k) t += red[k * D + i];
+    dP[(size_t)prow * D + i] = t;
+  }
 }
 
 }  // namespace
@@ -185,6 +208,8 @@ hipError_t kmb_embed_bwd_launch(const bf16_t* dz, const int64_t* ids, const int3
 
 hipError_t kmb_pos_bwd_launch(const bf16_t* dz, int B, int S, int D, float* dP, int pos_base, int P_rows,
                               hipStream_t stream) {
-  hipLaunchKernelGGL(pos_bwd_kernel, dim3(P_rows, (D + 255) / 256), dim3(256), 0, stream, dz, B, S, D, dP, pos_base);
+  if ((D & 7) || D > 8192) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(1024 / (D >> 3)) * D * sizeof(float);   // <= 32 KB
+  hipLaunchKernelGGL(pos_bwd_kernel, dim3(P_rows), dim3(1024), lds, stream, dz, B, S, D, dP, pos_base);
   return hipGetLastError();
 }
