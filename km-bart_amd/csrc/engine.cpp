@@ -237,6 +237,13 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
   int S = 512 / tiles;   // two 128x128 workgroups per CU; floor: a partial last round costs more than it fills
                          // (tools/wgrad_split_sweep.py: 36 tiles S14 59 us vs S11 70 us, 72 tiles S7 97 vs S6 104)
   if (S > 16) S = 16;
+  // 128-160 tiles and a very long reduction (3072x768 over 32768 tokens): 256x256 tiles with a slice count that fills
+  // the chip once beat the 128x128 kernel at S = 3 by 10-12 % (tools/wgrad_split_sweep.py); with these slices the
+  // launcher's timing picks the 256x256 kernel
+  if (tiles >= 128 && tiles <= 160 && nt >= 512) {   // (wider ranges gain what the longer slab reduction costs)
+    const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (256 / tiles256 > S) S = 256 / tiles256;
+  }
   if (S > nt / 2) S = nt / 2;
   while (S > 1 && (size_t)S * g.M * g.N > h->slab_floats) --S;
   if (S <= 1 || g.ld_out_f32 != g.N || ((size_t)g.M * g.N & 3)) return run_gemm(g, s);
@@ -356,7 +363,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   const size_t CH = Md < (size_t)h->lm_chunk ? Md : (size_t)h->lm_chunk;
   float* logits_c = bp.take<float>(CH * h->Vpad);
   bf16_t* dlogits_c = bp.take<bf16_t>(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
-  const size_t slab_floats = (size_t)16 << 20;          // split-K partial slabs of the weight-gradient GEMMs
+  const size_t slab_floats = (size_t)20 << 20;          // split-K partial slabs of the weight-gradient GEMMs (80 MB)
   float* slab = bp.take<float>(slab_floats);
   float* loss_rows = bp.take<float>(Md);
   bf16_t* dhdec = bp.take<bf16_t>(Md * d);
