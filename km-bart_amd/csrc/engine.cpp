@@ -623,7 +623,7 @@ int kmb_create(const kmb_config* cfg, kmb_handle** out) {
   h->d = cfg->d_model; h->He = cfg->encoder_attention_heads; h->Hd = cfg->decoder_attention_heads;
   h->Fe = cfg->encoder_ffn_dim; h->Fd = cfg->decoder_ffn_dim; h->V = cfg->vocab_size;
   h->Vpad = (int)align_up((size_t)cfg->vocab_size, 128);
-  h->Fin = cfg->image_feature_size; h->Fpad = (int)align_up((size_t)cfg->image_feature_size, 8);
+  h->Fin = cfg->image_feature_size; h->Fpad = (int)align_up((size_t)cfg->image_feature_size, 64);   // K of the image projection: a multiple of the GEMMs' K step
   h->Prows = cfg->max_position_embeddings + cfg->extra_pos_embeddings;
   const int d = h->d;
   h->img_w = add_param(h, "model.encoder.embed_images.linear.weight", d, h->Fin);
