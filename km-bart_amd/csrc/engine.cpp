@@ -850,8 +850,22 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
     if (bt.labels && need_grad) {
       // dH = dlogits E  (reduction over the padded vocabulary; pad columns / rows are zero)
       KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, Md, h->Vpad, d);
-      gd.out_bf16 = h->dhdec; gd.ld_out_bf16 = d;
-      KCHK(run_gemm(gd, s));
+      // [Md, d] has few 256x256 tiles (192 at Md = 16384: three quarters of the CUs) and the reduction runs over the
+      // whole vocabulary (788 K steps): split it so that the grid is a whole number of rounds; a small pass sums the
+      // slabs into the bf16 gradient.  The slabs live in the fp32 logits buffer, which is free once the CE ran.
+      const int tiles256 = ((Md + 255) / 256) * ((d + 255) / 256);
+      const size_t CHl = (size_t)(Md < h->lm_chunk ? Md : h->lm_chunk) * h->Vpad;   // floats in the logits buffer
+      int S = tiles256 > 0 ? (256 * 3) / tiles256 : 1;
+      if (S > 8) S = 8;
+      while (S > 1 && (size_t)S * Md * d > CHl) --S;
+      if (S > 1 && ((size_t)Md * d & 7) == 0 && h->Vpad / 64 >= 2 * S) {
+        gd.split_k = S; gd.slab = h->logits_c;
+        KCHK(run_gemm(gd, s));
+        HIPCHK(kmb_reduce_slabs_bf16_launch(h->logits_c, S, (size_t)Md * d, h->dhdec, (size_t)Md * d, s));
+      } else {
+        gd.out_bf16 = h->dhdec; gd.ld_out_bf16 = d;
+        KCHK(run_gemm(gd, s));
+      }
       // dE[V,d] = dlogits^T H  (overwrites: the embedding scatter-adds of backward come on top)
       // (on the side stream: it overlaps the start of backward; the embedding scatter-adds wait for it)
       KCHK(ensure_side(h));

@@ -39,6 +39,8 @@ hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride
 hipError_t kmb_ln_fwd_slabs_launch(const float* slabs, int nslabs, size_t stride, const float* bias, const bf16_t* residual,
                                    int ld_res, const float* gamma, const float* beta, bf16_t* y, int M, int D, float eps,
                                    hipStream_t stream);
+hipError_t kmb_reduce_slabs_bf16_launch(const float* slabs, int nslabs, size_t stride, bf16_t* out, size_t n,
+                                        hipStream_t stream);
 hipError_t kmb_reduce_slabs_launch(const float* slabs, int nslabs, size_t stride, float* out, size_t n, float beta,
                                    hipStream_t stream);
 // column sums of a bf16 matrix -> partials [nparts][N]; nparts = kmb_colsum_parts(M)

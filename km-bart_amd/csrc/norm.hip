@@ -287,6 +287,22 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   }
 }
 
+// the same sum stored as bf16 (a split-K data gradient): n % 8 == 0
+__global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __restrict__ slabs, int nslabs, size_t stride,
+                                                                bf16_t* __restrict__ out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    f32x4 a = reinterpret_cast<const f32x4*>(slabs)[2 * i], b = reinterpret_cast<const f32x4*>(slabs)[2 * i + 1];
+    for (int s = 1; s < nslabs; ++s) {
+      const f32x4 a2 = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride)[2 * i];
+      const f32x4 b2 = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride)[2 * i + 1];
+      a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3];
+      b[0] += b2[0]; b[1] += b2[1]; b[2] += b2[2]; b[3] += b2[3];
+    }
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    reinterpret_cast<u32x4*>(out)[i] = pack8(v);
+  }
+}
+
 // grid (ceil(N/64), nparts); block 256 = 8 column chunks x 32 row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
                                                      float* __restrict__ partials, int rows_per_part) {
@@ -396,6 +412,16 @@ hipError_t kmb_reduce_slabs_launch(const float* slabs, int nslabs, size_t stride
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, nslabs, stride, out, n / 4, beta);
+  return hipGetLastError();
+}
+
+hipError_t kmb_reduce_slabs_bf16_launch(const float* slabs, int nslabs, size_t stride, bf16_t* out, size_t n,
+                                        hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if ((n & 7) || (stride & 3) || ((uintptr_t)out & 15)) return hipErrorInvalidValue;
+  size_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, nslabs, stride, out, n / 8);
   return hipGetLastError();
 }
 
