@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
   char* dSs = smem + 5 * TILE_BYTES;
   float* lse_s = reinterpret_cast<float*>(smem + 6 * TILE_BYTES);
   float* del_s = lse_s + 64;
-  float* colk = del_s + 64;   // [64] column sums of dK over all keys (bias-gradient partial)
-  float* colv = colk + 64;    // [64] same for dV
-  float* dQacc = colv + 64;   // [nqt*64][64] fp32
+  float* colk = del_s + 64;   // [4 waves][64] column sums of dK over each wave's keys (bias-gradient partials)
+  float* colv = colk + 256;   // [4 waves][64] same for dV
+  float* dQacc = colv + 256;  // [nqt*64][64] fp32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
   const bf16_t* dOh = p.dO + h * HD;
 
   const int nkt = (p.Tk + 63) / 64;
-  if (tid < 128) colk[tid] = 0.f;  // colk and colv are adjacent
+  for (int i = tid; i < 512; i += 256) colk[i] = 0.f;  // colk and colv are adjacent
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     stage_tile(Ks, Kh, (size_t)b * p.Tk, kt * 64, p.Tk, p.ldk, tid);
@@ -272,8 +272,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_cols(Ks, j, kk, r, g), dq[j], 0, 0, 0);
-          dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ptf, frag_cols(dOs, j, kk, r, g), dv[j], 0, 0, 0);
-          dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dstf, frag_cols(Qs, j, kk, r, g), dk[j], 0, 0, 0);
+          // operands swapped: the accumulators hold the TRANSPOSED 16x16 tiles -- lane (r, g) has key r of this wave and
+          // the four consecutive feature columns 16 j + 4 g .. +3, so dK / dV leave as 8-byte stores (4 + 4 store
+          // instructions per wave instead of 32 + 32 two-byte ones; a store instruction costs the wave ~60 cycles)
+          dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, j, kk, r, g), ptf, dv[j], 0, 0, 0);
+          dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, j, kk, r, g), dstf, dk[j], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -284,33 +287,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
           *a = (kt == 0) ? dq[j][q] : (*a + dq[j][q]);
         }
     }
-    // this wave's 16 keys of dK / dV
-    if (p.dk_colsum != nullptr) {  // uniform branch
+    // this wave's 16 keys of dK / dV (transposed tiles: key = lane & 15, columns 16 j + 4 g + q)
+    const int key = kt * 64 + wave * 16 + r;
+    const bool key_ok = key < p.Tk;
+    if (p.dk_colsum != nullptr) {  // uniform branch: column sums over the keys = over the 16 r-lanes of a DPP row
+      auto row16_sum = [](float v) {   // inclusive prefix sums by row_shr 1, 2, 4, 8 (zeros shifted in): lane 15 = total
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+        return v;
+      };
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float sk = 0.f, sv = 0.f;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const bool valid = (kt * 64 + wave * 16 + g * 4 + q) < p.Tk;
-          sk += valid ? dk[j][q] : 0.f;
-          sv += valid ? dv[j][q] : 0.f;
+          const float sk = row16_sum(key_ok ? dk[j][q] : 0.f);
+          const float sv = row16_sum(key_ok ? dv[j][q] : 0.f);
+          if (r == 15) {   // this wave's own partial row: plain read-modify-write, no atomics, deterministic
+            colk[wave * 64 + j * 16 + g * 4 + q] += sk;
+            colv[wave * 64 + j * 16 + g * 4 + q] += sv;
+          }
         }
-        sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
-        sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
-        if (g == 0) { atomicAdd(&colk[j * 16 + r], sk); atomicAdd(&colv[j * 16 + r], sv); }
-      }
     }
+    if (key_ok) {
+      typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+      bf16_t* kr = p.dK + ((size_t)b * p.Tk + key) * p.lddk + h * HD + g * 4;
+      bf16_t* vr = p.dV + ((size_t)b * p.Tk + key) * p.lddv + h * HD + g * 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int key = kt * 64 + wave * 16 + g * 4 + q;
-      if (key < p.Tk) {
-        bf16_t* kr = p.dK + ((size_t)b * p.Tk + key) * p.lddk + h * HD;
-        bf16_t* vr = p.dV + ((size_t)b * p.Tk + key) * p.lddv + h * HD;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          kr[j * 16 + r] = f2bf(dk[j][q]);
-          vr[j * 16 + r] = f2bf(dv[j][q]);
-        }
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<u32x2*>(kr + j * 16) = u32x2{pack2bf(dk[j][0], dk[j][1]), pack2bf(dk[j][2], dk[j][3])};
+        *reinterpret_cast<u32x2*>(vr + j * 16) = u32x2{pack2bf(dv[j][0], dv[j][1]), pack2bf(dv[j][2], dv[j][3])};
       }
     }
   }
@@ -328,8 +335,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
     p.dq_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = sq;
   }
   if (p.dk_colsum != nullptr && tid < 64) {
-    p.dk_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = colk[tid];
-    p.dv_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = colv[tid];
+    p.dk_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = (colk[tid] + colk[64 + tid]) + (colk[128 + tid] + colk[192 + tid]);
+    p.dv_colsum[(size_t)b * p.ld_colsum + h * HD + tid] = (colv[tid] + colv[64 + tid]) + (colv[128 + tid] + colv[192 + tid]);
   }
 }
 
@@ -431,7 +438,7 @@ hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
 
 hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream) {
   const int nqt = (p.Tq + 63) / 64;
-  const size_t lds = 6 * TILE_BYTES + 256 * sizeof(float) + (size_t)nqt * 64 * 64 * sizeof(float);
+  const size_t lds = 6 * TILE_BYTES + (128 + 512) * sizeof(float) + (size_t)nqt * 64 * 64 * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
