@@ -260,7 +260,7 @@ int ensure_side(kmb_handle* h) {
   const char* env = getenv("KMB_NO_SIDE_STREAM");
   if (env && env[0] == '1') { h->side_on = false; return 0; }
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  h->ring.resize(64);
+  h->ring.resize(1024);   // more than one backward pass records (~90): an event is never re-recorded while an earlier wait on it may be pending
   for (auto& e : h->ring) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   h->layer_done.resize(h->cfg.encoder_layers + h->cfg.decoder_layers + 2);
   for (auto& e : h->layer_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -276,7 +276,16 @@ int wgrad_side(kmb_handle* h, const KmbGemm& g, hipStream_t sA) {
   hipEvent_t e = h->next_event();
   HIPCHK(hipEventRecord(e, sA));
   HIPCHK(hipStreamWaitEvent(h->side, e, 0));
-  return run_wgrad(h, g, h->side);
+  KCHK(run_wgrad(h, g, h->side));
+  // KMB_SIDE_SERIALIZE=1 (diagnostic): the caller's stream waits for every weight gradient -- the side stream's
+  // launches stay where they are, nothing overlaps (run-to-run reproducibility)
+  static const bool serialize = getenv("KMB_SIDE_SERIALIZE") != nullptr;
+  if (serialize) {
+    hipEvent_t e2 = h->next_event();
+    HIPCHK(hipEventRecord(e2, h->side));
+    HIPCHK(hipStreamWaitEvent(sA, e2, 0));
+  }
+  return 0;
 }
 
 int bias_grad(kmb_handle* h, const bf16_t* dy, int ld, int M, int N, float* out, hipStream_t s) {

@@ -227,6 +227,40 @@ class Engine:
             check(self.lib.kmb_adamw_step(self.h, C.byref(hp), offset, self.n - offset if count is None else count,
                                           _stream()))
 
+    def adamw_step_overlapped(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0,
+                              offset=0, count=None):
+        """The same update issued per gradient bucket on a second stream, each launch behind that bucket's completion
+        event of the backward pass that is still executing on the GPU (the host enqueues a step in ~2 ms, the GPU needs
+        ~20 ms for backward): the HBM-bound update of the decoder and encoder layers runs beside the compute-bound rest of
+        backward; only the tied matrix (last bucket) is left for after it.  Parameters of a bucket are not read again by
+        the backward pass once its event is recorded.  Returns False (nothing issued) when a piece is not 8-aligned or a
+        data-parallel reducer owns the gradients (they are final only after its all-reduce)."""
+        if not getattr(self, "adamw_overlap_ok", True):
+            return False
+        count = self.n - offset if count is None else count
+        if getattr(self, "_bucket_list", None) is None:
+            self._bucket_list = self.buckets()
+            self._opt_stream = torch.cuda.Stream(device=self.device)
+        end = offset + count
+        pieces = []
+        for i, (boff, bcnt) in enumerate(self._bucket_list):
+            lo, hi = max(offset, boff), min(end, boff + bcnt)
+            if lo < hi:
+                if lo & 7:
+                    return False
+                pieces.append((i, lo, hi - lo))
+        if sum(c for _, _, c in pieces) != count:
+            return False
+        hp = KmbAdamW(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay,
+                      step=self.step_count, correct_bias=1 if correct_bias else 0, grad_scale=grad_scale)
+        with torch.cuda.device(self.device):
+            main, side = torch.cuda.current_stream(), self._opt_stream
+            for i, lo, cnt in pieces:
+                self.stream_wait_bucket(i, side)
+                check(self.lib.kmb_adamw_step(self.h, C.byref(hp), lo, cnt, C.c_void_p(side.cuda_stream)))
+            main.wait_stream(side)
+        return True
+
     # ---- data-parallel buckets --------------------------------------------------------------
     def buckets(self):
         out = []

@@ -15,6 +15,8 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       correct_bias=correct_bias))
         self.grad_scale = 1.0  # data-parallel wrapper may fold 1/world here
+        import os
+        self.overlap = os.environ.get("KMB_ADAMW_OVERLAP", "1") != "0"
 
     def _engine_ranges(self, group):
         """[(engine, offset, count)] with adjacent parameters coalesced."""
@@ -44,8 +46,11 @@ class AdamW(torch.optim.Optimizer):
             for e in engines.values():
                 e.step_count += 1
             for eng, off, cnt in ranges:
-                eng.adamw_step(group["lr"], group["betas"], group["eps"], group["weight_decay"],
-                               group["correct_bias"], self.grad_scale, offset=off, count=cnt, bump=False)
+                args = (group["lr"], group["betas"], group["eps"], group["weight_decay"], group["correct_bias"],
+                        self.grad_scale)
+                # per gradient bucket, beside the backward pass still running on the GPU (Engine.adamw_step_overlapped)
+                if not (self.overlap and eng.adamw_step_overlapped(*args, offset=off, count=cnt)):
+                    eng.adamw_step(*args, offset=off, count=cnt, bump=False)
         return loss
 
     def zero_grad(self, set_to_none=False):

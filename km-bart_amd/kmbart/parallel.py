@@ -108,6 +108,7 @@ class DistributedDataParallel(torch.nn.Module):
             from . import _lib
             _lib.load().kmb_gemm_shared_device(1)
             self._first_reduce = True
+            eng.adamw_overlap_ok = False   # gradients are final only after the all-reduce, not at the bucket events
 
     def _reduce(self):
         if self._first_reduce:

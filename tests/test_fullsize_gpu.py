@@ -117,3 +117,41 @@ def test_generation_modes(model):
     assert torch.equal(s1, s2) and s1.shape[0] == 6
     with pytest.raises((ValueError, AssertionError)):
         model.generate(max_length=12, num_beams=2, num_return_sequences=3, **kw)   # mixins.py:196-208
+
+
+def test_bucketwise_adamw_beside_backward_equals_the_single_launch():
+    """AdamW.step() issues the update per gradient bucket on a second stream, each launch behind that bucket's event of
+    the backward pass still running on the GPU.  After one step everything outside the tied matrix (whose gradient carries
+    the embedding scatter-add's fp32 atomics) must equal the single-launch update bit for bit; after three steps the two
+    trajectories agree to rounding noise."""
+    import bench
+    from kmbart.optim import AdamW
+    from src.data.synthetic import make_batch
+    from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration
+    d = _dev(make_batch(int(os.environ.get("KMB_TEST_ADAMW_BATCH", "64")), seed=77))   # 256 for a long backward
+    snaps = []
+    for overlap in (True, False):
+        torch.manual_seed(3)
+        m = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(dict(bench.VCG_BASE, dropout=0.0))).to(DEV)
+        m.train()
+        opt = AdamW(m.parameters(), lr=1e-3)
+        opt.overlap = overlap
+        eng = m._need_engine()
+        # weight gradients on the main stream: backward is then bit-reproducible (DESIGN.md section 5), so the optimizer
+        # overlap is the only variable
+        eng.lib.kmb_set_side_stream(eng.h, 0)
+        per_step = []
+        for _ in range(3):
+            _loss(m, d).backward()
+            opt.step()
+            torch.cuda.synchronize()
+            per_step.append([t.clone() for t in (eng.params, eng.exp_avg, eng.exp_avg_sq, eng.params_bf16)])
+        snaps.append(per_step)
+        del m, opt, eng
+    n_tied = 50320 * 768   # model.shared.weight: the last elements of the arena
+    for a, b, name in zip(snaps[0][0], snaps[1][0], ("params", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(a[:-n_tied], b[:-n_tied]), name + " after one step"
+        assert torch.allclose(a[-n_tied:], b[-n_tied:], rtol=1e-4, atol=1e-7), name + " (tied matrix) after one step"
+    for a, b, name in zip(snaps[0][2], snaps[1][2], ("params", "exp_avg", "exp_avg_sq", "bf16 mirror")):
+        err = float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+        assert err < 1e-3, (name, err)
