@@ -196,6 +196,8 @@ int kmb_gemm_shared_device(int on);
 /* ================= measurement ================= */
 /* time every GEMM launch of the following calls with HIP events on its own stream (bench.py roofline leg);
  * variant = a_kc*2 + b_kc: 3 forward (X W^T), 2 dgrad (dY W), 0 wgrad (dY^T X) */
+int kmb_debug_trace(int on);                          /* diagnostic: checksum intermediate buffers of kmb_backward */
+int kmb_debug_trace_dump(const char* path);           /* "index layer name checksum" per recorded buffer */
 int kmb_set_side_stream(kmb_handle* h, int enable);   /* weight-gradient GEMMs on a side stream (default on) */
 int kmb_profile_gemm(int enable);
 int kmb_profile_read(int variant, int64_t* launches, double* total_ms, double* total_flops);

@@ -12,7 +12,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libkmbart_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "embed.hip", "loss.hip", "optim.hip", "heads.hip", "engine.cpp", "capi_ops.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+# -fno-slp-vectorize: with SLP-packed fp32 math (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers on register pairs
+# assembled by v_mov) hipcc 7.2 produced an ln_bwd_kernel whose dz output is wrong in a few elements per launch (lanes 48-63,
+# one of the four values of a lane) whenever another kernel shares the GPU -- the source of run-to-run gradient
+# differences with the weight gradients on a second stream (tools/ln_bwd_contention.py: 20 of 20 contended runs differ at
+# -O2 / -O3, also with the SDWA peephole or early if-conversion off or the division replaced; 0 of 20 at -O1 and at -O3
+# without the SLP vectoriser).  Explicit two-wide vector code (kmb_f32x2) is not affected.  DESIGN.md section 5.
+FILE_FLAGS = {}
 
 
 def _stale(target, deps):
@@ -37,7 +44,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = ["hipcc", "-x", "hip"] + FLAGS + ["-c", s, "-o", o]
+        cmd = ["hipcc", "-x", "hip"] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, r.stderr[-4000:]))

@@ -288,6 +288,24 @@ int wgrad_side(kmb_handle* h, const KmbGemm& g, hipStream_t sA) {
   return 0;
 }
 
+// diagnostic: KMB_BWD_TRACE=1 checksums intermediate buffers of backward on their own stream (no synchronisation); the
+// table is printed by kmb_debug_trace_dump.  Finds the first buffer that differs between two passes.
+struct TraceRec { const char* name; int layer; };
+std::vector<TraceRec> g_trace;
+unsigned long long* g_trace_dev = nullptr;
+bool g_trace_on = false;
+int g_trace_layer = -1;
+int trace(const char* name, const void* p, size_t bytes, hipStream_t s) {
+  if (!g_trace_on) return 0;
+  static const char* only = getenv("KMB_BWD_TRACE_ONLY");   // substring filter: fewer probes disturb the timing less
+  if (only && !strstr(name, only)) return 0;
+  if (!g_trace_dev) HIPCHK(hipMalloc(&g_trace_dev, 4096 * sizeof(unsigned long long)));
+  if (g_trace.size() >= 4096) return 0;
+  HIPCHK(kmb_hash_words_launch(p, bytes, g_trace_dev + g_trace.size(), s));
+  g_trace.push_back({name, g_trace_layer});
+  return 0;
+}
+
 int bias_grad(kmb_handle* h, const bf16_t* dy, int ld, int M, int N, float* out, hipStream_t s) {
   HIPCHK(kmb_colsum_launch(dy, ld, M, N, h->parts, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, kmb_colsum_parts(M), N, out, N, s));
@@ -477,6 +495,7 @@ int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const b
   bf16_t* dsub = dr.thr16 ? bb.dsub[0] : dz;
   KCHK(ln_backward(h, dy, z, mean, rstd, L.ln_g, L.ln_b, dz, dr.thr16 ? dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
                    L.fc2_b));
+  KCHK(trace("ffn.dz", dz, (size_t)M * d * 2, s));
   KCHK(wgrad_side(h, lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(L.fc2_w), M, d, F);
   g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = bb.du; g.ld_out_bf16 = F;
@@ -484,9 +503,11 @@ int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const b
   KCHK(run_gemm(g, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, (M + 63) / 64, F, h->gf(L.fc1_b), F, s));
   KCHK(wgrad_side(h, lin_wgrad(bb.du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
+  KCHK(trace("ffn.du", bb.du, (size_t)M * F * 2, s));
   g = lin_dgrad(bb.du, F, h->wb(L.fc1_w), M, F, d);
   g.residual = dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
+  KCHK(trace("ffn.dx", dx_out, (size_t)M * d * 2, s));
   return 0;
 }
 
@@ -516,18 +537,24 @@ int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf
   bf16_t* dsub = dr.thr16 ? bb.dsub[1] : dz;
   KCHK(ln_backward(h, dy, z, mean, rstd, A.ln_g, A.ln_b, dz, dr.thr16 ? dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
                    A.o_b));
+  KCHK(trace("sa.dz", dz, (size_t)M * d * 2, s));
   KCHK(wgrad_side(h, lin_wgrad(dsub, d, o, d, h->gf(A.o_w), M, d, d, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(A.o_w), M, d, d);
   g.out_bf16 = h->dob; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
+  KCHK(trace("sa.dob", h->dob, (size_t)M * d * 2, s));
+  KCHK(trace("sa.o(saved)", o, (size_t)M * d * 2, s));
+  KCHK(trace("sa.qkv(saved)", qkv, (size_t)M * 3 * d * 2, s));
   AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
   KCHK(attn_backward(h, io, B, H, o, lse, h->dob, bb.dqkv, 3 * d, bb.dqkv + d, bb.dqkv + 2 * d, 3 * d, h->parts,
                      h->parts + d, h->parts + 2 * d, 3 * d, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(A.qkv_b), 3 * d, s));
+  KCHK(trace("sa.dqkv", bb.dqkv, (size_t)M * 3 * d * 2, s));
   KCHK(wgrad_side(h, lin_wgrad(bb.dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
   g = lin_dgrad(bb.dqkv, 3 * d, h->wb(A.qkv_w), M, 3 * d, d);
   g.residual = dz; g.ld_res = d; g.out_bf16 = dx_out; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
+  KCHK(trace("sa.dx", dx_out, (size_t)M * d * 2, s));
   return 0;
 }
 
@@ -949,6 +976,19 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
     if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   KCHK(ensure_side(h));
   const bool side = h->side_on && h->side != nullptr;
+  if (getenv("KMB_PRINT_LAYOUT")) {   // diagnostic: workspace addresses (overlap check)
+    auto pr = [&](const char* n, const void* p, size_t bytes) { fprintf(stderr, "LAYOUT %s %p %zu\n", n, p, bytes); };
+    const size_t Mm = (size_t)(Me > Md ? Me : Md);
+    pr("slab", h->slab, h->slab_floats * 4); pr("dhdec", h->dhdec, (size_t)Md * d * 2); pr("dyA", h->dyA, Mm * d * 2);
+    pr("dyB", h->dyB, Mm * d * 2); pr("dz", h->dz, Mm * d * 2); pr("dob", h->dob, Mm * d * 2); pr("denc", h->denc, (size_t)Me * d * 2);
+    pr("parts", h->parts, 0); pr("logits_c", h->logits_c, 0); pr("dlogits_c", h->dlogits_c, (size_t)Md * h->Vpad * 2);
+    for (int k = 0; k < 2; ++k) {
+      for (int st = 0; st < 3; ++st) { pr("bb.dz", h->bb[k].dz[st], Mm * d * 2); pr("bb.dsub", h->bb[k].dsub[st], Mm * d * 2); }
+      pr("bb.du", h->bb[k].du, Mm * (size_t)(h->Fe > h->Fd ? h->Fe : h->Fd) * 2); pr("bb.dqkv", h->bb[k].dqkv, Mm * 3 * d * 2);
+      pr("bb.dcq", h->bb[k].dcq, (size_t)Md * d * 2); pr("bb.dckv", h->bb[k].dckv, (size_t)Me * 2 * d * 2);
+    }
+    pr("ws_begin", h->ws, h->ws_bytes);
+  }
   int ev = 0;
   // layer c may only start once the side stream has finished layer c-2 (it still reads that layer's gradient buffers)
   auto layer_begin = [&](int c) -> int {
@@ -987,6 +1027,7 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
     DecAct& a = h->da[l];
     kmb_handle::BwdBufs& bb = h->bb[c & 1];
     KCHK(layer_begin(c));
+    g_trace_layer = 100 + l;
     bf16_t* t0 = pp[cur]; bf16_t* t1 = pp[cur ^ 1];
     KCHK(ffn_backward(h, L, h->Fd, a.y2, a.u, a.hh, a.z3, a.m3, a.r3, dy, t0, Md, h->drop_site(102 + 3 * l, tr), bb, s));
     {  // cross-attention block: y2 = LN(z2), z2 = y1 + drop(out_proj(attn(cq, ckv)))
@@ -995,6 +1036,7 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
       bf16_t* dsub = dr.thr16 ? bb.dsub[2] : dz;
       KCHK(ln_backward(h, t0, a.z2, a.m2, a.r2, L.ca.ln_g, L.ca.ln_b, dz, dr.thr16 ? dsub : nullptr,
                        KmbDrop{0u, 0u, 1.f}, dr, Md, s, L.ca.o_b));
+      KCHK(trace("ca.dz", dz, (size_t)Md * d * 2, s));
       KCHK(wgrad_side(h, lin_wgrad(dsub, d, a.o2, d, h->gf(L.ca.o_w), Md, d, d, 0.f), s));
       KmbGemm g = lin_dgrad(dsub, d, h->wb(L.ca.o_w), Md, d, d);
       g.out_bf16 = h->dob; g.ld_out_bf16 = d;
@@ -1004,6 +1046,9 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
                          h->parts + d, h->parts + 2 * d, 3 * d, s));
       // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn: q|k|v biases are adjacent
       HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(L.ca.qkv_b), 3 * d, s));
+      KCHK(trace("ca.dob", h->dob, (size_t)Md * d * 2, s));
+      KCHK(trace("ca.dcq", bb.dcq, (size_t)Md * d * 2, s));
+      KCHK(trace("ca.dckv", bb.dckv, (size_t)Me * 2 * d * 2, s));
       KCHK(wgrad_side(h, lin_wgrad(bb.dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
       g = lin_dgrad(bb.dcq, d, h->wb(L.ca.qkv_w), Md, d, d);
       g.residual = dz; g.ld_res = d; g.out_bf16 = t1; g.ld_out_bf16 = d;
@@ -1013,6 +1058,8 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
       if (denc_init) { g.residual = h->denc; g.ld_res = d; }
       g.out_bf16 = h->denc; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
+      KCHK(trace("ca.t1", t1, (size_t)Md * d * 2, s));
+      KCHK(trace("ca.denc", h->denc, (size_t)Me * d * 2, s));
       denc_init = true;
     }
     KCHK(self_attn_backward(h, L.sa, h->Hd, h->xd[l], a.qkv, a.o1, a.lse1, a.z1, a.m1, a.r1, t1, t0, B, T,
@@ -1041,6 +1088,7 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
     EncAct& a = h->ea[l];
     kmb_handle::BwdBufs& bb = h->bb[c & 1];
     KCHK(layer_begin(c));
+    g_trace_layer = l;
     bf16_t* t0 = pp[cur]; bf16_t* t1 = pp[cur ^ 1];
     KCHK(ffn_backward(h, L, h->Fe, a.y1, a.u, a.hh, a.z2, a.m2, a.r2, dy, t0, Me, h->drop_site(11 + 2 * l, tr), bb, s));
     KCHK(self_attn_backward(h, L.sa, h->He, h->xe[l], a.qkv, a.o, a.lse, a.z1, a.m1, a.r1, t0, t1, B, S,
@@ -1068,6 +1116,23 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
   }
   HIPCHK(hipEventRecord(h->events[ev++], s));
   HIPCHK(hipEventRecord(h->events[ev++], s));  // tied matrix: complete once the encoder-side scatter-add is in
+  return 0;
+}
+
+// diagnostic: start (on = 1) / stop recording buffer checksums in backward; dump prints "index layer name checksum"
+int kmb_debug_trace(int on) {
+  g_trace_on = on != 0;
+  if (on) g_trace.clear();
+  return 0;
+}
+int kmb_debug_trace_dump(const char* path) {
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<unsigned long long> hst(g_trace.size());
+  if (!hst.empty()) HIPCHK(hipMemcpy(hst.data(), g_trace_dev, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  FILE* f = fopen(path, "w");
+  if (!f) return fail("kmb_debug_trace_dump: cannot open %s", path);
+  for (size_t i = 0; i < hst.size(); ++i) fprintf(f, "%zu %d %s %016llx\n", i, g_trace[i].layer, g_trace[i].name, hst[i]);
+  fclose(f);
   return 0;
 }
 

@@ -105,6 +105,7 @@ hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst
 hipError_t kmb_dropout_mask_launch(uint32_t seed, uint32_t thr16, int rows, int cols, uint8_t* keep, hipStream_t stream);
 hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, hipStream_t stream);
 hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, hipStream_t stream);
+hipError_t kmb_hash_words_launch(const void* x, size_t nbytes, unsigned long long* out, hipStream_t stream);
 
 // ---------------------------------------------------------------- heads.hip
 hipError_t kmb_kl_div_launch(const float* logits, int ld, int C, const float* target, int ldt, int rows,

@@ -223,6 +223,23 @@ hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, hipStream_t strea
   hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, stream, x, n >> 3, s);
   return hipGetLastError();
 }
+// diagnostic (KMB_BWD_TRACE): order-independent 64-bit checksum of a buffer, accumulated into *out by integer atomics
+__global__ __launch_bounds__(256) void hash_words_kernel(const uint32_t* __restrict__ x, size_t n, unsigned long long* out) {
+  unsigned long long a = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned long long v = x[i] + 0x9E3779B97F4A7C15ull * (i + 1);
+    v ^= v >> 29; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 32;
+    a += v;
+  }
+  atomicAdd(out, a);
+}
+hipError_t kmb_hash_words_launch(const void* x, size_t nbytes, unsigned long long* out, hipStream_t stream) {
+  (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), stream);
+  const size_t n = nbytes / 4;
+  hipLaunchKernelGGL(hash_words_kernel, dim3(256), dim3(256), 0, stream, (const uint32_t*)x, n, out);
+  return hipGetLastError();
+}
+
 hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, stream, x, n, s);

@@ -7,7 +7,7 @@ import torch  # noqa: F401  -- must come first: torch bundles its own HIP runtim
 #                              before it would map a second runtime from /opt/rocm and break stream sharing
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libkmbart_hip.so")
+LIB_PATH = os.environ.get("KMB_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libkmbart_hip.so")   # KMB_LIB_PATH: a diagnostic build of the same library
 
 c_p = C.c_void_p
 i32, i64, u32, f32, f64 = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
@@ -101,6 +101,8 @@ PROTOTYPES = {
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kmb_gemm_shared_device": (C.c_int, [C.c_int]),
+    "kmb_debug_trace": (C.c_int, [C.c_int]),
+    "kmb_debug_trace_dump": (C.c_int, [C.c_char_p]),
     "kmb_set_side_stream": (C.c_int, [c_p, C.c_int]),
     "kmb_profile_gemm": (C.c_int, [C.c_int]),
     "kmb_profile_read": (C.c_int, [C.c_int, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),

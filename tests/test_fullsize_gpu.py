@@ -137,9 +137,6 @@ def test_bucketwise_adamw_beside_backward_equals_the_single_launch():
         opt = AdamW(m.parameters(), lr=1e-3)
         opt.overlap = overlap
         eng = m._need_engine()
-        # weight gradients on the main stream: backward is then bit-reproducible, so the optimizer
-        # overlap is the only variable
-        eng.lib.kmb_set_side_stream(eng.h, 0)
         per_step = []
         for _ in range(3):
             _loss(m, d).backward()
@@ -155,3 +152,26 @@ def test_bucketwise_adamw_beside_backward_equals_the_single_launch():
     for a, b, name in zip(snaps[0][2], snaps[1][2], ("params", "exp_avg", "exp_avg_sq", "bf16 mirror")):
         err = float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
         assert err < 1e-3, (name, err)
+
+
+def test_backward_is_bit_reproducible_with_the_weight_gradients_on_a_second_stream(model):
+    """The same batch twice through forward + backward: every gradient except the tied matrix (fp32 atomics of the
+    embedding scatter-add) must come back bit for bit, although the weight-gradient GEMMs run on a second stream beside
+    the rest of backward.  (They did not until the library was built without the SLP vectoriser: its packed-fp32 code in
+    the LayerNorm backward kernel produced a few wrong elements whenever another kernel shared the GPU -- DESIGN.md
+    section 5, tools/ln_bwd_contention.py.)"""
+    from src.data.synthetic import make_batch
+    d = _dev(make_batch(64, seed=78))
+    model.train()
+    eng = model._need_engine()
+    grads = []
+    for _ in range(4):
+        _loss(model, d).backward()
+        torch.cuda.synchronize()
+        grads.append(eng.grads.clone())
+    off, rows, cols = eng.index["model.shared.weight"]
+    for g in grads[2:]:
+        same = grads[1] == g
+        same[off: off + rows * cols] = True
+        assert bool(same.all()), int((~same).sum())
+        assert torch.allclose(grads[1][off: off + rows * cols], g[off: off + rows * cols], rtol=0, atol=1e-5)

@@ -64,3 +64,18 @@ run("dgrad GEMM 2048x768x2304 + residual", lambda: gemm(X2, W2, a_kc=True, b_kc=
 W3 = bf(torch.randn(3072, 768, device=DEV) * 0.05); o3 = torch.zeros(2048, 3072, dtype=torch.bfloat16, device=DEV)
 p3 = torch.zeros(2048, 3072, dtype=torch.bfloat16, device=DEV); bias = torch.randn(3072, device=DEV)
 run("fwd GEMM 2048x3072x768 GeLU", lambda: gemm(X, W3, bias=bias, act=1, preact=p3, out_bf16=o3), [o3, p3])
+# LayerNorm backward, decoder shape
+M, D = 2048, 768
+z = bf(torch.randn(M, D, device=DEV)); gamma = torch.randn(D, device=DEV)
+mean, rstd = z.float().mean(-1), (z.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+dy = bf(torch.randn(M, D, device=DEV)); dz = torch.zeros_like(z)
+dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+scratch = torch.empty(int(lib.kmb_op_ln_bwd_scratch(M, D)), device=DEV)
+run("ln_bwd 2048x768", lambda: check(lib.kmb_op_ln_bwd(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), None, None, None,
+                                                        ptr(dg), ptr(db), ptr(scratch), M, D, stream())), [dz, dg, db])
+M = 4096
+z = bf(torch.randn(M, D, device=DEV)); mean, rstd = z.float().mean(-1), (z.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+dy = bf(torch.randn(M, D, device=DEV)); dz = torch.zeros_like(z)
+scratch = torch.empty(int(lib.kmb_op_ln_bwd_scratch(M, D)), device=DEV)
+run("ln_bwd 4096x768", lambda: check(lib.kmb_op_ln_bwd(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), None, None, None,
+                                                        ptr(dg), ptr(db), ptr(scratch), M, D, stream())), [dz, dg, db])
