@@ -79,3 +79,13 @@ dy = bf(torch.randn(M, D, device=DEV)); dz = torch.zeros_like(z)
 scratch = torch.empty(int(lib.kmb_op_ln_bwd_scratch(M, D)), device=DEV)
 run("ln_bwd 4096x768", lambda: check(lib.kmb_op_ln_bwd(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), None, None, None,
                                                         ptr(dg), ptr(db), ptr(scratch), M, D, stream())), [dz, dg, db])
+# large forward / data-gradient shapes (the persistent variants when KMB_GEMM_VARIANT=11 / 12 is set)
+Mb = 16384
+Xb = bf(torch.randn(Mb, 768, device=DEV)); ob = torch.zeros(Mb, 3072, dtype=torch.bfloat16, device=DEV); pb = torch.zeros_like(ob)
+run("fwd GEMM 16384x3072x768 bias + GeLU + pre-activation", lambda: gemm(Xb, W3, bias=bias, act=1, preact=pb, out_bf16=ob), [ob, pb])
+Hb = bf(torch.randn(Mb, 3072, device=DEV)); W4 = bf(torch.randn(768, 3072, device=DEV) * 0.05); Rb = bf(torch.randn(Mb, 768, device=DEV))
+o4 = torch.zeros(Mb, 768, dtype=torch.bfloat16, device=DEV); b4 = torch.randn(768, device=DEV)
+run("fwd GEMM 16384x768x3072 bias + dropout + residual", lambda: gemm(Hb, W4, bias=b4, residual=Rb, drop_p=0.1, drop_seed=7, out_bf16=o4), [o4])
+W5 = bf(torch.randn(768, 3072, device=DEV) * 0.05); aux = bf(torch.randn(Mb, 3072, device=DEV)); cs = torch.zeros((Mb + 63) // 64, 3072, device=DEV)
+o5 = torch.zeros(Mb, 3072, dtype=torch.bfloat16, device=DEV)
+run("dgrad GEMM 16384x3072x768 GeLU' + column sums", lambda: gemm(Xb, W5, a_kc=True, b_kc=False, act=2, aux=aux, colsum=cs, out_bf16=o5), [o5, cs])
