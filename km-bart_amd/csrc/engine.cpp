@@ -322,8 +322,8 @@ int ln_backward(kmb_handle* h, const bf16_t* dy, const bf16_t* z, const float* m
   HIPCHK(kmb_ln_bwd_launch(dy, z, mean, rstd, h->pf(g_off), dz, out2, dy_drop, out2_drop, h->parts, M, d, s));
   const int np = kmb_ln_bwd_parts(M);
   // partials are [np][3][d]: dgamma | dbeta (adjacent in the arena too: one reduce) | column sums of the sub-layer gradient
-  HIPCHK(kmb_reduce_parts_launch(h->parts, np, 3 * d, h->gf(g_off), 2 * d, s));
-  if (bias_off != NO_BIAS) HIPCHK(kmb_reduce_parts_launch(h->parts + 2 * d, np, 3 * d, h->gf(bias_off), d, s));
+  if (bias_off != NO_BIAS) HIPCHK(kmb_reduce_parts2_launch(h->parts, np, 3 * d, h->gf(g_off), 2 * d, h->gf(bias_off), d, s));
+  else HIPCHK(kmb_reduce_parts_launch(h->parts, np, 3 * d, h->gf(g_off), 2 * d, s));
   return 0;
 }
 

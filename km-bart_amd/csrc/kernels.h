@@ -36,6 +36,8 @@ hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mea
 // out[c] = sum_p partials[p*stride + c]  for c < n   (overwrites)
 hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride, float* out, int n,
                                    hipStream_t stream);
+hipError_t kmb_reduce_parts2_launch(const float* partials, int nparts, int stride, float* out1, int n1, float* out2, int n2,
+                                    hipStream_t stream);
 hipError_t kmb_ln_fwd_slabs_launch(const float* slabs, int nslabs, size_t stride, const float* bias, const bf16_t* residual,
                                    int ld_res, const float* gamma, const float* beta, bf16_t* y, int M, int D, float eps,
                                    hipStream_t stream);

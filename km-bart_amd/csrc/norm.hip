@@ -250,12 +250,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 
 // out[c] = beta*out[c] + sum_p partials[p*stride + c].  Two shapes of the same reduction:
 //  (a) many partial rows, few columns (LayerNorm / bias gradients): 32 columns x 8 part-lanes per block
+// (out2 != nullptr: columns [n, n + n2) of the partial rows go to out2 -- LayerNorm's dgamma | dbeta and the bias gradient
+//  of the sub-layer in ONE launch)
 template <int PL>  // part-lanes per block: 32 columns x PL part-lanes
 __global__ __launch_bounds__(32 * PL) void reduce_parts_kernel(const float* __restrict__ partials, int nparts,
-                                                               size_t stride, float* __restrict__ out, int n) {
+                                                               size_t stride, float* __restrict__ out, int n_all,
+                                                               float* __restrict__ out2, int n1) {
   __shared__ float red[PL][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
+  const int n = n_all;
   float s = 0.f;
   if (c < n) {
 #pragma unroll 8
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(32 * PL) void reduce_parts_kernel(const float* __re
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < PL; ++k) t += red[k][cl];
-    out[c] = t;
+    if (out2 != nullptr && c >= n1) out2[c - n1] = t;
+    else out[c] = t;
   }
 }
 //  (b) few slabs, many elements (split-K weight gradients): float4 per thread
@@ -398,9 +403,21 @@ hipError_t kmb_reduce_parts_launch(const float* partials, int nparts, int stride
   // only n / 32 blocks exist (72 for a LayerNorm): with many partial rows the kernel is latency-bound, so give each
   // block 32 part-lanes (1024 threads) worth of loads in flight
   if (nparts >= 256)
-    hipLaunchKernelGGL((reduce_parts_kernel<32>), dim3((n + 31) / 32), dim3(1024), 0, stream, partials, nparts, (size_t)stride, out, n);
+    hipLaunchKernelGGL((reduce_parts_kernel<32>), dim3((n + 31) / 32), dim3(1024), 0, stream, partials, nparts, (size_t)stride, out, n, (float*)nullptr, n);
   else
-    hipLaunchKernelGGL((reduce_parts_kernel<8>), dim3((n + 31) / 32), dim3(256), 0, stream, partials, nparts, (size_t)stride, out, n);
+    hipLaunchKernelGGL((reduce_parts_kernel<8>), dim3((n + 31) / 32), dim3(256), 0, stream, partials, nparts, (size_t)stride, out, n, (float*)nullptr, n);
+  return hipGetLastError();
+}
+
+// the same with two destinations: columns [0, n1) -> out1, [n1, n1 + n2) -> out2
+hipError_t kmb_reduce_parts2_launch(const float* partials, int nparts, int stride, float* out1, int n1, float* out2, int n2,
+                                    hipStream_t stream) {
+  const int n = n1 + n2;
+  if (n <= 0) return hipSuccess;
+  if (nparts >= 256)
+    hipLaunchKernelGGL((reduce_parts_kernel<32>), dim3((n + 31) / 32), dim3(1024), 0, stream, partials, nparts, (size_t)stride, out1, n, out2, n1);
+  else
+    hipLaunchKernelGGL((reduce_parts_kernel<8>), dim3((n + 31) / 32), dim3(256), 0, stream, partials, nparts, (size_t)stride, out1, n, out2, n1);
   return hipGetLastError();
 }
 
