@@ -1,5 +1,7 @@
+"""Debug: parameters / gradients after one step with the optimizer issued per bucket beside backward vs in one launch,
+and two plain runs against each other (which arena ranges differ)."""
 import os, sys
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, ROOT+"/km-bart_amd", ROOT+"/tests"): sys.path.insert(0,p)
 import torch, bench
 from kmbart.optim import AdamW

@@ -1,5 +1,7 @@
+"""LayerNorm backward alone and beside a long GEMM on a second stream: which outputs differ from the solo result, by how
+much and where (the SLP-vectoriser finding of DESIGN.md section 5; 0 differing runs with the library as built now)."""
 import ctypes as C, os, sys
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT+"/km-bart_amd"); sys.path.insert(0, ROOT+"/tests")
 import torch
 from gpu_util import DEV, bf, check, gemm, ptr, stream

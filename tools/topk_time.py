@@ -1,6 +1,6 @@
 """Time of the log-softmax top-k kernel at the decode shape (320 rows x 50320) for several k."""
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "km-bart_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from gpu_util import DEV, ptr, stream, check
