@@ -891,7 +891,8 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       // slabs into the bf16 gradient.  The slabs live in the fp32 logits buffer, which is free once the CE ran.
       const int tiles256 = ((Md + 255) / 256) * ((d + 255) / 256);
       const size_t CHl = (size_t)(Md < h->lm_chunk ? Md : h->lm_chunk) * h->Vpad;   // floats in the logits buffer
-      int S = tiles256 > 0 ? (256 * 3) / tiles256 : 1;
+      static const int rounds = getenv("KMB_HEAD_DGRAD_ROUNDS") ? atoi(getenv("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
+      int S = tiles256 > 0 ? (256 * rounds) / tiles256 : 1;
       if (S > 8) S = 8;
       while (S > 1 && (size_t)S * Md * d > CHl) --S;
       if (S > 1 && ((size_t)Md * d & 7) == 0 && h->Vpad / 64 >= 2 * S) {
