@@ -161,6 +161,7 @@ def main():
     ddp = DistributedDataParallel(model, device_ids=[local], reduce_single_rank=force_dist) if use_dist else model
     ddp.train()
     opt = AdamW(model.parameters(), lr=args.lr)
+    opt.allow_overlap(True)   # train_step_fwd_bwd + step run back to back: nothing touches the gradients in between
 
     parity = None
     if rank == 0 and args.gpus == 1:

@@ -148,8 +148,32 @@ int kmb_stream_wait_bucket(kmb_handle* h, int i, void* stream);
 int kmb_logits_ld(const kmb_handle* h);
 int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad, float* loss_out,
                 float* logits_out, kmb_bf16* enc_out, void* stream);
+/* Optional inputs / outputs of the forward that the bare MultiModalBartModel and the `encoder_outputs` keyword need
+ * (src/model/model.py:39-103): */
+typedef struct kmb_forward_opts {
+  const kmb_bf16* encoder_states;   /* [B*S, d_model] or NULL: skip the encoder and use these states (model.py:76-83) */
+  kmb_bf16* decoder_states_out;     /* [B*T, d_model] or NULL: copy of the last decoder hidden states (model.py:87-103) */
+  int32_t skip_head;                /* 1: stop after the decoder (no logits, no loss): MultiModalBartModel.forward */
+} kmb_forward_opts;
+/* kmb_forward with those options; need_grad must be 0 when encoder_states is given.  In the fp32 validation mode the
+ * kmb_bf16 pointers of kmb_forward / kmb_forward_ex carry floats (kmb_act_bytes() == 4). */
+int kmb_forward_ex(kmb_handle* h, const kmb_batch* batch, const kmb_forward_opts* opts, int train, int need_grad,
+                   float* loss_out, float* logits_out, kmb_bf16* enc_out, void* stream);
+/* logits [B*T, kmb_logits_ld()] of the decoder states the LAST forward left in the workspace: `outputs[1]` of a training
+ * forward (src/model/model.py:397-405) as one extra head GEMM instead of 1.6 GB written every step */
+int kmb_last_logits(kmb_handle* h, float* logits_out, void* stream);
+/* fp32 VALIDATION mode (1) / bf16 product mode (0, default).  Mode 1 keeps every activation in float and runs the
+ * eval-mode forward on exact-fp32 kernels (csrc/fp32_validate.hip) against the fp32 master weights: parity evidence for
+ * north_star's "logits within 1e-3 of the fp32 reference path", never the measured path.  Training, backward and
+ * generation are refused in mode 1.  Rebind the workspace after switching (kmb_workspace_bytes doubles). */
+int kmb_set_precision(kmb_handle* h, int fp32);
+int kmb_act_bytes(const kmb_handle* h);
 /* loss.backward() (src/training.py:138,142); loss_scale multiplies every gradient */
 int kmb_backward(kmb_handle* h, float loss_scale, void* stream);
+/* the same with the scale as a DEVICE scalar: autograd hands `loss.backward()` its upstream gradient (ones, or the
+ * GradScaler's scale, src/training.py:137-142) as a device tensor; reading it on the device keeps the API path free of a
+ * host synchronisation.  A scale of exactly 1 costs three early-exit launches. */
+int kmb_backward_dev(kmb_handle* h, const float* loss_scale_dev, void* stream);
 /* transformers.AdamW.step (vcg_train.py:100, src/training.py:139,143) over [offset, offset+count) */
 int kmb_adamw_step(kmb_handle* h, const KmbAdamW* hp, int64_t offset, int64_t count, void* stream);
 /* status word written by device-side input validation (bit 0: #<img_feat> ids != #region rows) */
@@ -179,9 +203,10 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
 /* _reorder_cache (src/model/mixins.py:419-434): self-attention caches follow beam_idx [B*num_beams] */
 int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stream);
 /* log_softmax + top-k per row of (logp + add[row]); force_token >= 0 forces that token
- * (adjust_logits_during_generation, src/model/mixins.py:400-417) */
-int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int k,
-                        float* out_val, int32_t* out_idx, void* stream);
+ * (adjust_logits_during_generation, src/model/mixins.py:400-417); ban_token >= 0 scores that token -inf AFTER the
+ * normalisation (min_length: transformers 3.0.2 postprocess_next_token_scores acts on the log-probabilities) */
+int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
+                        int k, float* out_val, int32_t* out_idx, void* stream);
 /* one beam-search step's candidate selection (mixins.py beam loop: topk over num_beams * V): per batch item the best k of
  * its beams' top-k lists; out[B][k][2] int32 = {fp32 score bits, beam * V + token} */
 int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream);

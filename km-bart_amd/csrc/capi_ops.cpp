@@ -113,9 +113,9 @@ int kmb_gemm_shared_device(int on) {
 int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream) {
   return hipfail(kmb_beam_merge_launch(val, idx, B, num_beams, k, V, out, (hipStream_t)stream), "beam_merge");
 }
-int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int k,
-                        float* out_val, int32_t* out_idx, void* stream) {
-  return hipfail(kmb_logsoftmax_topk_launch(logits, ld, V, rows, add, force_token, k, out_val, out_idx, (hipStream_t)stream), "logsoftmax_topk");
+int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
+                        int k, float* out_val, int32_t* out_idx, void* stream) {
+  return hipfail(kmb_logsoftmax_topk_launch(logits, ld, V, rows, add, force_token, ban_token, k, out_val, out_idx, (hipStream_t)stream), "logsoftmax_topk");
 }
 
 }  // extern "C"

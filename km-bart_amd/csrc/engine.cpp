@@ -47,6 +47,14 @@ inline uint64_t splitmix(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// fp32 validation mode (kmb_set_precision): activations are float, the GEMM / attention / LayerNorm / embedding launches
+// go to the plain fp32 kernels of fp32_validate.hip.  Activation pointers keep their bf16_t* type in the host code;
+// EP() advances them by ELEMENTS of the current width.  Set for the duration of one forward call (a handle is
+// single-threaded, include/kmbart.h).
+thread_local bool g_f32 = false;
+inline size_t esz() { return g_f32 ? 4 : 2; }
+template <typename T> inline T* EP(T* p, size_t n) { return (T*)((char*)p + n * esz()); }
+
 struct ParamInfo { std::string name; size_t off; int rows, cols; };
 struct AttnP { size_t qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
 struct LayerP { AttnP sa, ca; size_t fc1_w, fc1_b, fc2_w, fc2_b, ln_g, ln_b; };
@@ -68,6 +76,8 @@ class Bump {
     off_ += n * sizeof(T);
     return p;
   }
+  // n activation elements of the current precision (bf16, or float in the fp32 validation mode)
+  bf16_t* act(size_t n) { return reinterpret_cast<bf16_t*>(take<char>(n * esz())); }
   size_t used() const { return align_up(off_, 256); }
   bool ok() const { return base_ == nullptr || off_ <= cap_; }
  private:
@@ -93,6 +103,8 @@ struct kmb_handle {
   bf16_t* imgw_pad = nullptr;       // inside the bf16 arena tail: [d, Fpad]
   char* ws = nullptr; size_t ws_bytes = 0;
   uint64_t seed = 0x5eedULL; uint64_t step = 0;
+  bool fp32 = false;    // kmb_set_precision(1): fp32 validation forward
+  bool have_hdec = false;   // xd[Ld] of the last forward is still in the workspace (kmb_last_logits)
   int lm_chunk = 8192;  // rows of fp32 logits per LM-head launch (bounds the logits buffer at 1.65 GB for V = 50320)
   // ---- state of the last forward (consumed by backward)
   kmb_batch bt{}; bool have_fwd = false; bool fwd_train = false;
@@ -139,12 +151,17 @@ struct kmb_handle {
     dr.scale = 1.f / (1.f - (float)thr / 65536.f);
     return dr;
   }
-  bf16_t* wb(size_t off) const { return PB + off; }
+  bf16_t* wb(size_t off) const { return g_f32 ? reinterpret_cast<bf16_t*>(P + off) : PB + off; }   // GEMM B operand: bf16 mirror (fp32 master in validation mode)
   float* pf(size_t off) const { return P + off; }
   float* gf(size_t off) const { return G + off; }
 };
 
 namespace {
+
+struct PrecisionScope {   // g_f32 follows the handle for the duration of one call
+  explicit PrecisionScope(const kmb_handle* h) { g_f32 = h->fp32; }
+  ~PrecisionScope() { g_f32 = false; }
+};
 
 size_t add_param(kmb_handle* h, const std::string& name, int rows, int cols) {
   h->arena = align_up(h->arena, 64);
@@ -190,6 +207,12 @@ struct GemmProfiler {
 KmbGemm gemm0() { KmbGemm g; memset(&g, 0, sizeof(g)); g.col_scale = 1.f; g.drop_scale = 1.f; return g; }
 
 int run_gemm(const KmbGemm& g, hipStream_t s) {
+  if (g_f32) {
+    const char* why32 = kmb_f32_gemm_check(g);
+    if (why32) return fail("fp32 validation GEMM: %s", why32);
+    HIPCHK(kmb_f32_gemm_launch(g, s));
+    return 0;
+  }
   const char* why = kmb_gemm_check(g);
   if (why) return fail("%s (M=%d N=%d K=%d lda=%d ldb=%d akc=%d bkc=%d)", why, g.M, g.N, g.K, g.lda, g.ldb, g.a_kc, g.b_kc);
   if (g_prof.on) {
@@ -356,59 +379,59 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   int32_t* status = bp.take<int32_t>(4);
   int32_t* count = bp.take<int32_t>(4);
   float* loss_dev = bp.take<float>(4);
-  bf16_t* xf = bp.take<bf16_t>((size_t)(Ntot > 0 ? Ntot : 1) * h->Fpad);
+  bf16_t* xf = bp.act((size_t)(Ntot > 0 ? Ntot : 1) * h->Fpad);
   float* img_emb = bp.take<float>((size_t)(Ntot > 0 ? Ntot : 1) * d);
-  bf16_t* dimg = bp.take<bf16_t>((size_t)(Ntot > 0 ? Ntot : 1) * d);
+  bf16_t* dimg = bp.act((size_t)(Ntot > 0 ? Ntot : 1) * d);
   int32_t* img_src = bp.take<int32_t>(Me);
-  bf16_t* ze0 = bp.take<bf16_t>(Me * d);
+  bf16_t* ze0 = bp.act(Me * d);
   float* me0 = bp.take<float>(Me); float* re0 = bp.take<float>(Me);
-  bf16_t* zd0 = bp.take<bf16_t>(Md * d);
+  bf16_t* zd0 = bp.act(Md * d);
   float* md0 = bp.take<float>(Md); float* rd0 = bp.take<float>(Md);
   std::vector<bf16_t*> xe(Le + 1), xd(Ld + 1);
-  for (int l = 0; l <= Le; ++l) xe[l] = bp.take<bf16_t>(Me * d);
-  for (int l = 0; l <= Ld; ++l) xd[l] = bp.take<bf16_t>(Md * d);
+  for (int l = 0; l <= Le; ++l) xe[l] = bp.act(Me * d);
+  for (int l = 0; l <= Ld; ++l) xd[l] = bp.act(Md * d);
   std::vector<EncAct> ea(Le);
   for (int l = 0; l < Le; ++l) {
     EncAct& a = ea[l];
-    a.qkv = bp.take<bf16_t>(Me * 3 * d); a.o = bp.take<bf16_t>(Me * d); a.z1 = bp.take<bf16_t>(Me * d);
-    a.y1 = bp.take<bf16_t>(Me * d); a.u = bp.take<bf16_t>(Me * Fe); a.hh = bp.take<bf16_t>(Me * Fe);
-    a.z2 = bp.take<bf16_t>(Me * d);
+    a.qkv = bp.act(Me * 3 * d); a.o = bp.act(Me * d); a.z1 = bp.act(Me * d);
+    a.y1 = bp.act(Me * d); a.u = bp.act(Me * Fe); a.hh = bp.act(Me * Fe);
+    a.z2 = bp.act(Me * d);
     a.lse = bp.take<float>((size_t)B * h->He * S);
     a.m1 = bp.take<float>(Me); a.r1 = bp.take<float>(Me); a.m2 = bp.take<float>(Me); a.r2 = bp.take<float>(Me);
   }
   std::vector<DecAct> da(Ld);
   for (int l = 0; l < Ld; ++l) {
     DecAct& a = da[l];
-    a.qkv = bp.take<bf16_t>(Md * 3 * d); a.o1 = bp.take<bf16_t>(Md * d); a.z1 = bp.take<bf16_t>(Md * d);
-    a.y1 = bp.take<bf16_t>(Md * d); a.cq = bp.take<bf16_t>(Md * d); a.ckv = bp.take<bf16_t>(Me * 2 * d);
-    a.o2 = bp.take<bf16_t>(Md * d); a.z2 = bp.take<bf16_t>(Md * d); a.y2 = bp.take<bf16_t>(Md * d);
-    a.u = bp.take<bf16_t>(Md * Fd); a.hh = bp.take<bf16_t>(Md * Fd); a.z3 = bp.take<bf16_t>(Md * d);
+    a.qkv = bp.act(Md * 3 * d); a.o1 = bp.act(Md * d); a.z1 = bp.act(Md * d);
+    a.y1 = bp.act(Md * d); a.cq = bp.act(Md * d); a.ckv = bp.act(Me * 2 * d);
+    a.o2 = bp.act(Md * d); a.z2 = bp.act(Md * d); a.y2 = bp.act(Md * d);
+    a.u = bp.act(Md * Fd); a.hh = bp.act(Md * Fd); a.z3 = bp.act(Md * d);
     a.lse1 = bp.take<float>((size_t)B * h->Hd * T); a.lse2 = bp.take<float>((size_t)B * h->Hd * T);
     a.m1 = bp.take<float>(Md); a.r1 = bp.take<float>(Md); a.m2 = bp.take<float>(Md); a.r2 = bp.take<float>(Md);
     a.m3 = bp.take<float>(Md); a.r3 = bp.take<float>(Md);
   }
   const size_t CH = Md < (size_t)h->lm_chunk ? Md : (size_t)h->lm_chunk;
   float* logits_c = bp.take<float>(CH * h->Vpad);
-  bf16_t* dlogits_c = bp.take<bf16_t>(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
+  bf16_t* dlogits_c = bp.act(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
   const size_t slab_floats = (size_t)20 << 20;          // split-K partial slabs of the weight-gradient GEMMs (80 MB)
   float* slab = bp.take<float>(slab_floats);
   float* loss_rows = bp.take<float>(Md);
-  bf16_t* dhdec = bp.take<bf16_t>(Md * d);
-  bf16_t* dyA = bp.take<bf16_t>(Mmax * d); bf16_t* dyB = bp.take<bf16_t>(Mmax * d);
-  bf16_t* dz = bp.take<bf16_t>(Mmax * d);
+  bf16_t* dhdec = bp.act(Md * d);
+  bf16_t* dyA = bp.act(Mmax * d); bf16_t* dyB = bp.act(Mmax * d);
+  bf16_t* dz = bp.act(Mmax * d);
   const int Fmax = Fe > Fd ? Fe : Fd;
   kmb_handle::BwdBufs bb[2];
   for (int k = 0; k < 2; ++k) {
     for (int site = 0; site < 3; ++site) {
-      bb[k].dz[site] = bp.take<bf16_t>(Mmax * d);
-      bb[k].dsub[site] = bp.take<bf16_t>(Mmax * d);
+      bb[k].dz[site] = bp.act(Mmax * d);
+      bb[k].dsub[site] = bp.act(Mmax * d);
     }
-    bb[k].du = bp.take<bf16_t>(Mmax * Fmax);
-    bb[k].dqkv = bp.take<bf16_t>(Mmax * 3 * d);
-    bb[k].dcq = bp.take<bf16_t>(Md * d);
-    bb[k].dckv = bp.take<bf16_t>(Me * 2 * d);
+    bb[k].du = bp.act(Mmax * Fmax);
+    bb[k].dqkv = bp.act(Mmax * 3 * d);
+    bb[k].dcq = bp.act(Md * d);
+    bb[k].dckv = bp.act(Me * 2 * d);
   }
-  bf16_t* dob = bp.take<bf16_t>(Mmax * d); bf16_t* denc = bp.take<bf16_t>(Me * d);
+  bf16_t* dob = bp.act(Mmax * d); bf16_t* denc = bp.act(Me * d);
   float* parts = bp.take<float>(parts_floats(h, (int)Mmax, B));
   // pre-training head scratch (only when heads exist and rows were reserved)
   bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr;
@@ -419,8 +442,8 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     size_t Cpad = 8;
     for (int k = 0; k < 3; ++k)
       if (h->head[k].on && align_up((size_t)h->head[k].C, 8) > Cpad) Cpad = align_up((size_t)h->head[k].C, 8);
-    hx = bp.take<bf16_t>(n * 2 * d); hy = bp.take<bf16_t>(n * d); hdy = bp.take<bf16_t>(n * d);
-    hdx = bp.take<bf16_t>(n * 2 * d); hdlg = bp.take<bf16_t>(n * Cpad); hlg = bp.take<float>(n * Cpad);
+    hx = bp.act(n * 2 * d); hy = bp.act(n * d); hdy = bp.act(n * d);
+    hdx = bp.act(n * 2 * d); hdlg = bp.act(n * Cpad); hlg = bp.take<float>(n * Cpad);
     hloss = bp.take<float>(n); dhead = bp.take<float>(Md * d);
   }
   if (assign) {
@@ -450,9 +473,31 @@ int attn_forward(kmb_handle* h, const AttnIO& io, int B, int H, bf16_t* o, float
   a.Q = io.q; a.K = io.k; a.V = io.v; a.ldq = io.ldq; a.ldk = io.ldkv; a.ldv = io.ldkv;
   a.B = B; a.H = H; a.Tq = io.Tq; a.Tk = io.Tk; a.key_mask = io.mask; a.causal = io.causal;
   a.O = o; a.ldo = h->d; a.lse = lse;
+  if (g_f32) { HIPCHK(kmb_f32_attn_fwd_launch(a, s)); return 0; }
   const char* why = kmb_attn_check(a, 0);
   if (why) return fail("%s", why);
   HIPCHK(kmb_attn_fwd_launch(a, s));
+  return 0;
+}
+
+int ln_forward(const bf16_t* z, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int M, int D,
+               float eps, hipStream_t s) {
+  if (g_f32) HIPCHK(kmb_f32_ln_fwd_launch((const float*)z, gamma, beta, (float*)y, mean, rstd, M, D, eps, s));
+  else HIPCHK(kmb_ln_fwd_launch(z, gamma, beta, y, mean, rstd, M, D, eps, s));
+  return 0;
+}
+
+int embed_ln_forward(const int64_t* ids, const int32_t* img_src, const float* E, const float* img_emb, const float* P,
+                     int pos_base, int S, float scale, const float* gamma, const float* beta, bf16_t* z, bf16_t* y,
+                     float* mean, float* rstd, int M, int D, float eps, KmbDrop drop, hipStream_t s) {
+  if (g_f32) {
+    if (drop.thr16) return fail("fp32 validation mode runs without dropout");
+    HIPCHK(kmb_f32_embed_ln_fwd_launch(ids, img_src, E, img_emb, P, pos_base, S, scale, gamma, beta, (float*)z, (float*)y,
+                                       mean, rstd, M, D, eps, s));
+  } else {
+    HIPCHK(kmb_embed_ln_fwd_launch(ids, img_src, E, img_emb, P, pos_base, S, scale, gamma, beta, z, y, mean, rstd, M, D,
+                                   eps, drop, s));
+  }
   return 0;
 }
 
@@ -482,7 +527,7 @@ int ffn_forward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, bf16_t* 
   g.drop_thr16 = dr.thr16; g.drop_seed = dr.seed; g.drop_scale = dr.scale;
   g.residual = x; g.ld_res = d; g.out_bf16 = z; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
-  HIPCHK(kmb_ln_fwd_launch(z, h->pf(L.ln_g), h->pf(L.ln_b), out, mean, rstd, M, d, h->cfg.layer_norm_eps, s));
+  KCHK(ln_forward(z, h->pf(L.ln_g), h->pf(L.ln_b), out, mean, rstd, M, d, h->cfg.layer_norm_eps, s));
   return 0;
 }
 
@@ -519,13 +564,13 @@ int self_attn_forward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf1
   KmbGemm g = lin_fwd(x, d, h->wb(A.qkv_w), h->pf(A.qkv_b), M, 3 * d, d);
   g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = qkv; g.ld_out_bf16 = 3 * d;
   KCHK(run_gemm(g, s));
-  AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
+  AttnIO io{qkv, 3 * d, EP(qkv, d), EP(qkv, 2 * d), 3 * d, T, T, mask, causal};
   KCHK(attn_forward(h, io, B, H, o, lse, s));
   g = lin_fwd(o, d, h->wb(A.o_w), h->pf(A.o_b), M, d, d);
   g.drop_thr16 = dr.thr16; g.drop_seed = dr.seed; g.drop_scale = dr.scale;
   g.residual = x; g.ld_res = d; g.out_bf16 = z; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
-  HIPCHK(kmb_ln_fwd_launch(z, h->pf(A.ln_g), h->pf(A.ln_b), out, mean, rstd, M, d, h->cfg.layer_norm_eps, s));
+  KCHK(ln_forward(z, h->pf(A.ln_g), h->pf(A.ln_b), out, mean, rstd, M, d, h->cfg.layer_norm_eps, s));
   return 0;
 }
 
@@ -613,7 +658,12 @@ int encoder_forward(kmb_handle* h, const kmb_batch& bt, bool train, hipStream_t 
   const int d = h->d, B = bt.B, S = bt.S, Me = B * S;
   const float eps = h->cfg.layer_norm_eps;
   const float scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f;
-  if (bt.n_features > 0) {
+  if (bt.n_features > 0 && g_f32) {   // the raw fp32 features against the fp32 master weight [d, Fin]
+    KmbGemm g = lin_fwd(reinterpret_cast<const bf16_t*>(bt.image_features), h->Fin, h->wb(h->img_w), h->pf(h->img_b),
+                        bt.n_features, d, h->Fin);
+    g.out_f32 = h->img_emb; g.ld_out_f32 = d;
+    KCHK(run_gemm(g, s));
+  } else if (bt.n_features > 0) {
     HIPCHK(kmb_cast_pad_launch(bt.image_features, bt.n_features, h->Fin, h->xf, h->Fpad, s));
     KmbGemm g = lin_fwd(h->xf, h->Fpad, h->imgw_pad, h->pf(h->img_b), bt.n_features, d, h->Fpad);
     g.out_f32 = h->img_emb; g.ld_out_f32 = d;
@@ -621,9 +671,9 @@ int encoder_forward(kmb_handle* h, const kmb_batch& bt, bool train, hipStream_t 
   }
   HIPCHK(kmb_img_rowmap_launch(bt.input_ids, bt.feat_offsets, B, S, h->cfg.img_feat_id, h->cfg.cls_token_id,
                                h->img_src, h->status, s));
-  HIPCHK(kmb_embed_ln_fwd_launch(bt.input_ids, h->img_src, h->pf(h->shared), h->img_emb, h->pf(h->enc_pos),
-                                 h->cfg.extra_pos_embeddings, S, scale, h->pf(h->enc_lne_g), h->pf(h->enc_lne_b),
-                                 h->ze0, h->xe[0], h->me0, h->re0, Me, d, eps, h->drop_site(1, train), s));
+  KCHK(embed_ln_forward(bt.input_ids, h->img_src, h->pf(h->shared), h->img_emb, h->pf(h->enc_pos),
+                        h->cfg.extra_pos_embeddings, S, scale, h->pf(h->enc_lne_g), h->pf(h->enc_lne_b),
+                        h->ze0, h->xe[0], h->me0, h->re0, Me, d, eps, h->drop_site(1, train), s));
   for (int l = 0; l < h->cfg.encoder_layers; ++l) {
     const LayerP& L = h->enc[l];
     EncAct& a = h->ea[l];
@@ -769,11 +819,12 @@ int kmb_bind_arenas(kmb_handle* h, float* params, float* grads, float* exp_avg, 
 }
 
 int64_t kmb_workspace_bytes(const kmb_handle* h, int B, int S, int T, int n_features) {
+  PrecisionScope scope(h);
   return (int64_t)layout_train(const_cast<kmb_handle*>(h), nullptr, 0, B, S, T, n_features, false);
 }
 int kmb_bind_workspace(kmb_handle* h, void* ws, int64_t bytes) {
   if (((uintptr_t)ws) & 255) return fail("kmb_bind_workspace: workspace must be 256-byte aligned");
-  h->ws = (char*)ws; h->ws_bytes = (size_t)bytes; h->have_fwd = false; h->gen.active = false;
+  h->ws = (char*)ws; h->ws_bytes = (size_t)bytes; h->have_fwd = false; h->have_hdec = false; h->gen.active = false;
   return 0;
 }
 
@@ -809,10 +860,28 @@ int kmb_read_status(kmb_handle* h, int32_t* status_host, void* stream) {
 }
 
 // --------------------------------------------------------------------------------- forward
-static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, int train, int need_grad,
-                        float* loss_out, float* logits_out, kmb_bf16* enc_out, void* stream) {
+// the tied LM head on rows [0, Md) of hdec: fp32 logits [Md, Vpad] (src/model/model.py:397)
+static int head_logits(kmb_handle* h, const bf16_t* hdec, int Md, float* logits_out, hipStream_t s) {
+  const int d = h->d;
+  const int CH = Md < h->lm_chunk ? Md : h->lm_chunk;
+  for (int r0 = 0; r0 < Md; r0 += CH) {
+    const int rows = (Md - r0) < CH ? (Md - r0) : CH;
+    KmbGemm g = lin_fwd(EP(hdec, (size_t)r0 * d), d, h->wb(h->shared), h->flb, rows, h->V, d);
+    g.out_f32 = logits_out + (size_t)r0 * h->Vpad; g.ld_out_f32 = h->Vpad;
+    KCHK(run_gemm(g, s));
+  }
+  return 0;
+}
+
+static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, const kmb_forward_opts* opts,
+                        int train, int need_grad, float* loss_out, float* logits_out, kmb_bf16* enc_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   KCHK(check_bound(h));
+  PrecisionScope scope(h);
+  if (h->fp32 && (train || need_grad || extra))
+    return fail("kmb_forward: the fp32 validation mode (kmb_set_precision) is an eval-mode forward only");
+  const bf16_t* enc_in = opts ? opts->encoder_states : nullptr;
+  if (enc_in && need_grad) return fail("kmb_forward_ex: a forward from given encoder states cannot be differentiated");
   if (!batch || !batch->input_ids || !batch->decoder_input_ids || !batch->feat_offsets)
     return fail("kmb_forward: input_ids, decoder_input_ids and feat_offsets are required");
   const kmb_batch& bt = *batch;
@@ -827,21 +896,23 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   h->gen.active = false;
   const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = B * S, Md = B * T;
   h->bt = bt; h->Me = Me; h->Md = Md; h->Ntot = bt.n_features;
-  h->fwd_train = train != 0; h->have_fwd = false;
+  h->fwd_train = train != 0; h->have_fwd = false; h->have_hdec = false;
   if (train) h->step += 1;
   const bool tr = train != 0;
   const float eps = h->cfg.layer_norm_eps;
   const float scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f;
   HIPCHK(hipMemsetAsync(h->status, 0, 16, s));
 
-  KCHK(encoder_forward(h, bt, tr, s));
+  // encoder once, unless the caller already holds its output (src/model/model.py:76-83)
+  if (enc_in) HIPCHK(hipMemcpyAsync(h->xe[h->cfg.encoder_layers], enc_in, (size_t)Me * d * esz(), hipMemcpyDeviceToDevice, s));
+  else KCHK(encoder_forward(h, bt, tr, s));
   const bf16_t* enc = h->xe[h->cfg.encoder_layers];
-  if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, enc, (size_t)Me * d * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
+  if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, enc, (size_t)Me * d * esz(), hipMemcpyDeviceToDevice, s));
 
   // ---- decoder (teacher forced): HF3.0.2 BartDecoder.forward via src/model/model.py:87-97
-  HIPCHK(kmb_embed_ln_fwd_launch(bt.decoder_input_ids, nullptr, h->pf(h->shared), nullptr, h->pf(h->dec_pos),
-                                 h->cfg.extra_pos_embeddings, T, scale, h->pf(h->dec_lne_g), h->pf(h->dec_lne_b),
-                                 h->zd0, h->xd[0], h->md0, h->rd0, Md, d, eps, h->drop_site(2, tr), s));
+  KCHK(embed_ln_forward(bt.decoder_input_ids, nullptr, h->pf(h->shared), nullptr, h->pf(h->dec_pos),
+                        h->cfg.extra_pos_embeddings, T, scale, h->pf(h->dec_lne_g), h->pf(h->dec_lne_b),
+                        h->zd0, h->xd[0], h->md0, h->rd0, Md, d, eps, h->drop_site(2, tr), s));
   for (int l = 0; l < h->cfg.decoder_layers; ++l) {
     const LayerP& L = h->dec[l];
     DecAct& a = h->da[l];
@@ -851,20 +922,24 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
     KmbGemm g = lin_fwd(a.y1, d, h->wb(L.ca.qkv_w), h->pf(L.ca.qkv_b), Md, d, d);
     g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = a.cq; g.ld_out_bf16 = d;
     KCHK(run_gemm(g, s));
-    g = lin_fwd(enc, d, h->wb(L.ca.qkv_w) + (size_t)d * d, h->pf(L.ca.qkv_b) + d, Me, 2 * d, d);
+    g = lin_fwd(enc, d, EP(h->wb(L.ca.qkv_w), (size_t)d * d), h->pf(L.ca.qkv_b) + d, Me, 2 * d, d);
     g.out_bf16 = a.ckv; g.ld_out_bf16 = 2 * d;
     KCHK(run_gemm(g, s));
-    AttnIO io{a.cq, d, a.ckv, a.ckv + d, 2 * d, T, S, bt.attention_mask, 0};
+    AttnIO io{a.cq, d, a.ckv, EP(a.ckv, d), 2 * d, T, S, bt.attention_mask, 0};
     KCHK(attn_forward(h, io, B, h->Hd, a.o2, a.lse2, s));
     const KmbDrop dr = h->drop_site(101 + 3 * l, tr);
     g = lin_fwd(a.o2, d, h->wb(L.ca.o_w), h->pf(L.ca.o_b), Md, d, d);
     g.drop_thr16 = dr.thr16; g.drop_seed = dr.seed; g.drop_scale = dr.scale;
     g.residual = a.y1; g.ld_res = d; g.out_bf16 = a.z2; g.ld_out_bf16 = d;
     KCHK(run_gemm(g, s));
-    HIPCHK(kmb_ln_fwd_launch(a.z2, h->pf(L.ca.ln_g), h->pf(L.ca.ln_b), a.y2, a.m2, a.r2, Md, d, eps, s));
+    KCHK(ln_forward(a.z2, h->pf(L.ca.ln_g), h->pf(L.ca.ln_b), a.y2, a.m2, a.r2, Md, d, eps, s));
     KCHK(ffn_forward(h, L, h->Fd, a.y2, a.u, a.hh, a.z3, a.m3, a.r3, h->xd[l + 1], Md, h->drop_site(102 + 3 * l, tr), s));
   }
   const bf16_t* hdec = h->xd[h->cfg.decoder_layers];
+  h->have_hdec = true;
+  if (opts && opts->decoder_states_out)   // MultiModalBartModel.forward returns the decoder states (src/model/model.py:100-103)
+    HIPCHK(hipMemcpyAsync(opts->decoder_states_out, hdec, (size_t)Md * d * esz(), hipMemcpyDeviceToDevice, s));
+  if (opts && opts->skip_head) return 0;
 
   // ---- tied LM head + CE (src/model/model.py:397-403), in row chunks of lm_chunk (8192) rows: one launch at the
   // benchmark batch.  Smaller chunks (KMB_LM_CHUNK) keep the fp32 logits on-die but quantise the tile count worse:
@@ -876,7 +951,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
     for (int r0 = 0, c = 0; r0 < Md; r0 += CH, ++c) {
       const int rows = (Md - r0) < CH ? (Md - r0) : CH;
       float* lg = logits_out ? logits_out + (size_t)r0 * h->Vpad : h->logits_c;
-      KmbGemm g = lin_fwd(hdec + (size_t)r0 * d, d, Eb, h->flb, rows, h->V, d);
+      KmbGemm g = lin_fwd(EP(hdec, (size_t)r0 * d), d, Eb, h->flb, rows, h->V, d);
       g.out_f32 = lg; g.ld_out_f32 = h->Vpad;
       KCHK(run_gemm(g, s));
       if (!bt.labels) continue;
@@ -944,7 +1019,28 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
 
 int kmb_forward(kmb_handle* h, const kmb_batch* batch, int train, int need_grad, float* loss_out, float* logits_out,
                 kmb_bf16* enc_out, void* stream) {
-  return forward_impl(h, batch, nullptr, train, need_grad, loss_out, logits_out, enc_out, stream);
+  return forward_impl(h, batch, nullptr, nullptr, train, need_grad, loss_out, logits_out, enc_out, stream);
+}
+
+int kmb_forward_ex(kmb_handle* h, const kmb_batch* batch, const kmb_forward_opts* opts, int train, int need_grad,
+                   float* loss_out, float* logits_out, kmb_bf16* enc_out, void* stream) {
+  return forward_impl(h, batch, nullptr, opts, train, need_grad, loss_out, logits_out, enc_out, stream);
+}
+
+int kmb_set_precision(kmb_handle* h, int fp32) {
+  h->fp32 = fp32 != 0; h->have_fwd = false; h->have_hdec = false; h->gen.active = false;
+  return 0;
+}
+int kmb_act_bytes(const kmb_handle* h) { return h->fp32 ? 4 : 2; }
+
+// logits of the LAST forward's decoder states (outputs[1] of a training forward, src/model/model.py:397-405) without
+// re-running the model: one head GEMM on the states still in the workspace
+int kmb_last_logits(kmb_handle* h, float* logits_out, void* stream) {
+  KCHK(check_bound(h));
+  if (!h->have_hdec || h->Md <= 0) return fail("kmb_last_logits: no forward whose decoder states are still in the workspace");
+  if (!logits_out) return fail("kmb_last_logits: logits_out is required");
+  PrecisionScope scope(h);
+  return head_logits(h, h->xd[h->cfg.decoder_layers], h->Md, logits_out, (hipStream_t)stream);
 }
 
 int kmb_reserve_head_rows(kmb_handle* h, int n) {
@@ -959,11 +1055,18 @@ int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretra
   if (need_grad && !batch->labels) return fail("kmb_forward_pretrain: need_grad requires labels");
   if ((extra->n_mrm > 0 && !h->head[0].on) || (extra->n_attr > 0 && !h->head[1].on) || (extra->n_rel > 0 && !h->head[2].on))
     return fail("kmb_forward_pretrain: rows given for a head this model was built without (num_labels / num_attributes / num_relations)");
-  return forward_impl(h, batch, extra, train, need_grad, nullptr, logits_out, enc_out, stream);
+  return forward_impl(h, batch, extra, nullptr, train, need_grad, nullptr, logits_out, enc_out, stream);
 }
 
 // --------------------------------------------------------------------------------- backward
-int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
+static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scale_dev, void* stream);
+int kmb_backward(kmb_handle* h, float loss_scale, void* stream) { return backward_impl(h, loss_scale, nullptr, stream); }
+int kmb_backward_dev(kmb_handle* h, const float* loss_scale_dev, void* stream) {
+  if (!loss_scale_dev) return fail("kmb_backward_dev: loss_scale_dev is required");
+  return backward_impl(h, 1.f, loss_scale_dev, stream);
+}
+
+static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scale_dev, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   KCHK(check_bound(h));
   if (!h->have_fwd) return fail("kmb_backward: no forward with need_grad=1 to differentiate");
@@ -1010,12 +1113,20 @@ int kmb_backward(kmb_handle* h, float loss_scale, void* stream) {
     }
     return 0;
   };
-  if (h->head_wgrad_pending) {  // the tied matrix's head gradient is written on the side stream
-    if (loss_scale != 1.f) HIPCHK(hipStreamWaitEvent(s, h->head_wgrad_done, 0));
-  }
-  if (loss_scale != 1.f) {
-    HIPCHK(kmb_scale_bf16_launch(h->dhdec, (size_t)Md * d, loss_scale, s));
-    HIPCHK(kmb_scale_f32_launch(h->gf(h->shared), (size_t)h->V * d, loss_scale, s));
+  const bool scaled = loss_scale != 1.f || loss_scale_dev != nullptr;
+  if (scaled) {
+    HIPCHK(kmb_scale_bf16_launch(h->dhdec, (size_t)Md * d, loss_scale, loss_scale_dev, s));
+    if (h->head_wgrad_pending) {
+      // the tied matrix's head gradient is being written on the side stream: scale it there, behind the GEMM, and move
+      // the completion event behind the scaling (the main stream keeps running ahead)
+      HIPCHK(kmb_scale_f32_launch(h->gf(h->shared), (size_t)h->V * d, loss_scale, loss_scale_dev, h->side));
+      HIPCHK(hipEventRecord(h->head_wgrad_done, h->side));
+    } else {
+      HIPCHK(kmb_scale_f32_launch(h->gf(h->shared), (size_t)h->V * d, loss_scale, loss_scale_dev, s));
+    }
+    // the pre-training heads' parameter gradients were written by forward (head_run) at scale 1
+    if (h->heads_end > h->heads_begin)
+      HIPCHK(kmb_scale_f32_launch(h->gf(h->heads_begin), h->heads_end - h->heads_begin, loss_scale, loss_scale_dev, s));
   }
   const bf16_t* enc = h->xe[Le];
   const bf16_t* dy = h->dhdec;
@@ -1210,25 +1321,25 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
   Bump bp(base, cap);
   GenLayout g;
   g.status = bp.take<int32_t>(4);
-  g.xf = bp.take<bf16_t>((size_t)(Ntot > 0 ? Ntot : 1) * h->Fpad);
+  g.xf = bp.act((size_t)(Ntot > 0 ? Ntot : 1) * h->Fpad);
   g.img_emb = bp.take<float>((size_t)(Ntot > 0 ? Ntot : 1) * d);
   g.img_src = bp.take<int32_t>(Me);
-  g.xe[0] = bp.take<bf16_t>(Me * d); g.xe[1] = bp.take<bf16_t>(Me * d);
+  g.xe[0] = bp.act(Me * d); g.xe[1] = bp.act(Me * d);
   EncAct& a = g.ea;
-  a.qkv = bp.take<bf16_t>(Me * 3 * d); a.o = bp.take<bf16_t>(Me * d); a.z1 = bp.take<bf16_t>(Me * d);
-  a.y1 = bp.take<bf16_t>(Me * d); a.u = bp.take<bf16_t>(Me * Fe); a.hh = bp.take<bf16_t>(Me * Fe);
-  a.z2 = bp.take<bf16_t>(Me * d); a.lse = bp.take<float>((size_t)B * h->He * S);
+  a.qkv = bp.act(Me * 3 * d); a.o = bp.act(Me * d); a.z1 = bp.act(Me * d);
+  a.y1 = bp.act(Me * d); a.u = bp.act(Me * Fe); a.hh = bp.act(Me * Fe);
+  a.z2 = bp.act(Me * d); a.lse = bp.take<float>((size_t)B * h->He * S);
   a.m1 = bp.take<float>(Me); a.r1 = bp.take<float>(Me); a.m2 = bp.take<float>(Me); a.r2 = bp.take<float>(Me);
   g.ckv.resize(Ld);
   for (int i = 0; i < 2; ++i) { g.kc[i].resize(Ld); g.vc[i].resize(Ld); }
   for (int l = 0; l < Ld; ++l) {
-    g.ckv[l] = bp.take<bf16_t>(Me * 2 * d);
-    for (int i = 0; i < 2; ++i) { g.kc[i][l] = bp.take<bf16_t>(R * Tmax * d); g.vc[i][l] = bp.take<bf16_t>(R * Tmax * d); }
+    g.ckv[l] = bp.act(Me * 2 * d);
+    for (int i = 0; i < 2; ++i) { g.kc[i][l] = bp.act(R * Tmax * d); g.vc[i][l] = bp.act(R * Tmax * d); }
   }
   g.kv_row = bp.take<int32_t>(R);
-  g.x0 = bp.take<bf16_t>(R * d); g.x1 = bp.take<bf16_t>(R * d); g.qkv = bp.take<bf16_t>(R * 3 * d);
-  g.o = bp.take<bf16_t>(R * d); g.z = bp.take<bf16_t>(R * d); g.y = bp.take<bf16_t>(R * d); g.cq = bp.take<bf16_t>(R * d);
-  g.u = bp.take<bf16_t>(R * Fd); g.hh = bp.take<bf16_t>(R * Fd);
+  g.x0 = bp.act(R * d); g.x1 = bp.act(R * d); g.qkv = bp.act(R * 3 * d);
+  g.o = bp.act(R * d); g.z = bp.act(R * d); g.y = bp.act(R * d); g.cq = bp.act(R * d);
+  g.u = bp.act(R * Fd); g.hh = bp.act(R * Fd);
   g.mean = bp.take<float>(R); g.rstd = bp.take<float>(R);
   g.slab = bp.take<float>((size_t)GEN_MAX_SPLIT * R * d);
   if (out) *out = g;
@@ -1256,7 +1367,8 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   GenLayout g;
   const size_t need = layout_gen(h, h->ws, h->ws_bytes, B, S, num_beams, max_length, bt.n_features, &g);
   if (need > h->ws_bytes) return fail("kmb_gen_begin: workspace too small (%zu > %zu bytes)", need, h->ws_bytes);
-  h->have_fwd = false;
+  if (h->fp32) return fail("kmb_gen_begin: generation is not available in the fp32 validation mode");
+  h->have_fwd = false; h->have_hdec = false;
   // point the encoder sub-graph at the (layer-shared) generation buffers
   const int Le = h->cfg.encoder_layers, Ld = h->cfg.decoder_layers;
   h->status = g.status; h->xf = g.xf; h->img_emb = g.img_emb; h->img_src = g.img_src;

@@ -82,8 +82,10 @@ hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_
 // generation: per row log_softmax over V then top-k of (logp + add[row]); writes k (value, index) pairs
 hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out,
                                  hipStream_t stream);
+// ban_token >= 0: that token's score is -inf AFTER the normalisation (min_length, transformers 3.0.2
+// postprocess_next_token_scores)
 hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
-                                      int force_token, int k, float* out_val, int32_t* out_idx,
+                                      int force_token, int ban_token, int k, float* out_val, int32_t* out_idx,
                                       hipStream_t stream);
 
 // ---------------------------------------------------------------- optim.hip
@@ -105,9 +107,22 @@ hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst
 
 // keep-mask dump of the dropout generator (tests)
 hipError_t kmb_dropout_mask_launch(uint32_t seed, uint32_t thr16, int rows, int cols, uint8_t* keep, hipStream_t stream);
-hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, hipStream_t stream);
-hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, hipStream_t stream);
+// x *= s * (s_dev ? *s_dev : 1); no memory traffic when the product is 1
+hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, const float* s_dev, hipStream_t stream);
+hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, const float* s_dev, hipStream_t stream);
 hipError_t kmb_hash_words_launch(const void* x, size_t nbytes, unsigned long long* out, hipStream_t stream);
+
+// --------------------------------------------------------- fp32_validate.hip
+// fp32 validation forward (kmb_set_precision): the KmbGemm / KmbAttn activation pointers hold floats, B is the fp32 master
+const char* kmb_f32_gemm_check(const KmbGemm& p);
+hipError_t kmb_f32_gemm_launch(const KmbGemm& p, hipStream_t stream);
+hipError_t kmb_f32_attn_fwd_launch(const KmbAttn& p, hipStream_t stream);
+hipError_t kmb_f32_ln_fwd_launch(const float* z, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                 int M, int D, float eps, hipStream_t stream);
+hipError_t kmb_f32_embed_ln_fwd_launch(const int64_t* ids, const int32_t* img_src, const float* E, const float* img_emb,
+                                       const float* P, int pos_base, int S, float scale, const float* gamma,
+                                       const float* beta, float* z, float* y, float* mean, float* rstd, int M, int D,
+                                       float eps, hipStream_t stream);
 
 // ---------------------------------------------------------------- heads.hip
 hipError_t kmb_kl_div_launch(const float* logits, int ld, int C, const float* target, int ldt, int rows,

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
 // is one block-wide arg-max over those 256 candidates, and only the winner's wave rescans the winner's ~V/256
 // elements (64 lanes wide, from L2) for its next candidate -- the row is swept 3 times in total instead of k+2.
 __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, int ldv, int V,
-                                                              const float* __restrict__ add, int force_token, int k,
-                                                              float* __restrict__ out_val,
+                                                              const float* __restrict__ add, int force_token,
+                                                              int ban, int k, float* __restrict__ out_val,
                                                               int32_t* __restrict__ out_idx) {
   __shared__ float sh[8];
   __shared__ float shv[4];
@@ -220,8 +220,9 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
   const float lse = m + __logf(s);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
+  // `ban`: that token scores -inf AFTER the normalisation (the log-sum-exp above includes it)
   for (int i = tid; i < V; i += 256) {
-    const float x = row[i];
+    const float x = i == ban ? -INFINITY : row[i];
     if (x > bv || bi == 0x7fffffff) { bv = x; bi = i; }
   }
   for (int j = 0; j < k; ++j) {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
       float nv = -INFINITY;
       int ni = 0x7fffffff;
       for (int i = owner + 256 * lane; i < V; i += 256 * 64) {
-        const float x = row[i];
+        const float x = i == ban ? -INFINITY : row[i];
         const bool after = (x < wv) || (x == wv && i > wi);
         if (after && (x > nv || ni == 0x7fffffff || (x == nv && i < ni))) { nv = x; ni = i; }
       }
@@ -271,8 +272,8 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
 // Thread t owns the float4 chunks t, t + 1024, ...; same (value desc, index asc) order.
 template <int NV>
 __global__ __launch_bounds__(1024) void logsoftmax_topk_reg_kernel(const float* __restrict__ logits, int ldv, int V,
-                                                                   const float* __restrict__ add, int force_token, int k,
-                                                                   float* __restrict__ out_val,
+                                                                   const float* __restrict__ add, int force_token,
+                                                                   int ban, int k, float* __restrict__ out_val,
                                                                    int32_t* __restrict__ out_idx) {
   __shared__ float sh[32];
   __shared__ float shv[16];
@@ -323,6 +324,13 @@ __global__ __launch_bounds__(1024) void logsoftmax_topk_reg_kernel(const float* 
 #pragma unroll
   for (int w = 0; w < 16; ++w) s += sh[16 + w];
   const float lse = m + __logf(s);
+  if (ban >= 0) {   // banned token: -inf after the normalisation
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((tid + 1024 * j) * 4 + e == ban) x[j][e] = -INFINITY;
+  }
   // Candidates are 64-bit keys: (order-preserving bits of the value) << 32 | (0x7fffffff - index), so "larger key" IS
   // (value desc, index asc) and every comparison is one branch-free unsigned compare.  (The first version compared
   // value and index with short-circuit logic: the compiler turned each element of the rescan into branches, 5.5 us
@@ -445,12 +453,13 @@ hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_
 }
 
 hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
-                                      int force_token, int k, float* out_val, int32_t* out_idx, hipStream_t stream) {
+                                      int force_token, int ban_token, int k, float* out_val, int32_t* out_idx,
+                                      hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
   if (ldv <= 13 * 4096 && (ldv & 3) == 0 && ((uintptr_t)logits & 15) == 0)
-    hipLaunchKernelGGL((logsoftmax_topk_reg_kernel<13>), dim3(rows), dim3(1024), 0, stream, logits, ldv, V, add, force_token, k, out_val, out_idx);
+    hipLaunchKernelGGL((logsoftmax_topk_reg_kernel<13>), dim3(rows), dim3(1024), 0, stream, logits, ldv, V, add, force_token, ban_token, k, out_val, out_idx);
   else
-    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, add, force_token, k, out_val, out_idx);
+    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, add, force_token, ban_token, k, out_val, out_idx);
   return hipGetLastError();
 }
 

@@ -203,7 +203,11 @@ hipError_t kmb_dropout_mask_launch(uint32_t seed, uint32_t thr16, int rows, int 
 }
 
 namespace {
-__global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x, size_t n8, float s) {
+// s_dev (optional): a device scalar multiplied into the scale; the kernels return at once when the product is 1 (the
+// un-scaled loss.backward() of the API path passes autograd's device-side `ones` without a host round trip)
+__global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x, size_t n8, float s, const float* s_dev) {
+  if (s_dev != nullptr) s *= *s_dev;
+  if (s == 1.f) return;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     float v[8];
     unpack8(reinterpret_cast<const u32x4*>(x)[i], v);
@@ -212,15 +216,17 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16_t* __restrict__ x,
     reinterpret_cast<u32x4*>(x)[i] = pack8(v);
   }
 }
-__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ x, size_t n, float s) {
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ x, size_t n, float s, const float* s_dev) {
+  if (s_dev != nullptr) s *= *s_dev;
+  if (s == 1.f) return;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= s;
 }
 }  // namespace
 
 // n must be a multiple of 8
-hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, hipStream_t stream) {
+hipError_t kmb_scale_bf16_launch(bf16_t* x, size_t n, float s, const float* s_dev, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, stream, x, n >> 3, s);
+  hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, stream, x, n >> 3, s, s_dev);
   return hipGetLastError();
 }
 // diagnostic (KMB_BWD_TRACE): order-independent 64-bit checksum of a buffer, accumulated into *out by integer atomics
@@ -240,8 +246,8 @@ hipError_t kmb_hash_words_launch(const void* x, size_t nbytes, unsigned long lon
   return hipGetLastError();
 }
 
-hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, hipStream_t stream) {
+hipError_t kmb_scale_f32_launch(float* x, size_t n, float s, const float* s_dev, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, stream, x, n, s);
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, stream, x, n, s, s_dev);
   return hipGetLastError();
 }

@@ -37,6 +37,10 @@ class KmbPretrain(C.Structure):
                 ("losses_out", c_p)]
 
 
+class KmbForwardOpts(C.Structure):
+    _fields_ = [("encoder_states", c_p), ("decoder_states_out", c_p), ("skip_head", i32)]
+
+
 class KmbGemm(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("lda", i32), ("ldb", i32), ("a_kc", i32), ("b_kc", i32),
                 ("M", i32), ("N", i32), ("K", i32), ("bias", c_p), ("col_scale", f32), ("col_scale_n", i32),
@@ -89,16 +93,21 @@ PROTOTYPES = {
     "kmb_stream_wait_bucket": (C.c_int, [c_p, C.c_int, c_p]),
     "kmb_logits_ld": (C.c_int, [c_p]),
     "kmb_forward": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p, c_p, c_p, c_p]),
+    "kmb_forward_ex": (C.c_int, [c_p, C.POINTER(KmbBatch), C.POINTER(KmbForwardOpts), C.c_int, C.c_int, c_p, c_p, c_p, c_p]),
+    "kmb_last_logits": (C.c_int, [c_p, c_p, c_p]),
+    "kmb_set_precision": (C.c_int, [c_p, C.c_int]),
+    "kmb_act_bytes": (C.c_int, [c_p]),
     "kmb_reserve_head_rows": (C.c_int, [c_p, C.c_int]),
     "kmb_forward_pretrain": (C.c_int, [c_p, C.POINTER(KmbBatch), C.POINTER(KmbPretrain), C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_backward": (C.c_int, [c_p, f32, c_p]),
+    "kmb_backward_dev": (C.c_int, [c_p, c_p, c_p]),
     "kmb_adamw_step": (C.c_int, [c_p, C.POINTER(KmbAdamW), i64, i64, c_p]),
     "kmb_read_status": (C.c_int, [c_p, C.POINTER(i32), c_p]),
     "kmb_gen_begin": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p]),
     "kmb_gen_step": (C.c_int, [c_p, c_p, C.c_int, c_p, c_p]),
     "kmb_gen_reorder": (C.c_int, [c_p, c_p, C.c_int, c_p]),
     "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),
-    "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p]),
+    "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kmb_gemm_shared_device": (C.c_int, [C.c_int]),
     "kmb_debug_trace": (C.c_int, [C.c_int]),

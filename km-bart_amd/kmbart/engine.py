@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import KmbAdamW, KmbBatch, KmbConfig, KmbPretrain, check, ptr
+from ._lib import KmbAdamW, KmbBatch, KmbConfig, KmbForwardOpts, KmbPretrain, check, ptr
 
 _CFG_INT_FIELDS = ("vocab_size", "d_model", "encoder_layers", "decoder_layers", "encoder_attention_heads",
                    "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_position_embeddings",
@@ -87,6 +87,8 @@ class Engine:
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._keep = []  # tensors the in-flight kernels read
         self.step_count = 0
+        self.fwd_serial = 0      # bumped by every call that rewrites the workspace (LazyLogits validity)
+        self.fp32_mode = False
 
     def __del__(self):
         try:
@@ -106,6 +108,20 @@ class Engine:
         """fp32 master -> bf16 mirror (after init / load_state_dict / manual edits)."""
         with torch.cuda.device(self.device):
             check(self.lib.kmb_sync_params(self.h, _stream()))
+
+    def set_precision(self, fp32):
+        """fp32 validation mode (True) / bf16 product mode (False).  Mode True runs the eval-mode forward with float
+        activations on exact-fp32 kernels against the fp32 master weights (parity evidence, never the measured path);
+        encoder states then come back as float32 tensors."""
+        torch.cuda.synchronize(self.device)
+        check(self.lib.kmb_set_precision(self.h, 1 if fp32 else 0))
+        self.fp32_mode = bool(fp32)
+        self.workspace = None
+        self.fwd_serial += 1
+
+    @property
+    def act_dtype(self):
+        return torch.float32 if self.fp32_mode else torch.bfloat16
 
     def set_seed(self, seed):
         check(self.lib.kmb_set_seed(self.h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
@@ -142,25 +158,51 @@ class Engine:
     # ---- training step ----------------------------------------------------------------------
     def forward(self, input_ids, image_features, attention_mask=None, decoder_input_ids=None,
                 decoder_attention_mask=None, labels=None, train=False, need_grad=False, want_logits=False,
-                want_encoder=True):
-        """Returns (loss [1] or None, logits [B,T,V] fp32 or None, encoder_out [B,S,D] bf16 or None)."""
+                want_encoder=True, encoder_states=None, want_decoder_states=False, skip_head=False):
+        """Returns (loss [1] or None, logits [B,T,V] fp32 or None, encoder_out [B,S,D] or None); with
+        want_decoder_states a 4th element, the last decoder hidden states [B,T,D].  `encoder_states` [B,S,D] skips the
+        encoder (reference src/model/model.py:76-83); activations are bf16 (float32 in the fp32 validation mode)."""
         with torch.cuda.device(self.device):
-            b, keep, (B, S, T, ntot) = self._batch(input_ids, image_features, attention_mask, decoder_input_ids,
-                                                   decoder_attention_mask, labels)
+            b, keep, (B, S, T, ntot) = self._batch(input_ids, image_features if encoder_states is None else [],
+                                                   attention_mask, decoder_input_ids, decoder_attention_mask, labels)
             self._ensure_ws(self.lib.kmb_workspace_bytes(self.h, B, S, T, ntot))
+            D = int(self.config.d_model)
             logits = None
             if want_logits:
                 logits = torch.empty((B * T, self.logits_ld), dtype=torch.float32, device=self.device)
             enc = None
             if want_encoder:
-                enc = torch.empty((B, S, int(self.config.d_model)), dtype=torch.bfloat16, device=self.device)
+                enc = torch.empty((B, S, D), dtype=self.act_dtype, device=self.device)
             loss = torch.empty(1, dtype=torch.float32, device=self.device) if labels is not None else None
-            check(self.lib.kmb_forward(self.h, C.byref(b), 1 if train else 0, 1 if need_grad else 0, ptr(loss),
-                                       ptr(logits), ptr(enc), _stream()))
+            opts = KmbForwardOpts()
+            dec = None
+            if encoder_states is not None:
+                if tuple(encoder_states.shape) != (B, S, D):
+                    raise ValueError("encoder_outputs[0] must be [batch, src_len, d_model] = %s, got %s"
+                                     % ((B, S, D), tuple(encoder_states.shape)))
+                encoder_states = encoder_states.to(device=self.device, dtype=self.act_dtype).contiguous()
+                opts.encoder_states = ptr(encoder_states)
+                keep.append(encoder_states)
+            if want_decoder_states:
+                dec = torch.empty((B, T, D), dtype=self.act_dtype, device=self.device)
+                opts.decoder_states_out = ptr(dec)
+            opts.skip_head = 1 if skip_head else 0
+            self.fwd_serial += 1
+            check(self.lib.kmb_forward_ex(self.h, C.byref(b), C.byref(opts), 1 if train else 0, 1 if need_grad else 0,
+                                          ptr(loss), ptr(logits), ptr(enc), _stream()))
             self._keep = keep
             if logits is not None:
                 logits = logits.view(B, T, self.logits_ld)[:, :, : int(self.config.vocab_size)]
-            return loss, logits, enc
+            self._last_bt = (B, T)
+            return (loss, logits, enc, dec) if want_decoder_states else (loss, logits, enc)
+
+    def last_logits(self):
+        """fp32 logits [B,T,V] of the decoder states the last forward left in the workspace (one head GEMM)."""
+        B, T = self._last_bt
+        with torch.cuda.device(self.device):
+            logits = torch.empty((B * T, self.logits_ld), dtype=torch.float32, device=self.device)
+            check(self.lib.kmb_last_logits(self.h, ptr(logits), _stream()))
+        return logits.view(B, T, self.logits_ld)[:, :, : int(self.config.vocab_size)]
 
     def forward_pretrain(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask,
                          labels, mrm=None, attr=None, rel=None, factors=(1.0, 1.0, 1.0, 1.0), train=False,
@@ -197,6 +239,8 @@ class Engine:
             losses = torch.zeros(5, dtype=torch.float32, device=dev)
             ex.losses_out = ptr(losses)
             logits = torch.empty((B * T, self.logits_ld), dtype=torch.float32, device=dev) if want_logits else None
+            self.fwd_serial += 1
+            self._last_bt = (B, T)
             check(self.lib.kmb_forward_pretrain(self.h, C.byref(b), C.byref(ex), 1 if train else 0,
                                                 1 if need_grad else 0, ptr(logits), None, _stream()))
             self._keep = keep
@@ -214,13 +258,20 @@ class Engine:
                                "(reference src/model/modules.py:98-100 would raise a shape mismatch)")
 
     def backward(self, loss_scale=1.0):
+        """loss_scale: a Python float, or a 1-element fp32 device tensor (autograd's upstream gradient: no host sync)."""
         with torch.cuda.device(self.device):
-            check(self.lib.kmb_backward(self.h, C.c_float(loss_scale), _stream()))
+            if torch.is_tensor(loss_scale):
+                sc = loss_scale.detach().to(device=self.device, dtype=torch.float32).reshape(1).contiguous()
+                check(self.lib.kmb_backward_dev(self.h, ptr(sc), _stream()))
+                self._keep_scale = sc
+            else:
+                check(self.lib.kmb_backward(self.h, C.c_float(loss_scale), _stream()))
 
     def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0,
                    offset=0, count=None, bump=True):
         if bump:
             self.step_count += 1
+        self.fwd_serial += 1   # the weights move: logits of an earlier forward can no longer be reproduced
         hp = KmbAdamW(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay,
                       step=self.step_count, correct_bias=1 if correct_bias else 0, grad_scale=grad_scale)
         with torch.cuda.device(self.device):
@@ -253,6 +304,7 @@ class Engine:
             return False
         hp = KmbAdamW(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay,
                       step=self.step_count, correct_bias=1 if correct_bias else 0, grad_scale=grad_scale)
+        self.fwd_serial += 1
         with torch.cuda.device(self.device):
             main, side = torch.cuda.current_stream(), self._opt_stream
             for i, lo, cnt in pieces:
@@ -278,6 +330,7 @@ class Engine:
         with torch.cuda.device(self.device):
             b, keep, (B, S, _, ntot) = self._batch(input_ids, image_features, attention_mask, None, None, None)
             self._ensure_ws(self.lib.kmb_gen_workspace_bytes(self.h, B, S, num_beams, max_length, ntot))
+            self.fwd_serial += 1
             check(self.lib.kmb_gen_begin(self.h, C.byref(b), num_beams, max_length, _stream()))
             self._keep = keep
             self._gen_rows = B * num_beams
@@ -297,22 +350,23 @@ class Engine:
             check(self.lib.kmb_gen_reorder(self.h, ptr(beam_idx), int(step), _stream()))
             self._keep_idx = beam_idx
 
-    def beam_candidates(self, logits, num_beams, k, add=None, force_token=-1):
+    def beam_candidates(self, logits, num_beams, k, add=None, force_token=-1, ban_token=-1):
         """log_softmax(+beam score) top-k per beam row, merged per batch item: int32 [B, k, 2] on the device,
         [..., 0] = fp32 score bits, [..., 1] = beam * V + token (one small D2H copy per decode step)."""
         R = logits.shape[0]
-        val, idx = self.logsoftmax_topk(logits, k, add=add, force_token=force_token)
+        val, idx = self.logsoftmax_topk(logits, k, add=add, force_token=force_token, ban_token=ban_token)
         out = torch.empty((R // num_beams, k, 2), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             check(self.lib.kmb_beam_merge(ptr(val), ptr(idx), R // num_beams, int(num_beams), int(k),
                                           int(self.config.vocab_size), ptr(out), _stream()))
         return out
 
-    def logsoftmax_topk(self, logits, k, add=None, force_token=-1):
+    def logsoftmax_topk(self, logits, k, add=None, force_token=-1, ban_token=-1):
         R = logits.shape[0]
         val = torch.empty((R, k), dtype=torch.float32, device=self.device)
         idx = torch.empty((R, k), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             check(self.lib.kmb_logsoftmax_topk(ptr(logits), logits.stride(0), int(self.config.vocab_size), R,
-                                               ptr(add), int(force_token), int(k), ptr(val), ptr(idx), _stream()))
+                                               ptr(add), int(force_token), int(ban_token), int(k), ptr(val), ptr(idx),
+                                               _stream()))
         return val, idx

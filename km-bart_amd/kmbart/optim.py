@@ -16,7 +16,15 @@ class AdamW(torch.optim.Optimizer):
                                       correct_bias=correct_bias))
         self.grad_scale = 1.0  # data-parallel wrapper may fold 1/world here
         import os
-        self.overlap = os.environ.get("KMB_ADAMW_OVERLAP", "1") != "0"
+        # Overlapped stepping (Engine.adamw_step_overlapped) issues each bucket's update on a second stream behind that
+        # bucket's completion event of the backward pass still running on the GPU.  It is only correct when NOTHING
+        # touches the gradients between `loss.backward()` and `step()` (clip_grad_norm_, GradScaler.unscale_, manual
+        # scaling all enqueue on the main stream and would race with the side-stream update), so it is opt-in: the
+        # loops that guarantee the adjacency (src.training.fine_tune / pretrain without a scaler, bench.py) set
+        # `optimizer.overlap = True`; KMB_ADAMW_OVERLAP=1 forces it on, =0 forbids it.
+        env = os.environ.get("KMB_ADAMW_OVERLAP")
+        self.overlap = env == "1"
+        self._overlap_locked = env is not None
 
     def _engine_ranges(self, group):
         """[(engine, offset, count)] with adjacent parameters coalesced."""
@@ -37,19 +45,32 @@ class AdamW(torch.optim.Optimizer):
                 out.append((eng, off, cnt))
         return out
 
+    def allow_overlap(self, on=True):
+        """Called by a training loop that runs `loss.backward()` and `step()` back to back (see __init__)."""
+        if not self._overlap_locked:
+            self.overlap = bool(on)
+
+    def _engines(self):
+        engines = {}
+        for g in self.param_groups:
+            for e, _, _ in self._engine_ranges(g):
+                engines[id(e)] = e
+        return list(engines.values())
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            ranges = self._engine_ranges(group)
-            engines = {id(e): e for e, _, _ in ranges}
-            for e in engines.values():
-                e.step_count += 1
+        all_ranges = [self._engine_ranges(group) for group in self.param_groups]
+        # ONE bias-correction step per optimizer.step(), whatever the number of parameter groups
+        for e in self._engines():
+            e.step_count += 1
+        overlap = self.overlap and self.grad_scale == 1.0
+        for group, ranges in zip(self.param_groups, all_ranges):
             for eng, off, cnt in ranges:
                 args = (group["lr"], group["betas"], group["eps"], group["weight_decay"], group["correct_bias"],
                         self.grad_scale)
                 # per gradient bucket, beside the backward pass still running on the GPU (Engine.adamw_step_overlapped)
-                if not (self.overlap and eng.adamw_step_overlapped(*args, offset=off, count=cnt)):
+                if not (overlap and eng.adamw_step_overlapped(*args, offset=off, count=cnt)):
                     eng.adamw_step(*args, offset=off, count=cnt, bump=False)
         return loss
 
@@ -57,11 +78,7 @@ class AdamW(torch.optim.Optimizer):
         pass  # gradients are views into the arena and are overwritten by the next backward
 
     def state_dict(self):
-        engines = {}
-        for g in self.param_groups:
-            for e, _, _ in self._engine_ranges(g):
-                engines[id(e)] = e
-        eng = list(engines.values())
+        eng = self._engines()
         return {
             "kmbart_adamw": True,
             "step": [e.step_count for e in eng],
@@ -71,13 +88,44 @@ class AdamW(torch.optim.Optimizer):
         }
 
     def load_state_dict(self, state):
-        engines = {}
-        for g in self.param_groups:
-            for e, _, _ in self._engine_ranges(g):
-                engines[id(e)] = e
-        for i, e in enumerate(engines.values()):
-            e.step_count = int(state["step"][i])
-            e.exp_avg.copy_(state["exp_avg"][i])
-            e.exp_avg_sq.copy_(state["exp_avg_sq"][i])
-        for g, s in zip(self.param_groups, state["param_groups"]):
-            g.update(s)
+        """Accepts this class's own format and the torch / transformers.AdamW format the reference saves in
+        `training_data.pt` (reference src/utils.py:20-39: {'state': {index: {'step', 'exp_avg', 'exp_avg_sq'}},
+        'param_groups': [{..., 'params': [indices]}]}): per-parameter moments are copied into the arena slices."""
+        if state.get("kmbart_adamw"):
+            for i, e in enumerate(self._engines()):
+                e.step_count = int(state["step"][i])
+                e.exp_avg.copy_(state["exp_avg"][i])
+                e.exp_avg_sq.copy_(state["exp_avg_sq"][i])
+            for g, s in zip(self.param_groups, state["param_groups"]):
+                g.update(s)
+            return
+        if "state" not in state or "param_groups" not in state:
+            raise ValueError("optimizer state is neither a kmbart AdamW state nor a torch-format {state, param_groups} dict")
+        if len(state["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded optimizer state has %d parameter groups, this optimizer has %d"
+                             % (len(state["param_groups"]), len(self.param_groups)))
+        steps = []
+        for g, sg in zip(self.param_groups, state["param_groups"]):
+            if len(sg["params"]) != len(g["params"]):
+                raise ValueError("loaded optimizer state has a parameter group of a different size")
+            for p, idx in zip(g["params"], sg["params"]):
+                st = state["state"].get(idx)
+                if st is None:
+                    st = state["state"].get(str(idx))
+                if not st:
+                    continue
+                eng = p._kmb_engine
+                off, cnt = p._kmb_range
+                if st["exp_avg"].numel() != cnt:
+                    raise ValueError("optimizer state of parameter %s has %d elements, expected %d"
+                                     % (idx, st["exp_avg"].numel(), cnt))
+                eng.exp_avg[off: off + cnt].copy_(st["exp_avg"].reshape(-1))
+                eng.exp_avg_sq[off: off + cnt].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.append(int(st["step"]))
+            g.update({k: v for k, v in sg.items() if k != "params"})
+        if steps:
+            if min(steps) != max(steps):
+                raise ValueError("per-parameter step counts differ (%d..%d): one fused step count is kept per engine"
+                                 % (min(steps), max(steps)))
+            for e in self._engines():
+                e.step_count = steps[0]

@@ -90,20 +90,27 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.model._backward(float(grad_out))
+        # the upstream gradient (ones, or the GradScaler's scale) stays on the device: no host synchronisation
+        ctx.model._backward(grad_out if grad_out.is_cuda else float(grad_out))
         return None, None, None
 
 
 class LazyLogits:
-    """outputs[1] of a training forward: the fp32 logits are produced on first use (one extra head GEMM on
-    the saved decoder states) instead of 1.6 GB per step that the training loop never reads."""
+    """outputs[1] of a training forward: the fp32 logits are produced on first use -- ONE head GEMM on the decoder
+    states that forward left in the engine's workspace (the actual training logits, dropout included, as the reference
+    returns them) -- instead of 1.6 GB written every step that the training loop never reads.  They can only be
+    produced while those states and the weights that made them are still there: after `optimizer.step()`, another
+    forward or a `generate()` the access raises; pass `return_logits=True` to forward to get them eagerly."""
 
-    def __init__(self, fn):
-        self._fn, self._t = fn, None
+    def __init__(self, engine):
+        self._eng, self._serial, self._t = engine, engine.fwd_serial, None
 
     def tensor(self):
         if self._t is None:
-            self._t = self._fn()
+            if self._eng.fwd_serial != self._serial:
+                raise RuntimeError("the logits of this forward are gone: the model has run another forward / generate or "
+                                   "an optimizer step since (call forward(..., return_logits=True) to keep them)")
+            self._t = self._eng.last_logits()
         return self._t
 
     def __getattr__(self, name):
@@ -276,10 +283,14 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         """Reference src/model/model.py:325-405.  Returns (loss, logits, encoder_last_hidden) with labels,
         (logits, encoder_last_hidden) without.  The cached-decode branch is served by generate()."""
         eng = self._need_engine()
-        if encoder_outputs is not None or decoder_cached_states is not None:
-            raise NotImplementedError("encoder_outputs / decoder_cached_states are internal to generate() here")
+        if decoder_cached_states is not None or use_cache:
+            raise NotImplementedError("the KV-cached decode step runs inside generate() (kmb_gen_step); forward() is the "
+                                      "teacher-forced pass")
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
+        enc_states = None
+        if encoder_outputs is not None:   # src/model/model.py:76-83: a tuple whose first element is the encoder output
+            enc_states = encoder_outputs[0] if isinstance(encoder_outputs, (tuple, list)) else encoder_outputs
         if decoder_input_ids is None:
             # transformers shift_tokens_right(input_ids, pad) (HF3.0.2 _prepare_bart_decoder_inputs)
             pad = self.config.pad_token_id
@@ -290,11 +301,11 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             decoder_input_ids = prev
         if decoder_attention_mask is None and bool((decoder_input_ids == self.config.pad_token_id).any()):
             decoder_attention_mask = decoder_input_ids.ne(self.config.pad_token_id).long()
-        need_grad = labels is not None and torch.is_grad_enabled()
+        need_grad = labels is not None and torch.is_grad_enabled() and enc_states is None
         want_logits = (labels is None) if return_logits is None else bool(return_logits)
         loss, logits, enc = eng.forward(input_ids, image_features, attention_mask, decoder_input_ids,
                                         decoder_attention_mask, labels, train=self.training, need_grad=need_grad,
-                                        want_logits=want_logits)
+                                        want_logits=want_logits, encoder_states=enc_states)
         if labels is None:
             return (logits, enc)
         if need_grad:
@@ -302,20 +313,8 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         else:
             loss = loss.view(())
         if logits is None:
-            args = (input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask)
-            logits = LazyLogits(lambda: self._logits_only(*args))
+            logits = LazyLogits(eng)
         return (loss, logits, enc)
-
-    def _logits_only(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask):
-        was = self.training
-        self.training = False
-        try:
-            _, logits, _ = self._engine.forward(input_ids, image_features, attention_mask, decoder_input_ids,
-                                                decoder_attention_mask, None, train=False, need_grad=False,
-                                                want_logits=True, want_encoder=False)
-        finally:
-            self.training = was
-        return logits
 
     def _backward(self, loss_scale=1.0):
         self._engine.backward(loss_scale)
@@ -384,8 +383,6 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 assert num_return_sequences == 1, "Greedy decoding will always produce the same output"
             else:
                 assert num_beams >= num_return_sequences
-        elif num_beams > 1:
-            raise NotImplementedError("beam-search multinomial sampling is not implemented")
         B = input_ids.shape[0]
         dev = eng.device
         if attention_mask is None:
@@ -432,26 +429,45 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         # Host bookkeeping on plain Python lists: indexing small CPU tensors element by element (as the reference does)
         # costs ~10 us per access and made a beam step 6x longer than its GPU work.
         hyps = [BeamHypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
-        beam_scores = [0.0 if (i % num_beams) == 0 else -1e9 for i in range(R)]
+        # greedy beam search starts from beam 0 only; beam sampling lets every beam draw (HF 3.0.2 _generate_beam_search)
+        beam_scores = [0.0 if ((i % num_beams) == 0 or do_sample) else -1e9 for i in range(R)]
+        sampler = getattr(self, "_sampler", None) or (lambda probs, n: torch.multinomial(probs, num_samples=n))
         seqs = [[int(decoder_start_token_id)] for _ in range(R)]   # decoder inputs of every beam row
         done = [False] * B
         k = 2 * num_beams
         last_tokens = torch.full((R,), decoder_start_token_id, dtype=torch.long, device=dev)
         while cur_len < max_length:
             logits = eng.gen_step(last_tokens, cur_len - 1)
-            force = -1
-            if cur_len == 1:
-                force = cfg.bos_token_id          # adjust_logits_during_generation, mixins.py:400-405
-            if cur_len == max_length - 1 and eos_token_id is not None:
-                force = eos_token_id
-            if eos_token_id is not None and cur_len < min_length:
-                logits[:, eos_token_id] = -float("inf")
+            # min_length: transformers 3.0.2 postprocess_next_token_scores sets the EOS score to -inf AFTER log_softmax
+            ban = eos_token_id if (eos_token_id is not None and cur_len < min_length) else -1
             add = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
-            # per beam row: log_softmax + beam score, top 2*num_beams; per batch item: the best 2*num_beams of the union
-            # (== top 2*num_beams over num_beams * V: each row contributed its own best 2*num_beams); one D2H copy
-            cand = eng.beam_candidates(logits, num_beams, k, add=add, force_token=force).cpu()
-            next_scores = cand[:, :, 0].contiguous().view(torch.float32).tolist()
-            next_tokens = cand[:, :, 1].tolist()
+            if do_sample:
+                # beam-search multinomial sampling (HF 3.0.2 _generate_beam_search, do_sample branch, reached from
+                # mixins.py:336-361 with generate_text's --do_sample/--top_p/--top_k and --num_beams): no forced BOS/EOS;
+                # 2*num_beams draws per batch item from softmax over the beams' filtered (log-prob + beam score) / T
+                sc = torch.log_softmax(logits[:, :V].float(), dim=-1)
+                if ban >= 0:
+                    sc[:, ban] = -float("inf")
+                sc = sc + add[:, None]
+                if temperature != 1.0:
+                    sc = sc / temperature
+                sc = _top_k_top_p_filtering(sc, top_k=top_k, top_p=top_p, min_tokens_to_keep=2).view(B, num_beams * V)
+                drawn = sampler(torch.softmax(sc, dim=-1), k)
+                ns = torch.gather(sc, -1, drawn)
+                ns, order = torch.sort(ns, descending=True, dim=1)
+                next_scores = ns.cpu().tolist()
+                next_tokens = torch.gather(drawn, -1, order).cpu().tolist()
+            else:
+                force = -1
+                if cur_len == 1:
+                    force = cfg.bos_token_id          # adjust_logits_during_generation, mixins.py:400-405
+                if cur_len == max_length - 1 and eos_token_id is not None:
+                    force = eos_token_id
+                # per beam row: log_softmax + beam score, top 2*num_beams; per batch item: the best 2*num_beams of the
+                # union (== top 2*num_beams over num_beams * V: each row contributed its own best 2*num_beams); one D2H copy
+                cand = eng.beam_candidates(logits, num_beams, k, add=add, force_token=force, ban_token=ban).cpu()
+                next_scores = cand[:, :, 0].contiguous().view(torch.float32).tolist()
+                next_tokens = cand[:, :, 1].tolist()
             new_scores, new_tokens, new_idx = [], [], []
             for b in range(B):
                 if done[b]:
@@ -492,9 +508,10 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 eff = b * num_beams + beam_id
                 hyps[b].add(list(seqs[eff]), beam_scores[eff])
         best, best_scores, lens = [], [], []
+        nret_each = 1 if do_sample else num_return_sequences   # sampling replicated the batch instead (mixins.py:259-262)
         for h in hyps:
             sh = sorted(h.beams, key=lambda x: x[0])
-            for _ in range(num_return_sequences):
+            for _ in range(nret_each):
                 sc, hyp = sh.pop()
                 best.append(hyp)
                 best_scores.append(sc)
@@ -622,8 +639,7 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
         if rel is not None and rel[0].numel() > 0:
             out["relation_loss"] = losses[4]
         if logits is None:
-            args = (input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask)
-            logits = LazyLogits(lambda: self._logits_only(*args))
+            logits = LazyLogits(eng)
         return (out, logits)
 
 
@@ -646,4 +662,42 @@ def _top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("inf"
     return logits
 
 
-MultiModalBartModel = MultiModalBartForConditionalGeneration  # the bare model shares the engine
+class MultiModalBartModel(MultiModalBartForConditionalGeneration):
+    """The bare encoder-decoder (reference src/model/model.py:27-103): forward returns the decoder's last hidden states
+    followed by the encoder's, `decoder_outputs + encoder_outputs` with the empty entries filtered out (:100-103) --
+    no LM head, no loss.  State-dict keys carry no `model.` prefix (this IS the reference's `.model` attribute); a
+    conditional-generation checkpoint loads as well.  It runs on the same engine, whose arena simply keeps the tied
+    matrix for the two embedding lookups."""
+
+    def forward(self, input_ids, image_features, attention_mask=None, decoder_input_ids=None, encoder_outputs=None,
+                decoder_attention_mask=None, decoder_cached_states=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, **unused):
+        eng = self._need_engine()
+        if decoder_cached_states is not None or (use_cache and not self.training):
+            raise NotImplementedError("the KV-cached decode step runs inside generate() (kmb_gen_step)")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
+        assert decoder_input_ids is not None   # model.py:74
+        enc_states = None
+        if encoder_outputs is not None:
+            assert isinstance(encoder_outputs, tuple)   # model.py:84
+            enc_states = encoder_outputs[0]
+        if decoder_attention_mask is None and bool((decoder_input_ids == self.config.pad_token_id).any()):
+            decoder_attention_mask = decoder_input_ids.ne(self.config.pad_token_id).long()
+        _, _, enc, dec = eng.forward(input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask,
+                                     None, train=self.training, need_grad=False, want_logits=False, want_encoder=True,
+                                     encoder_states=enc_states, want_decoder_states=True, skip_head=True)
+        return (dec, enc)
+
+    def generate(self, *args, **kwargs):
+        raise AttributeError("MultiModalBartModel has no LM head; use MultiModalBartForConditionalGeneration.generate")
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        sd.pop("final_logits_bias", None)
+        return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
+
+    def load_state_dict(self, state_dict, strict=True):
+        full = {(k if (k.startswith("model.") or k == "final_logits_bias") else "model." + k): v
+                for k, v in state_dict.items()}
+        return super().load_state_dict(full, strict=strict)

@@ -1,6 +1,12 @@
 """Training loop with the reference's `fine_tune` contract (reference src/training.py:96-171):
-forward -> loss.item() -> zero_grad -> (scaled) backward -> optimizer step, per-step log line
-`Epoch [e/E], Step [i/N], Loss: x.xxxx, ETA: ...`, optional TensorBoard scalars and a callback."""
+forward -> zero_grad -> (scaled) backward -> optimizer step, per-step log line
+`Epoch [e/E], Step [i/N], Loss: x.xxxx, ETA: ...`, optional TensorBoard scalars and a callback.
+
+One deliberate difference in timing, none in content: the reference reads `loss.item()` right after forward
+(training.py:134), which stalls the host until the GPU has drained and leaves the GPU idle while the host enqueues
+the next ~600 launches.  Here step i's loss is read AFTER step i+1 has been enqueued (the last one after the loop), so
+log lines / TensorBoard points / the returned epoch mean carry the same values, one step later.  A `callback` gets
+called in step order as in the reference; it forces the pending loss to be read first."""
 from datetime import datetime
 
 import torch
@@ -8,6 +14,13 @@ import torch
 
 def _on(batch, key, device):
     return batch[key].to(device) if key in batch and batch[key] is not None else None
+
+
+def _allow_overlap(optimizer, ok):
+    """These loops run `loss.backward()` and `optimizer.step()` back to back with nothing touching the gradients in
+    between: kmbart.optim.AdamW may then step each gradient bucket beside the rest of backward (see its __init__)."""
+    if hasattr(optimizer, "allow_overlap"):
+        optimizer.allow_overlap(ok)
 
 
 def _features(feats, device):
@@ -19,9 +32,25 @@ def fine_tune(epoch, model, train_loader, optimizer, device, args, logger=None, 
               tb_writer=None, tb_interval=1, scaler=None):
     n_steps = len(train_loader)
     model.train()
-    loss_sum = 0.0
     t0 = datetime.now()
     use_amp = bool(getattr(args, "amp", False))
+    _allow_overlap(optimizer, not (use_amp and scaler is not None))
+    pending = None
+    state = {"sum": 0.0}
+
+    def report(item):
+        if item is None:
+            return
+        j, dev_loss, _ = item
+        loss_value = dev_loss.item()
+        state["sum"] += loss_value
+        if logger is not None and j % log_interval == 0:
+            eta = (n_steps - (j + 1)) / (j + 1) * (datetime.now() - t0)
+            logger.info("Epoch [{}/{}], Step [{}/{}], Loss: {:.4f}, ETA: {}".format(
+                epoch + 1, args.epochs, j + 1, n_steps, loss_value, str(eta)))
+        if tb_writer is not None and j % tb_interval == 0:
+            tb_writer.add_scalars("loss/step", {"loss": loss_value}, epoch * n_steps + j + 1)
+
     for i, batch in enumerate(train_loader):
         # the engine computes in bf16 with fp32 accumulation regardless of `amp`; autocast is kept so
         # that torch ops a caller adds around the model behave as in the reference
@@ -37,8 +66,6 @@ def fine_tune(epoch, model, train_loader, optimizer, device, args, logger=None, 
                 answer_attention_mask=_on(batch, "answer_attention_mask", device),
             )
             loss = outputs[0]
-        loss_value = loss.item()
-        loss_sum += loss_value
         optimizer.zero_grad()
         if use_amp and scaler is not None:
             scaler.scale(loss).backward()
@@ -47,15 +74,15 @@ def fine_tune(epoch, model, train_loader, optimizer, device, args, logger=None, 
         else:
             loss.backward()
             optimizer.step()
-        if logger is not None and i % log_interval == 0:
-            eta = (n_steps - (i + 1)) / (i + 1) * (datetime.now() - t0)
-            logger.info("Epoch [{}/{}], Step [{}/{}], Loss: {:.4f}, ETA: {}".format(
-                epoch + 1, args.epochs, i + 1, n_steps, loss_value, str(eta)))
-        if tb_writer is not None and i % tb_interval == 0:
-            tb_writer.add_scalars("loss/step", {"loss": loss_value}, epoch * n_steps + i + 1)
+        report(pending)                       # step i-1, while step i runs on the GPU
+        pending = (i, loss.detach(), None)
         if callback is not None:
+            report(pending)
+            pending = None
             callback(step=i, epoch=epoch, model=model, train_loader=train_loader, optimizer=optimizer, args=args,
                      logger=logger)
+    report(pending)
+    loss_sum = state["sum"]
     if tb_writer is not None:
         tb_writer.add_scalars("loss/epoch", {"train": loss_sum / max(n_steps, 1)}, epoch + 1)
     return loss_sum / max(n_steps, 1)
@@ -67,9 +94,28 @@ def pretrain(epoch, model, train_loader, optimizer, device, args, logger=None, c
     returns a dict of losses as outputs[0]; `loss` drives backward, the others are logged."""
     n_steps = len(train_loader)
     model.train()
-    loss_sum = 0.0
     t0 = datetime.now()
     use_amp = bool(getattr(args, "amp", False))
+    _allow_overlap(optimizer, not (use_amp and scaler is not None))
+    pending = None
+    state = {"sum": 0.0}
+
+    def report(item):
+        if item is None:
+            return
+        j, dev_loss, parts = item
+        loss_value = dev_loss.item()
+        state["sum"] += loss_value
+        if logger is not None and j % log_interval == 0:
+            eta = (n_steps - (j + 1)) / (j + 1) * (datetime.now() - t0)
+            logger.info("Epoch [{}/{}], Step [{}/{}], Loss: {:.4f}, ETA: {}".format(
+                epoch + 1, args.epochs, j + 1, n_steps, loss_value, str(eta)))
+        if tb_writer is not None and j % tb_interval == 0:
+            step = epoch * n_steps + j + 1
+            tb_writer.add_scalars("loss/step", {"total loss": loss_value}, step)
+            for name, value in parts.items():
+                tb_writer.add_scalars("loss/step", {name.replace("_", " "): value.item()}, step)
+
     for i, batch in enumerate(train_loader):
         def opt(key):
             return batch[key].to(device) if key in batch and batch[key] is not None else None
@@ -92,8 +138,6 @@ def pretrain(epoch, model, train_loader, optimizer, device, args, logger=None, c
         )
         losses = outputs[0]
         loss = losses["loss"]
-        loss_value = loss.item()
-        loss_sum += loss_value
         optimizer.zero_grad()
         if use_amp and scaler is not None:
             scaler.scale(loss).backward()
@@ -102,19 +146,15 @@ def pretrain(epoch, model, train_loader, optimizer, device, args, logger=None, c
         else:
             loss.backward()
             optimizer.step()
-        if logger is not None and i % log_interval == 0:
-            eta = (n_steps - (i + 1)) / (i + 1) * (datetime.now() - t0)
-            logger.info("Epoch [{}/{}], Step [{}/{}], Loss: {:.4f}, ETA: {}".format(
-                epoch + 1, args.epochs, i + 1, n_steps, loss_value, str(eta)))
-        if tb_writer is not None and i % tb_interval == 0:
-            step = epoch * n_steps + i + 1
-            tb_writer.add_scalars("loss/step", {"total loss": loss_value}, step)
-            for name, value in losses.items():
-                if name != "loss":
-                    tb_writer.add_scalars("loss/step", {name.replace("_", " "): value.item()}, step)
+        report(pending)
+        pending = (i, loss.detach(), {k: v.detach() for k, v in losses.items() if k != "loss"})
         if callback is not None:
+            report(pending)
+            pending = None
             callback(step=i, epoch=epoch, model=model, train_loader=train_loader, optimizer=optimizer, args=args,
                      logger=logger)
+    report(pending)
+    loss_sum = state["sum"]
     if tb_writer is not None:
         tb_writer.add_scalars("loss/epoch", {"train": loss_sum / max(n_steps, 1)}, epoch + 1)
     return loss_sum / max(n_steps, 1)

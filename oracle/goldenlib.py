@@ -74,3 +74,13 @@ def golden_features(regions, seed=11, feat_dim=2048):
         wh = u[:, 2:] * 484.0 + 16.0
         out.append(torch.cat([f, xy, xy + wh], dim=1).contiguous())
     return out
+
+
+def trained_state_dict():
+    """The tiny model trained on the reverse-copy task (oracle/make_golden.py step 3), stored as fp16: generation
+    fixtures that are not degenerate.  fp16 -> fp32 is exact, so the oracle and the engine load identical weights."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                        "tiny_trained_fp16.npz")
+    z = np.load(path)
+    return {k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}

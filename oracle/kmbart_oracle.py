@@ -489,12 +489,33 @@ def _reorder_cache(cache, beam_idx):
     return cache
 
 
+def top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=NEG_INF, min_tokens_to_keep=1):
+    """HF3.0.2 `top_k_top_p_filtering` (generation_utils): keep the top_k largest, then the smallest prefix of the
+    sorted distribution whose cumulative probability exceeds top_p (at least min_tokens_to_keep)."""
+    if top_k > 0:
+        top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
+        logits = logits.masked_fill(logits < torch.topk(logits, top_k)[0][..., -1, None], filter_value)
+    if top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        cum = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
+        rm = cum > top_p
+        if min_tokens_to_keep > 1:
+            rm[..., :min_tokens_to_keep] = False
+        rm[..., 1:] = rm[..., :-1].clone()
+        rm[..., 0] = False
+        logits = logits.masked_fill(rm.scatter(1, sorted_indices, rm), filter_value)
+    return logits
+
+
 @torch.no_grad()
 def generate(sd, cfg, input_ids, image_features, attention_mask=None, max_length=None, min_length=None,
              num_beams=None, num_return_sequences=None, early_stopping=None, length_penalty=None,
-             do_sample=False, top_k=0, top_p=1.0, return_scores=False, **unused):
-    """Greedy (num_beams==1) and beam search, do_sample=False only.  mixins.py:150-384."""
-    assert not do_sample, "oracle restates the deterministic paths only"
+             do_sample=False, top_k=0, top_p=1.0, temperature=1.0, return_scores=False, sampler=None, **unused):
+    """Greedy / sampling without beams (num_beams==1) and beam search with or without multinomial sampling.
+    mixins.py:150-384 -> HF3.0.2 _generate_no_beam_search / _generate_beam_search.  `sampler(probs, n)` replaces
+    torch.multinomial (tests feed both implementations the same draws)."""
+    if sampler is None:
+        sampler = lambda probs, n: torch.multinomial(probs, num_samples=n)  # noqa: E731
     max_length = cfg.max_length if max_length is None else max_length
     min_length = cfg.min_length if min_length is None else min_length
     num_beams = cfg.num_beams if num_beams is None else num_beams
@@ -505,7 +526,14 @@ def generate(sd, cfg, input_ids, image_features, attention_mask=None, max_length
     B = input_ids.shape[0]
     if attention_mask is None:
         attention_mask = input_ids.ne(pad).long() if bool((input_ids == pad).any()) else torch.ones_like(input_ids)
-    if num_beams == 1:
+    if do_sample:   # mixins.py:259-262: sampling replicates the batch, one sequence is returned per replica
+        if nret > 1:
+            rep_idx = torch.arange(B).repeat_interleave(nret)
+            input_ids, attention_mask = input_ids[rep_idx], attention_mask[rep_idx]
+            image_features = [image_features[i] for i in rep_idx.tolist()]
+            B = B * nret
+        nret = 1
+    elif num_beams == 1:
         assert nret == 1
     else:
         assert num_beams >= nret
@@ -525,7 +553,12 @@ def generate(sd, cfg, input_ids, image_features, attention_mask=None, max_length
             logits, cache = _decode_logits(sd, cfg, ids, enc_out, attention_mask, cache)
             if eos is not None and cur_len < min_length:
                 logits[:, eos] = NEG_INF
-            nxt = torch.argmax(logits, dim=-1)
+            if do_sample:
+                lg = logits / temperature if temperature != 1.0 else logits
+                lg = top_k_top_p_filtering(lg, top_k=top_k, top_p=top_p)
+                nxt = sampler(F.softmax(lg, dim=-1), 1).squeeze(1)
+            else:
+                nxt = torch.argmax(logits, dim=-1)
             tok = nxt * unfinished + pad * (1 - unfinished)
             ids = torch.cat([ids, tok.unsqueeze(-1)], dim=-1)
             cur_len += 1
@@ -538,26 +571,39 @@ def generate(sd, cfg, input_ids, image_features, attention_mask=None, max_length
     # HF3.0.2 _generate_beam_search, do_sample=False
     hyps = [BeamHypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
     beam_scores = torch.zeros((B, num_beams), dtype=torch.float)
-    beam_scores[:, 1:] = -1e9
+    if not do_sample:   # greedy beam search starts from beam 0 only
+        beam_scores[:, 1:] = -1e9
     beam_scores = beam_scores.view(-1)
     done = [False] * B
     next_scores = next_tokens = None
     while cur_len < max_length:
         logits, cache = _decode_logits(sd, cfg, ids, enc_out, attention_mask, cache)
-        # adjust_logits_during_generation (mixins.py:400-405): force BOS at len 1, EOS at max_length-1
-        if cur_len == 1:
+        # adjust_logits_during_generation (mixins.py:400-405): force BOS at len 1, EOS at max_length-1 -- only when
+        # not sampling (HF3.0.2: `if self.config.is_encoder_decoder and do_sample is False`)
+        if cur_len == 1 and not do_sample:
             keep = logits[:, cfg.bos_token_id].clone()
             logits.fill_(NEG_INF)
             logits[:, cfg.bos_token_id] = keep
-        if cur_len == max_length - 1 and eos is not None:
+        if cur_len == max_length - 1 and eos is not None and not do_sample:
             keep = logits[:, eos].clone()
             logits.fill_(NEG_INF)
             logits[:, eos] = keep
         scores = F.log_softmax(logits, dim=-1)
-        if eos is not None and cur_len < min_length:
+        if eos is not None and cur_len < min_length:   # postprocess_next_token_scores: on the log-probabilities
             scores[:, eos] = NEG_INF
-        next_scores = (scores + beam_scores[:, None]).view(B, num_beams * V)
-        next_scores, next_tokens = torch.topk(next_scores, 2 * num_beams, dim=1, largest=True, sorted=True)
+        if do_sample:
+            _scores = scores + beam_scores[:, None]
+            if temperature != 1.0:
+                _scores = _scores / temperature
+            _scores = top_k_top_p_filtering(_scores, top_k=top_k, top_p=top_p, min_tokens_to_keep=2)
+            _scores = _scores.contiguous().view(B, num_beams * V)
+            next_tokens = sampler(F.softmax(_scores, dim=-1), 2 * num_beams)
+            next_scores = torch.gather(_scores, -1, next_tokens)
+            next_scores, order = torch.sort(next_scores, descending=True, dim=1)
+            next_tokens = torch.gather(next_tokens, -1, order)
+        else:
+            next_scores = (scores + beam_scores[:, None]).view(B, num_beams * V)
+            next_scores, next_tokens = torch.topk(next_scores, 2 * num_beams, dim=1, largest=True, sorted=True)
         next_batch_beam = []
         for b in range(B):
             if done[b]:

@@ -1,0 +1,175 @@
+"""GPU: the remaining corners of the reference's Python surface on the engine.
+
+  * MultiModalBartModel.forward -> (decoder states, encoder states) (reference src/model/model.py:39-103);
+  * forward(encoder_outputs=...) reuses a precomputed encoder (model.py:76-83);
+  * outputs[1] of a training forward = the actual training logits, produced lazily from the saved decoder states;
+  * beam search with min_length (EOS banned AFTER log_softmax) and beam-search multinomial sampling
+    (src/model/mixins.py:336-361 -> transformers 3.0.2 _generate_beam_search) against the oracle with a shared sampler;
+  * AdamW: one bias-correction step per step() with several parameter groups; torch-format optimizer state loads."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import goldenlib as G  # noqa: E402
+from oracle import kmbart_oracle as O  # noqa: E402
+from oracle.make_golden import tiny_batch  # noqa: E402
+from kmbart.optim import AdamW  # noqa: E402
+from src.model import MultiModalBartModel  # noqa: E402
+from test_model_gpu import ACT_TOL, DEV, build, cfg_from_oracle, rel, run_fwd  # noqa: E402
+
+
+def dev_batch(b):
+    return dict(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
+                attention_mask=b["attention_mask"].to(DEV))
+
+
+def test_bare_model_returns_decoder_and_encoder_states():
+    ocfg = G.tiny_config()
+    sd = G.golden_state_dict(ocfg, seed=17)
+    b = tiny_batch(seed=61)
+    with torch.no_grad():
+        enc = O.encoder_forward(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"])
+        pm, causal = O.prepare_decoder_masks(ocfg, b["decoder_input_ids"], b["decoder_attention_mask"])
+        hdec, _ = O.decoder_forward(sd, ocfg, b["decoder_input_ids"], enc, b["attention_mask"], pm, causal)
+    model = MultiModalBartModel(cfg_from_oracle(ocfg))
+    model.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    model.to(DEV).eval()
+    out = model(decoder_input_ids=b["decoder_input_ids"].to(DEV),
+                decoder_attention_mask=b["decoder_attention_mask"].to(DEV), **dev_batch(b))
+    assert isinstance(out, tuple) and len(out) == 2
+    dm, am = b["decoder_attention_mask"].bool(), b["attention_mask"].bool()
+    assert out[0].shape == hdec.shape and out[1].shape == enc.shape
+    assert rel(out[0].cpu()[dm], hdec[dm]) < ACT_TOL and rel(out[1].cpu()[am], enc[am]) < ACT_TOL
+    # bare-model checkpoints carry no `model.` prefix and no logits bias
+    keys = model.state_dict().keys()
+    assert "shared.weight" in keys and "final_logits_bias" not in keys and not any(k.startswith("model.") for k in keys)
+    # the second call reuses the encoder output (model.py:76-83): identical decoder states
+    again = model(decoder_input_ids=b["decoder_input_ids"].to(DEV), encoder_outputs=(out[1],),
+                  decoder_attention_mask=b["decoder_attention_mask"].to(DEV), **dev_batch(b))
+    assert torch.equal(again[0], out[0])
+
+
+def test_forward_with_encoder_outputs_scores_like_the_full_forward():
+    ocfg = G.tiny_config()
+    sd = G.golden_state_dict(ocfg, seed=19)
+    b = tiny_batch(seed=63)
+    model = build(ocfg, sd).eval()
+    with torch.no_grad():
+        loss, logits, enc = run_fwd(model, b, return_logits=True)
+        loss2, logits2, enc2 = run_fwd(model, b, return_logits=True, encoder_outputs=(enc, [], []))
+    assert torch.equal(logits, logits2) and float(loss) == float(loss2) and torch.equal(enc, enc2)
+    # grads enabled + encoder_outputs: a plain scoring loss (nothing to differentiate into the given states)
+    out = run_fwd(model.train(), b, encoder_outputs=(enc,))
+    assert not out[0].requires_grad
+
+
+def test_lazy_logits_are_the_training_logits_and_expire():
+    ocfg = G.tiny_config()
+    sd = G.golden_state_dict(ocfg, seed=23)
+    b = tiny_batch(seed=65)
+    model = build(ocfg, sd, dropout=0.1).train()
+    model._engine.set_seed(5)
+    eager = run_fwd(model, b, return_logits=True)[1].clone()
+    model._engine.set_seed(5)
+    out = run_fwd(model, b)
+    lazy = out[1]
+    out[0].backward()                       # backward leaves the saved decoder states alone
+    assert torch.equal(lazy[:, :, :], eager)          # same dropout masks: the ACTUAL training logits
+    opt = AdamW(model.parameters(), lr=1e-3)
+    out2 = run_fwd(model, b)
+    out2[0].backward()
+    opt.step()
+    with pytest.raises(RuntimeError, match="gone"):
+        out2[1].shape
+
+
+def test_beam_search_min_length_and_sampling_follow_the_oracle():
+    from oracle.make_golden import copy_task_batch
+    ocfg = G.tiny_config()
+    sd = G.trained_state_dict()                                # trained reverse-copy model: peaked, input-dependent
+    model = build(ocfg, sd).eval()
+    b = copy_task_batch(7, 4)
+    kw = dict(num_beams=3, max_length=10, min_length=7, early_stopping=True, num_return_sequences=2)
+    got, sc = model.generate(return_scores=True, **dev_batch(b), **kw)
+    ref, rsc = O.generate(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], return_scores=True, **kw)
+    assert got.cpu().tolist() == ref.tolist()
+    assert torch.allclose(sc, rsc, atol=5e-2)
+    assert all((row[1:7] != ocfg.eos_token_id).all() for row in got.cpu())
+    without = model.generate(**dev_batch(b), **dict(kw, min_length=0))
+    assert without.cpu().tolist() != got.cpu().tolist()        # the ban changed the search
+
+    # beam-search multinomial sampling: the same draws in both implementations (inverse-CDF on a fixed uniform
+    # stream), so the whole bookkeeping -- no forced BOS/EOS, all-zero initial beam scores, top-k/top-p with
+    # min_tokens_to_keep=2, 2*num_beams draws, sort, batch replication for num_return_sequences -- is compared
+    def make_sampler():
+        g = torch.Generator().manual_seed(1234)
+
+        def sampler(probs, n):   # without replacement, like torch.multinomial: Gumbel top-n on a fixed noise stream
+            p = probs.detach().double().cpu()
+            u = torch.rand(p.shape, generator=g, dtype=torch.float64).clamp_(1e-12, 1 - 1e-12)
+            keys = torch.log(p) - torch.log(-torch.log(u))
+            return torch.topk(keys, n, dim=-1)[1].to(probs.device)
+        return sampler
+
+    skw = dict(num_beams=3, max_length=9, do_sample=True, top_k=8, top_p=0.9, temperature=1.3, early_stopping=True,
+               num_return_sequences=2)
+    model._sampler = make_sampler()
+    got = model.generate(**dev_batch(b), **skw)
+    ref = O.generate(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], sampler=make_sampler(), **skw)
+    model._sampler = None
+    assert got.shape[0] == b["input_ids"].shape[0] * 2
+    # bf16 logits: a draw that lands within rounding of a CDF step may pick the neighbouring token; demand that most
+    # rows agree exactly and every row starts from the decoder start token
+    same = sum(a == r for a, r in zip(got.cpu().tolist(), ref.tolist()))
+    assert same * 2 >= got.shape[0], (got.cpu().tolist(), ref.tolist())
+    assert (got[:, 0] == ocfg.decoder_start_token_id).all()
+    # default sampler: runs, shapes right, different seeds differ
+    torch.manual_seed(1)
+    a = model.generate(**dev_batch(b), **skw)
+    torch.manual_seed(2)
+    c = model.generate(**dev_batch(b), **skw)
+    assert a.shape[0] == c.shape[0] == 2 * b["input_ids"].shape[0] and (a.shape != c.shape or not torch.equal(a, c))
+
+
+def test_adamw_param_groups_and_torch_state_dict():
+    ocfg = G.tiny_config()
+    sd = G.golden_state_dict(ocfg, seed=29)
+    b = tiny_batch(seed=69)
+
+    def step_with(groups):
+        model = build(ocfg, sd).train()
+        ps = list(model.parameters())
+        opt = AdamW([{"params": ps[:40]}, {"params": ps[40:]}] if groups == 2 else ps, lr=1e-3)
+        for _ in range(2):
+            run_fwd(model, b)[0].backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return model._engine.params.clone(), model._engine.step_count
+
+    p1, n1 = step_with(1)
+    p2, n2 = step_with(2)
+    assert n1 == n2 == 2          # one bias-correction step per optimizer.step(), whatever the number of groups
+    off, rows, cols = build(ocfg, sd)._engine.index["model.shared.weight"]
+    mask = torch.ones_like(p1, dtype=torch.bool)
+    mask[off: off + rows * cols] = False
+    assert torch.equal(p1[mask], p2[mask])
+    # a torch-format state ({state: {i: {step, exp_avg, exp_avg_sq}}, param_groups}), as the reference's
+    # training_data.pt holds (src/utils.py:20-39), loads into the arena
+    model = build(ocfg, sd).train()
+    params = list(model.parameters())
+    opt = AdamW(params, lr=1e-3)
+    g = torch.Generator().manual_seed(0)
+    state = {"state": {i: {"step": 7, "exp_avg": torch.randn(p.shape, generator=g),
+                           "exp_avg_sq": torch.rand(p.shape, generator=g)} for i, p in enumerate(params)},
+             "param_groups": [{"lr": 5e-4, "betas": (0.9, 0.999), "eps": 1e-6, "weight_decay": 0.0,
+                               "correct_bias": True, "params": list(range(len(params)))}]}
+    opt.load_state_dict(state)
+    eng = model._engine
+    assert eng.step_count == 7 and opt.param_groups[0]["lr"] == 5e-4
+    for i, p in enumerate(params):
+        o, n = p._kmb_range
+        assert torch.equal(eng.exp_avg[o: o + n].cpu(), state["state"][i]["exp_avg"].reshape(-1))
+        assert torch.equal(eng.exp_avg_sq[o: o + n].cpu(), state["state"][i]["exp_avg_sq"].reshape(-1))
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"foo": 1})

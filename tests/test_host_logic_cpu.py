@@ -56,6 +56,9 @@ class _FakeLoss:
     def backward(self):
         self.log.append("backward")
 
+    def detach(self):
+        return self
+
 
 class _FakeModel:
     def __init__(self, log):
@@ -82,7 +85,8 @@ class _FakeOpt:
 
 
 def test_fine_tune_order_and_log_line():
-    """reference src/training.py:118-153: forward -> loss.item() -> zero_grad -> backward -> step; log format."""
+    """reference src/training.py:118-153: forward -> zero_grad -> backward -> step, log format; the loss of step i is
+    read (`.item()`, a host synchronisation) only after step i+1 has been enqueued -- or before the callback runs."""
     from src.training import fine_tune
     log, lines = [], []
     b = make_batch(2, enc_len=16, dec_len=8, num_regions=3)
@@ -90,9 +94,18 @@ def test_fine_tune_order_and_log_line():
     seen = []
     fine_tune(0, _FakeModel(log), [b, b], _FakeOpt(log), "cpu", types.SimpleNamespace(amp=False, epochs=3), logger=logger,
               callback=lambda **kw: seen.append(sorted(kw)))
-    assert log == ["train"] + ["forward", "item", "zero_grad", "backward", "step"] * 2
+    assert log == ["train"] + ["forward", "zero_grad", "backward", "step", "item"] * 2   # a callback sees step i reported
     assert lines[0].startswith("Epoch [1/3], Step [1/2], Loss: 1.5000, ETA: ")
+    assert lines[1].startswith("Epoch [1/3], Step [2/2], Loss: 1.5000, ETA: ") and len(lines) == 2
     assert seen[0] == ["args", "epoch", "logger", "model", "optimizer", "step", "train_loader"]
+    # without a callback the read trails the enqueue by one step; every step is still reported, in order
+    log.clear()
+    lines.clear()
+    mean = fine_tune(0, _FakeModel(log), [b, b, b], _FakeOpt(log), "cpu", types.SimpleNamespace(amp=False, epochs=3),
+                     logger=logger)
+    one = ["forward", "zero_grad", "backward", "step"]
+    assert log == ["train"] + one + one + ["item"] + one + ["item", "item"]
+    assert [ln.split(",")[1].strip() for ln in lines] == ["Step [1/3]", "Step [2/3]", "Step [3/3]"] and mean == 1.5
 
 
 def test_generate_text_record_schema():
@@ -136,7 +149,7 @@ def test_pretrain_loop_uses_the_loss_dict():
     assert int(b["attribute_mask"][0].sum()) == len(b["attribute_labels"][0])
     logger = types.SimpleNamespace(info=lambda m, pad=False: lines.append(m))
     pretrain(0, M(), [b], _FakeOpt(log), "cpu", types.SimpleNamespace(amp=False, epochs=2), logger=logger)
-    assert log == ["train", "forward", "item", "zero_grad", "backward", "step"]
+    assert log == ["train", "forward", "zero_grad", "backward", "step", "item"]
     assert lines[0].startswith("Epoch [1/2], Step [1/1], Loss: 2.0000, ETA: ")
 
 

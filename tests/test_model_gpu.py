@@ -21,7 +21,7 @@ from kmbart.optim import AdamW  # noqa: E402
 DEV = "cuda:0"
 LOSS_TOL = 1e-3     # relative, BASELINE.json north_star
 ACT_TOL = 2e-2      # norm-wise relative error of bf16 activations / logits after 2..12 layers
-GRAD_TOL = 6e-2     # norm-wise relative error of bf16-computed gradients
+GRAD_TOL = 3e-2     # norm-wise relative error of bf16-computed gradients (full-size, per tensor class: test_fullsize_parity_gpu.py)
 
 
 def rel(a, b):
@@ -114,6 +114,7 @@ def test_every_gradient_against_oracle(case):
         e = rel(p.grad, r)
         if e > worst[1]:
             worst = (n, e)
+    print(f"[tiny {case}] worst gradient error {worst[1]:.3e} ({worst[0]})")
     assert worst[1] < GRAD_TOL, worst
 
 
@@ -180,32 +181,24 @@ def test_dropout_training_mode_is_deterministic_per_seed():
 
 
 def test_generation_matches_golden(gold_dir):
+    """Greedy and beam search on the tiny model TRAINED on the reverse-copy task (non-degenerate, peaked
+    distributions): token ids must equal the golden ones -- which oracle/make_golden.py verified identical, ids and
+    scores, to transformers 5.15 generate() for every early_stopping=True case -- and the scores agree to bf16."""
     gen = json.load(open(os.path.join(gold_dir, "tiny_generate.json")))
-    ocfg = G.tiny_config(init_std=0.2)
-    sd = G.golden_state_dict(ocfg, seed=9)
-    sd["final_logits_bias"][0, ocfg.eos_token_id] += 3.0
+    ocfg = G.tiny_config()
+    sd = G.trained_state_dict()
     model = build(ocfg, sd).eval()
     ids = torch.tensor(gen["input_ids"])
     am = torch.tensor(gen["attention_mask"])
-    feats = G.golden_features(gen["regions"])
+    feats = G.golden_features(gen["regions"], seed=gen["seed"])
     for case in gen["cases"]:
         kw = case["kwargs"]
         out = model.generate(input_ids=ids.to(DEV), image_features=[f.to(DEV) for f in feats],
                              attention_mask=am.to(DEV), return_scores="scores" in case, **kw)
         if "scores" in case:
             got, scores = out
-            if got.cpu().tolist() != case["ids"]:
-                # bf16 logits may flip a near-tie between two beams late in a long search; the hypotheses found
-                # must then be of the same quality as the golden ones (length-normalised log-prob)
-                assert got.shape[0] == len(case["ids"]), kw
-                assert np.allclose(scores.numpy(), case["scores"], atol=5e-2), (kw, scores, case["scores"])
-                nret = kw.get("num_return_sequences", 1)
-                same = sum(a == b for a, b in zip(got.cpu().tolist(), case["ids"]))
-                assert same * 3 >= len(case["ids"]), (kw, same)            # near-ties may reorder the lower-ranked beams
-                for a, b in zip(got.cpu().tolist()[::nret], case["ids"][::nret]):
-                    assert a[:4] == b[:4], kw                                # the best one starts the same way
-            else:
-                assert np.allclose(scores.numpy(), case["scores"], atol=8e-2)
+            assert got.cpu().tolist() == case["ids"], kw
+            assert np.allclose(scores.numpy(), case["scores"], atol=3e-2), (kw, scores, case["scores"])
         else:
             assert out.cpu().tolist() == case["ids"], kw
 

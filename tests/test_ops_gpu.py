@@ -392,12 +392,20 @@ def test_logsoftmax_topk(V, ld):
     add = rnd(rows, seed=62)
     val = torch.empty((rows, k), device=DEV)
     idx = torch.empty((rows, k), dtype=torch.int32, device=DEV)
-    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, k, ptr(val), ptr(idx), stream()))
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, -1, k, ptr(val), ptr(idx), stream()))
     lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
     rv, ri = torch.topk(lp, k, dim=1)
     assert torch.equal(idx.long(), ri)
     assert torch.allclose(val, rv, atol=1e-4)
-    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), 2, k, ptr(val), ptr(idx), stream()))
+    # ban_token (min_length): the EOS score is -inf AFTER the normalisation -- the other scores keep the full
+    # log-sum-exp (masking the logit first would renormalise every row by -log(1 - p_eos))
+    ban = int(ri[0, 0])
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, ban, k, ptr(val), ptr(idx), stream()))
+    lpb = lp.clone()
+    lpb[:, ban] = -float("inf")
+    bv, bi = torch.topk(lpb, k, dim=1)
+    assert torch.equal(idx.long(), bi) and torch.allclose(val, bv, atol=1e-4) and not bool((idx == ban).any())
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), 2, -1, k, ptr(val), ptr(idx), stream()))
     assert torch.all(idx[:, 0] == 2) and torch.allclose(val[:, 0], add, atol=1e-6)
     assert torch.all(torch.isinf(val[:, 1:]))
     assert idx[0, 1:].tolist() == [0, 1] + list(range(3, k))
@@ -407,7 +415,7 @@ def test_logsoftmax_topk(V, ld):
     logits[:, 7000] = logits[:, 5 + 256 * 11]
     logits[:, 300] = logits[:, 5 + 256 * 11]
     logits[:, 5 + 256 * 10] = -float("inf")
-    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, k, ptr(val), ptr(idx), stream()))
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, -1, k, ptr(val), ptr(idx), stream()))
     lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
     order = torch.sort(lp, dim=1, descending=True, stable=True)[1][:, :k]
     assert torch.equal(idx.long(), order)
@@ -420,7 +428,7 @@ def test_logsoftmax_topk(V, ld):
     logits[:, 7001] = logits[:, own[11]]
     logits[:, 301] = logits[:, own[11]]
     logits[:, own[10]] = -float("inf")
-    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, k, ptr(val), ptr(idx), stream()))
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, -1, k, ptr(val), ptr(idx), stream()))
     lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
     order = torch.sort(lp, dim=1, descending=True, stable=True)[1][:, :k]
     assert torch.equal(idx.long(), order)
@@ -461,7 +469,7 @@ def test_beam_merge_matches_torch_topk_over_all_beams():
     for force in (-1, 2):
         val = torch.empty((B * nb, k), device=DEV)
         idx = torch.empty((B * nb, k), dtype=torch.int32, device=DEV)
-        check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, B * nb, ptr(add), force, k, ptr(val), ptr(idx), stream()))
+        check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, B * nb, ptr(add), force, -1, k, ptr(val), ptr(idx), stream()))
         out = torch.empty((B, k, 2), dtype=torch.int32, device=DEV)
         check(lib.kmb_beam_merge(ptr(val), ptr(idx), B, nb, k, V, ptr(out), stream()))
         got_scores = out[:, :, 0].contiguous().view(torch.float32)

@@ -17,6 +17,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device("cuda", 0)
 model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(bench.VCG_BASE)).to(dev).train()
 opt = AdamW(model.parameters(), lr=1e-5)
+opt.allow_overlap(True)
 b = make_batch(B, seed=1)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 batch["image_features"] = [f.to(dev) for f in b["image_features"]]

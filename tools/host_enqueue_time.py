@@ -16,6 +16,7 @@ from src.model import MultiModalBartConfig, MultiModalBartForConditionalGenerati
 dev = torch.device("cuda", 0)
 model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(bench.VCG_BASE)).to(dev).train()
 opt = AdamW(model.parameters(), lr=1e-5)
+opt.allow_overlap(True)
 for B in (int(a) for a in (sys.argv[1:] or ["32", "64", "128", "256", "512"])):
     b = make_batch(B, seed=1)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}

@@ -29,6 +29,7 @@ torch.manual_seed(0)
 cfg = MultiModalBartConfig.from_dict(dict(bench.VCG_BASE, num_labels=1601, num_attributes=129, num_relations=129))
 model = MultiModalBartForPreTraining(cfg).to(dev).train()
 opt = AdamW(model.parameters(), lr=1e-5)
+opt.allow_overlap(True)
 S, T, R = 80, 48, 50
 b = make_pretrain_batch(args.batch, enc_len=S, dec_len=T, num_regions=R, seed=1234)
 dv = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}

@@ -11,10 +11,10 @@ logits = torch.randn(rows, ld, device=DEV) * 4
 add = torch.randn(rows, device=DEV)
 for k, ft in ((1, -1), (2, -1), (5, -1), (10, -1)):
     val = torch.empty((rows, k), device=DEV); idx = torch.empty((rows, k), dtype=torch.int32, device=DEV)
-    for _ in range(3): check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), ft, k, ptr(val), ptr(idx), stream()))
+    for _ in range(3): check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), ft, -1, k, ptr(val), ptr(idx), stream()))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20): check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), ft, k, ptr(val), ptr(idx), stream()))
+    for _ in range(20): check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), ft, -1, k, ptr(val), ptr(idx), stream()))
     e1.record(); torch.cuda.synchronize()
     print("k", k, "probe", ft, round(e0.elapsed_time(e1) / 20 * 1e3, 1), "us")

@@ -13,6 +13,7 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(bench.VCG_BASE)).to(dev).train()
 opt = AdamW(model.parameters(), lr=1e-4)
+opt.allow_overlap(True)
 b = make_batch(256, seed=1)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 batch["image_features"] = [f.to(dev) for f in b["image_features"]]
