@@ -18,10 +18,20 @@ container.  The oracle is therefore pinned two ways, both run by
     (same architecture and parameter names; see SURVEY.md §8c) to <= 1e-5;
   * the training harness: by driving this model through the REFERENCE's own
     `src.training.fine_tune` (importable here) and committing the loss sequence.
-Generation (greedy / beam) restates the published transformers 3.0.2
-`generation_utils` algorithm from its call sites in `src/model/mixins.py:33-434`;
-no independent token-exact cross-check exists offline: **parity unpinned** for
-the beam bookkeeping.
+  * the KM-BART-specific multimodal embedding: against a plain nn.Linear + nn.Embedding +
+    masked index assignment written from reference src/model/modules.py:24-41,89-102
+    (`make_golden.reference_style_multimodal_embedding`), which also feeds the transformers
+    side of the cross-check (the oracle's own function no longer does);
+  * generation: the beam search (HF 3.0.2 `_generate_beam_search` restated from its call
+    sites in `src/model/mixins.py:33-434`) against transformers 5.15 `generate()` on a tiny
+    model trained to a non-degenerate task: token ids AND length-normalised scores are
+    identical for every early_stopping=True case (the reference's setting,
+    src/generation.py:22-32), min_length included.  early_stopping=False differs by a
+    documented algorithm change (4.x bounds the attainable score with max_length).
+What stays **parity unpinned**: everything is pinned to transformers 5.15 and to the
+reference's importable modules, not to transformers 3.0.2 itself (absent offline); the
+multinomial-sampling branch of beam search has no independent check (its draws are not
+reproducible across implementations) beyond the shared deterministic bookkeeping.
 
 Reference map (file:line into /root/reference)
 ----------------------------------------------
