@@ -65,5 +65,31 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, defines, sources=("gemm.hip",)):
+    """Experiment build: lib/libkmbart_hip_<name>.so with extra -D defines on the given sources (the other objects are
+    the product build's).  Select it with KMB_LIB_PATH.  Never shipped: diagnostics and A/B measurements only."""
+    build(verbose=False)
+    objdir = os.path.join(LIBDIR, "obj")
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(objdir, src + ".o")
+        if src in sources:
+            o = os.path.join(objdir, "%s.%s.o" % (src, name))
+            cmd = ["hipcc", "-x", "hip"] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", o]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+        objs.append(o)
+    lib = os.path.join(LIBDIR, "libkmbart_hip_%s.so" % name)
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:   # python build.py --variant plain KMB_PLAIN_STORES
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build(force="--force" in sys.argv)

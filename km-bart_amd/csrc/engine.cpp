@@ -113,7 +113,7 @@ struct kmb_handle {
   std::vector<bf16_t*> xe, xd;
   bf16_t *ze0 = nullptr, *zd0 = nullptr; float *me0, *re0, *md0, *rd0;
   bf16_t* xf = nullptr; float* img_emb = nullptr; int32_t* img_src = nullptr; bf16_t* dimg = nullptr;
-  float* logits_c = nullptr; bf16_t* dlogits_c = nullptr; float* loss_rows = nullptr; int32_t* count = nullptr;
+  float* logits_c = nullptr; size_t logits_c_floats = 0; bf16_t* dlogits_c = nullptr; float* loss_rows = nullptr; int32_t* count = nullptr;
   int32_t* status = nullptr; float* loss_dev = nullptr;
   bf16_t *dhdec, *dyA, *dyB, *dz, *dob, *denc;
   // gradient buffers read by the weight-gradient GEMMs of the side stream: one per LayerNorm site
@@ -410,8 +410,12 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     a.m1 = bp.take<float>(Md); a.r1 = bp.take<float>(Md); a.m2 = bp.take<float>(Md); a.r2 = bp.take<float>(Md);
     a.m3 = bp.take<float>(Md); a.r3 = bp.take<float>(Md);
   }
+  // bf16 product path: the training logits live in dlogits_c (bf16, turned into their own gradient in place by the CE
+  // kernel); logits_c only holds the split-K slabs of the head's data gradient (<= 8 x Md x d floats).  The fp32
+  // validation mode keeps fp32 logits here, in row chunks of lm_chunk.
   const size_t CH = Md < (size_t)h->lm_chunk ? Md : (size_t)h->lm_chunk;
-  float* logits_c = bp.take<float>(CH * h->Vpad);
+  const size_t lc_floats = (g_f32 || h->Vpad > 65536) ? CH * h->Vpad : (size_t)8 * Md * d;
+  float* logits_c = bp.take<float>(lc_floats);
   bf16_t* dlogits_c = bp.act(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
   const size_t slab_floats = (size_t)20 << 20;          // split-K partial slabs of the weight-gradient GEMMs (80 MB)
   float* slab = bp.take<float>(slab_floats);
@@ -449,7 +453,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   if (assign) {
     H->status = status; H->count = count; H->loss_dev = loss_dev; H->xf = xf; H->img_emb = img_emb; H->dimg = dimg;
     H->img_src = img_src; H->ze0 = ze0; H->me0 = me0; H->re0 = re0; H->zd0 = zd0; H->md0 = md0; H->rd0 = rd0;
-    H->xe = xe; H->xd = xd; H->ea = ea; H->da = da; H->logits_c = logits_c; H->dlogits_c = dlogits_c;
+    H->xe = xe; H->xd = xd; H->ea = ea; H->da = da; H->logits_c = logits_c; H->logits_c_floats = lc_floats; H->dlogits_c = dlogits_c;
     H->loss_rows = loss_rows; H->dhdec = dhdec; H->dyA = dyA; H->dyB = dyB; H->dz = dz;
     H->bb[0] = bb[0]; H->bb[1] = bb[1]; H->dob = dob; H->denc = denc; H->parts = parts;
     H->slab = slab; H->slab_floats = slab_floats;
@@ -946,16 +950,30 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   // 512-row chunks measured 0.8 % slower end to end.
   if (bt.labels) HIPCHK(kmb_count_valid_launch(bt.labels, Md, h->count, s));
   if (bt.labels || logits_out) {
-    const int CH = Md < h->lm_chunk ? Md : h->lm_chunk;
+    // bf16 head (product path, no logits requested): ONE GEMM writes bf16 logits into dlogits_c and the CE kernel turns
+    // them into the gradient in place.  fp32 head: logits requested by the caller / fp32 validation mode / very wide
+    // vocabularies, in row chunks that bound the fp32 buffer.
+    const bool bf16_head = !g_f32 && !logits_out && h->Vpad <= 65536;
+    const int CH = bf16_head ? Md : (Md < h->lm_chunk ? Md : h->lm_chunk);
     const bf16_t* Eb = h->wb(h->shared);
+    const float lmf = extra ? extra->lm_factor : 1.f;
     for (int r0 = 0, c = 0; r0 < Md; r0 += CH, ++c) {
       const int rows = (Md - r0) < CH ? (Md - r0) : CH;
-      float* lg = logits_out ? logits_out + (size_t)r0 * h->Vpad : h->logits_c;
       KmbGemm g = lin_fwd(EP(hdec, (size_t)r0 * d), d, Eb, h->flb, rows, h->V, d);
+      if (bf16_head) {
+        bf16_t* lg = h->dlogits_c + (size_t)r0 * h->Vpad;
+        g.out_bf16 = lg; g.ld_out_bf16 = h->Vpad;
+        KCHK(run_gemm(g, s));
+        if (bt.labels)
+          HIPCHK(kmb_ce_bf16_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, lmf, h->loss_rows + r0,
+                                    need_grad ? lg : nullptr, s));
+        continue;
+      }
+      float* lg = logits_out ? logits_out + (size_t)r0 * h->Vpad : h->logits_c;
       g.out_f32 = lg; g.ld_out_f32 = h->Vpad;
       KCHK(run_gemm(g, s));
       if (!bt.labels) continue;
-      HIPCHK(kmb_ce_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, extra ? extra->lm_factor : 1.f, h->loss_rows + r0,
+      HIPCHK(kmb_ce_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, lmf, h->loss_rows + r0,
                            need_grad ? h->dlogits_c + (size_t)r0 * h->Vpad : nullptr, s));
     }
     if (bt.labels && need_grad) {
@@ -965,7 +983,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       // whole vocabulary (788 K steps): split it so that the grid is a whole number of rounds; a small pass sums the
       // slabs into the bf16 gradient.  The slabs live in the fp32 logits buffer, which is free once the CE ran.
       const int tiles256 = ((Md + 255) / 256) * ((d + 255) / 256);
-      const size_t CHl = (size_t)(Md < h->lm_chunk ? Md : h->lm_chunk) * h->Vpad;   // floats in the logits buffer
+      const size_t CHl = h->logits_c_floats;   // floats in the slab / logits buffer
       static const int rounds = getenv("KMB_HEAD_DGRAD_ROUNDS") ? atoi(getenv("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
       int S = tiles256 > 0 ? (256 * rounds) / tiles256 : 1;
       if (S > 8) S = 8;

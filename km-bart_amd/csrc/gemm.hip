@@ -56,6 +56,14 @@ extern "C" int kmb_debug_set_stamps(void* p) {
 #define KMB_STAMP_VALUE(i, v)
 #endif
 
+// KMB_PLAIN_STORES (experiment builds, build.py --variant): default-policy stores in the persistent kernels' epilogues
+// instead of non-temporal ones
+#ifdef KMB_PLAIN_STORES
+#define KMB_NT_STORE(v, p) (*(p) = (v))
+#else
+#define KMB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
 namespace {
 
 int g_shared_device = 0;   // kmb_gemm_shared_device(): other kernels (RCCL) hold CUs while the GEMMs run
@@ -171,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x
 // WAVE: one wave runs the body on its private 16-row staging chunk (v11); the column sums are carried across chunks
 // in csum_io and finished by the caller.
 template <int NT, bool HOIST, int NIT, int LD, bool SWZ, int TILE_ROWS, int ACT, bool RES, bool CS, bool FAST,
-          bool WAVE = false>
+          bool WAVE = false, int WCOLS = 128>
 __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float* ef, float* cs, int tid, int row0,
                                                    int col0, float* csum_io = nullptr) {
   constexpr int RPP = NT / 16;  // rows per pass
@@ -185,6 +193,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
   const bool cs_on = CS && (ACT >= 0 || p.colsum != nullptr);
   const int c8 = (tid & 15) * 8;
   const int gcol = col0 + c8;
+  if (WAVE && WCOLS < 128 && c8 >= WCOLS) return;   // a 96-column wave block: the last four column-lanes have no data
   // FAST: the whole tile lies inside C (a workgroup-uniform fact): no per-row / per-column edge handling at all
   if (!FAST && gcol >= p.N && !cs_on) return;
   const int nvalid = FAST ? 8 : (gcol >= p.N ? 0 : ((p.N - gcol) < 8 ? (p.N - gcol) : 8));
@@ -289,7 +298,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
     if (p.out_bf16 != nullptr) {
       if (full8) {
         u32x4* const dst = reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)grow * p.ld_out_bf16 + gcol);
-        if (WAVE) __builtin_nontemporal_store(pack8(v), dst);   // streaming: C must not evict the A / B panels from L2
+        if (WAVE) KMB_NT_STORE(pack8(v), dst);   // streaming: C must not evict the A / B panels from L2
         else *dst = pack8(v);
       } else {
         for (int e = 0; e < nvalid; ++e) p.out_bf16[(size_t)grow * p.ld_out_bf16 + gcol + e] = f2bf(v[e]);
@@ -920,11 +929,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 // workgroups of an XCD up to 12 us apart (no HBM burst limit at this size).  Whole kernel 76-77 us against 90 us for
 // v8; the vendor library's stream-K kernel (256 workgroups x 256 threads, 256x256x64, tools/gemm_yardstick.py) takes
 // 70.5 us per call in a back-to-back loop on this shape.
-template <bool KC>
-__device__ __forceinline__ void dma_offsets256w4(uint32_t (&off)[8], int ld, int r0, int R, int wave, int lane) {
+template <bool KC, int NP = 8>
+__device__ __forceinline__ void dma_offsets256w4(uint32_t (&off)[NP], int ld, int r0, int R, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int piece = wave * 8 + i;  // 32 pieces of 1 KiB per 256-row tile
+  for (int i = 0; i < NP; ++i) {
+    const int piece = wave * NP + i;  // 4 * NP pieces of 1 KiB per tile (32 for 256 rows, 24 for a 192-row KC image)
     if (KC) {
       const int row = piece * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
@@ -947,9 +956,10 @@ constexpr int EPW_BYTES = 16 * 128 * 4;            // wave-private fp32 staging:
 constexpr int LDS11 = 2 * ST4 + 4 * EPW_BYTES;     // 160 KB: the whole CU
 constexpr int LDS12 = 2 * (BM4 + 128) * BK * 2 + 4 * EPW_BYTES;   // 256x128 tiles: 128 KB
 
-template <int ACT, bool RES, bool CS, bool FAST, int WROWS>
-__device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][8], float* ef, int lane, int r, int g,
+template <int ACT, bool RES, bool CS, bool FAST, int WROWS, int NJ = 8>
+__device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][NJ], float* ef, int lane, int r, int g,
                                              int row0w, int col0w) {
+  constexpr int WCOLS = NJ * 16;   // columns of this wave's block (128, or 96 for the 256x192 tile)
   float csum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
@@ -957,9 +967,9 @@ __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][8
   // one ds_write_b128 per MFMA tile; 16-byte groups XOR-swizzled by the row so that the 16 row-lanes spread over banks
   float* const wbase = ef + r * 128;
   const int sw = (r & 7) << 3;
-  auto stage = [&](const f32x4 (&a)[8]) {
+  auto stage = [&](const f32x4 (&a)[NJ]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
     asm volatile("" ::: "memory");   // keep the stores inside their switch arm (no select tree over the accumulators)
   };
 #pragma unroll 1
@@ -974,8 +984,8 @@ __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][8
       case 6: stage(acc[6]); break;
       default: stage(acc[7]); break;
     }
-    gemm_epilogue_body<64, true, 4, 128, true, 128, ACT, RES, CS, FAST, true>(p, ef, nullptr, lane, row0w + i * 16, col0w,
-                                                                             csum);
+    gemm_epilogue_body<64, true, 4, 128, true, 128, ACT, RES, CS, FAST, true, WCOLS>(p, ef, nullptr, lane, row0w + i * 16,
+                                                                                    col0w, csum);
   }
   if (CS && (ACT >= 0 || p.colsum != nullptr)) {
     // column sums over this wave's 128 rows: fold the four row-lanes, one partial row per 64 rows of C (first filled,
@@ -985,7 +995,7 @@ __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][8
       csum[e] += __shfl_xor(csum[e], 16);
       csum[e] += __shfl_xor(csum[e], 32);
     }
-    if (lane < 16) {
+    if (lane < WCOLS / 8) {
       const int prow = row0w >> 6;
       const int c8 = lane * 8;
 #pragma unroll
@@ -1005,10 +1015,14 @@ __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][8
 // blocks with a bf16 output only; same operation order as gemm_epilogue_body (bit-identical results).
 //   BIAS: + bias[col];  SCALE: * col_scale (the whole wave block lies in the scaled columns);  ACT 1: GeLU (+ optional
 //   pre-activation store), 2: * GeLU'(aux);  DROP: dropout mask;  RES: + residual;  CS: column sums.
-template <bool BIAS, bool SCALE, int ACT, bool RES, bool DROP, bool CS, int WROWS, bool F32 = false>
-__device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)[8][8], float* ef, int lane, int r, int g,
+template <bool BIAS, bool SCALE, int ACT, bool RES, bool DROP, bool CS, int WROWS, bool F32 = false, int NJ = 8>
+__device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)[8][NJ], float* ef, int lane, int r, int g,
                                                   int row0w, int col0w) {
-  const int lr = lane >> 4, c8 = (lane & 15) * 8;
+  constexpr int WCOLS = NJ * 16;
+  const int lr = lane >> 4;
+  // a 96-column wave block (256x192 tile) keeps the 128-column lane map: the last four column-lanes of every row group
+  // redo column-lane 11's work on the same addresses (same values: harmless duplicate stores) instead of branching
+  const int c8 = WCOLS < 128 ? (((lane & 15) * 8 < WCOLS) ? (lane & 15) * 8 : WCOLS - 8) : (lane & 15) * 8;
   const int gcol = col0w + c8;
   kmb_f32x2 bias2[4], csum2[4];
 #pragma unroll
@@ -1021,9 +1035,9 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
   // staging write (transposed accumulators: lane (r, g) holds C[16 i + r][16 j + 4 g .. +3]) and read addresses
   float* const wbase = ef + r * 128;
   const int sw = (r & 7) << 3;
-  auto stage = [&](const f32x4 (&a)[8]) {
+  auto stage = [&](const f32x4 (&a)[NJ]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
     asm volatile("" ::: "memory");
   };
   const float* rd[4];
@@ -1092,7 +1106,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
       if (ACT == 1) {
         if (pre != nullptr) {
           const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
-          __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(pre + roff * p.ld_preact));
+          KMB_NT_STORE(pk, reinterpret_cast<u32x4*>(pre + roff * p.ld_preact));
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu2(v[e]);
@@ -1123,11 +1137,11 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
       }
       if (F32) {
         float* o = out32 + roff * p.ld_out_f32;
-        __builtin_nontemporal_store(f32x4{v[0][0], v[0][1], v[1][0], v[1][1]}, reinterpret_cast<f32x4*>(o));
-        __builtin_nontemporal_store(f32x4{v[2][0], v[2][1], v[3][0], v[3][1]}, reinterpret_cast<f32x4*>(o + 4));
+        KMB_NT_STORE((f32x4{v[0][0], v[0][1], v[1][0], v[1][1]}), reinterpret_cast<f32x4*>(o));
+        KMB_NT_STORE((f32x4{v[2][0], v[2][1], v[3][0], v[3][1]}), reinterpret_cast<f32x4*>(o + 4));
       } else {
         const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
-        __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16));
+        KMB_NT_STORE(pk, reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16));
       }
     }
     if (SIDE) {
@@ -1165,9 +1179,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   [[maybe_unused]] uint64_t kmb_loop_ticks = 0, kmb_epi_ticks = 0, kmb_wait_ticks = 0, kmb_drain_ticks = 0;  // diagnostic build
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int WN = BNT / 128, WM = 4 / WN, WROWS = BM4 / WM, MH = WROWS / 64;   // 2,2,128,2  or  1,4,64,1
-  constexpr int NPB = BNT / 32;                        // 1 KiB LDS-DMA pieces of B per wave and stage
-  constexpr int STG = (BM4 + BNT) * BK * 2;            // one pipeline stage
+  // BNT = 256: waves 2x2 of 128x128;  128: waves 4x1 of 64x128;  192: waves 2x2 of 128x96 (N = 768 = 4 x 192: 256 / 512
+  // tiles at M = 16384 / 32768, one / two per CU, where 256-wide tiles leave a quarter / half round idle)
+  constexpr int WN = BNT == 128 ? 1 : 2, WM = 4 / WN, WROWS = BM4 / WM, MH = WROWS / 64;   // 2,2,128,2  or  1,4,64,1
+  constexpr int WCOLS = BNT / WN, NJ = WCOLS / 16;     // columns / MFMA tile columns of a wave block: 128 / 8 or 96 / 6
+  // B image: a non-KC 192-column tile keeps the 256-column row stride (the XOR swizzle of the transposing reads
+  // permutes 32-byte chunks within groups of eight: 12 chunks do not close under it); its pieces cover the full stride
+  // and the lanes past column 191 fetch bytes nobody reads
+  constexpr int BIMG = (BNT == 192 && !B_KC) ? 256 : BNT;
+  constexpr int NPB = BIMG / 32;                       // 1 KiB LDS-DMA pieces of B per wave and stage
+  constexpr int STG = (BM4 + BIMG) * BK * 2;           // one pipeline stage
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BNT - 1) / BNT;
@@ -1229,8 +1250,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int row0 = tm * BM4, col0 = tn * BNT;
     dma_offsets256w4<A_KC>(offA, p.lda, row0, p.M, wave, lane);
-    if constexpr (BNT == 256) dma_offsets256w4<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
-    else dma_offsets<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
+    if constexpr (BNT == 128) dma_offsets<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
+    else dma_offsets256w4<B_KC, NPB>(offB, p.ldb, col0, p.N, wave, lane);
     gA_d = uniform_ptr(reinterpret_cast<const char*>(p.A) + (A_KC ? (size_t)row0 * p.lda * 2 : (size_t)row0 * 2));
     gB_d = uniform_ptr(reinterpret_cast<const char*>(p.B) + (B_KC ? (size_t)col0 * p.ldb * 2 : (size_t)col0 * 2));
   };
@@ -1253,9 +1274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define KMB_V11_SPLIT 1
 #endif
   constexpr int NA3 = KMB_V11_SPLIT == 3 ? 4 : 8;
-  constexpr int NB3 = KMB_V11_SPLIT == 0 ? 8 : 0;
-  constexpr int NB0 = KMB_V11_SPLIT == 0 ? 0 : KMB_V11_SPLIT == 2 ? 4 : 8;
-  constexpr int NB1 = 8 - NB3 - NB0;
+  constexpr int NB3 = KMB_V11_SPLIT == 0 ? NPB : 0;
+  constexpr int NB0 = KMB_V11_SPLIT == 0 ? 0 : KMB_V11_SPLIT == 2 ? NPB / 2 : NPB;
+  constexpr int NB1 = NPB - NB3 - NB0;
   constexpr int P3 = (NA3 + NB3) / 2, P0 = (8 - NA3 + NB0) / 2, P1 = NB1 / 2;   // pairs of pieces per sub-phase
   auto dma_a = [&](int buf, int lo, int hi) {
     char* da = dstA + buf * STG;
@@ -1277,22 +1298,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto dma_stage_a = [&](int buf) { dma_a(buf, 0, 8); };
   auto dma_stage_b = [&](int buf, int) { dma_b(buf, 0, NPB); };
 
-  constexpr int NDA = A_KC ? 4 : 8;    // ds_read instructions per 4 A fragments
-  constexpr int NDB = B_KC ? 8 : 16;   // ... per 8 B fragments
-  bf16x8 fa[2][4], fb[2][8];
-  f32x4 acc[8][8];
+  constexpr int NDA = A_KC ? 4 : 8;          // ds_read instructions per 4 A fragments
+  constexpr int NDB = B_KC ? NJ : 2 * NJ;    // ... per NJ B fragments
+  constexpr int NM = 4 * NJ;                 // MFMAs of one sub-phase (4 A fragments x NJ B fragments)
+  bf16x8 fa[2][4], fb[2][NJ];
+  f32x4 acc[8][NJ];
   auto read_a = [&](const char* stage, int kk, int half, bf16x8 (&dst)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * (MH * 4) + half * 4 + i, kk, r, g);
   };
-  auto read_b = [&](const char* stage, int kk, bf16x8 (&dst)[8]) {
+  auto read_b = [&](const char* stage, int kk, bf16x8 (&dst)[NJ]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j] = read_frag3<B_KC, BNT>(stage + A_BYTES, wn * 8 + j, kk, r, g);
+    for (int j = 0; j < NJ; ++j) dst[j] = read_frag3<B_KC, BIMG>(stage + A_BYTES, wn * NJ + j, kk, r, g);
   };
 #ifdef KMB_V11_MFMA32_TIMING
   // TIMING EXPERIMENT ONLY (diagnostic builds): the same fragments fed to 32x32x16 MFMAs -- half as many instructions,
   // 32 cycles each, 8 of them holding the issue port.  Results are meaningless; the K loop's duration is the point.
   f32x16 acc32[4][4];
+  static_assert(NJ == 8, "timing experiment: 128-column wave blocks only");
   auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[8]) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -1304,11 +1327,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 #define KMB_MF(n) ((n) / 2)
 #else
-  auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[8]) {
+  auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[NJ]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < NJ; ++j)
         acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);  // C^T tile
   };
 #define KMB_MF(n) (n)
@@ -1340,7 +1363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < MH * 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef KMB_V11_MFMA32_TIMING
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1373,13 +1396,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < P0; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(20 / (P0 > 0 ? P0 : 1)), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF((NM - 12) / (P0 > 0 ? P0 : 1)), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- sub-phase 1: A(k0, rows 64-127) x B(k0)  ||  read B(k1), A(k1, rows 0-63) ----
       read_b(cur, 1, fb[1]);
       read_a(cur, 1, 0, fa[0]);
-      dma_b((it + 1) & 1, NB3 + NB0, 8);
+      dma_b((it + 1) & 1, NB3 + NB0, NPB);
       mma(1, fa[1], fb[0]);
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(6), 1);   // MFMAs first: their operands were read a sub-phase ago
       __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
@@ -1391,7 +1414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < P1; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(12 / (P1 > 0 ? P1 : 1)), 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF((NM - 20) / (P1 > 0 ? P1 : 1)), 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       advance_cursor();
@@ -1400,7 +1423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       mma(0, fa[0], fb[1]);
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(8), 2);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 2);
-      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(24), 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(NM - 8), 2);
       __builtin_amdgcn_sched_barrier(0);
       {
         KMB_WAIT_BEGIN();
@@ -1422,7 +1445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < P3; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 3);  // VMEM (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(24 / P3), 3);
+        __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF((NM - 8) / P3), 3);
       }
       __builtin_amdgcn_sched_barrier(0);
       } else {
@@ -1476,17 +1499,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- epilogue of this tile (the next tile's first two stages are in flight / resident meanwhile) ----
     [[maybe_unused]] const uint64_t kmb_t_epi = __builtin_amdgcn_s_memrealtime();
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int row0w = tm * BM4 + wm * WROWS, col0w = tn * BNT + wn * 128;
+    const int row0w = tm * BM4 + wm * WROWS, col0w = tn * BNT + wn * WCOLS;
     if (row0w < p.M && col0w < p.N) {
-      const bool interior = (row0w + WROWS <= p.M) && (col0w + 128 <= p.N);
+      const bool interior = (row0w + WROWS <= p.M) && (col0w + WCOLS <= p.N);
       const bool hb = p.bias != nullptr, hr = p.residual != nullptr, hd = p.drop_thr16 != 0u, hc = p.colsum != nullptr;
       const bool hs = col0w < p.col_scale_n;   // wave-uniform when col_scale_n is a multiple of 128 (checked below)
       const bool lean_ok = interior && p.out_bf16 != nullptr && p.out_f32 == nullptr && (p.tile_order & 256) == 0 &&
-                           (p.col_scale_n <= 0 || (p.col_scale_n & 127) == 0);
-#define KMB_LEAN(B, S, A, R, D, C) v11_epilogue_lean<B, S, A, R, D, C, WROWS>(p, acc, ef, lane, r, g, row0w, col0w)
+                           (p.col_scale_n <= 0 || (p.col_scale_n % WCOLS) == 0);
+#define KMB_LEAN(B, S, A, R, D, C) v11_epilogue_lean<B, S, A, R, D, C, WROWS, false, NJ>(p, acc, ef, lane, r, g, row0w, col0w)
       if (interior && p.out_f32 != nullptr && p.out_bf16 == nullptr && p.beta == 0.f && (p.ld_out_f32 & 3) == 0 &&
           (p.tile_order & 256) == 0 && p.act == 0 && hb && !hr && !hd && !hc && p.col_scale_n <= 0) {
-        v11_epilogue_lean<true, false, 0, false, false, false, WROWS, true>(p, acc, ef, lane, r, g, row0w, col0w);   // logits
+        v11_epilogue_lean<true, false, 0, false, false, false, WROWS, true, NJ>(p, acc, ef, lane, r, g, row0w, col0w);   // logits
       } else if (lean_ok && p.act == 0 && hb && !hr && !hd && !hc) {
         if (hs) KMB_LEAN(true, true, 0, false, false, false);
         else KMB_LEAN(true, false, 0, false, false, false);
@@ -1501,7 +1524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       } else if (lean_ok && p.act == 2 && !hb && !hr && !hd && hc && !hs) {
         KMB_LEAN(false, false, 2, false, false, true);
       } else {
-        v11_epilogue<-1, true, true, false, WROWS>(p, acc, ef, lane, r, g, row0w, col0w);   // edges and rare classes
+        v11_epilogue<-1, true, true, false, WROWS, NJ>(p, acc, ef, lane, r, g, row0w, col0w);   // edges and rare classes
       }
 #undef KMB_LEAN
     }
@@ -1744,7 +1767,7 @@ uint32_t* v11_sched_slot() {
 }
 
 // variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256;
-// 11 / 12: persistent 256x256 / 256x128
+// 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   if (variant == 11) {
@@ -1759,6 +1782,12 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
     else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
+  } else if (variant == 13) {
+    dim3 grid(v11_grid(p, 192)), block(256);
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
   } else if (variant == 8) {
     const int tiles = ((p.M + BM4 - 1) / BM4) * ((p.N + BN4 - 1) / BN4);
     dim3 grid(tiles * nsl), block(512);
@@ -1844,6 +1873,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS12);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS12);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS12);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
   }
   const bool dma_ok = (p.K % BK) == 0;           // LDS-DMA variants have no K-edge zero fill
   const bool big = dma_ok && p.M > 128;
@@ -1868,8 +1900,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     int v = forced;
     if (v == 11 && !v11_ok(p)) v = 8;
     if (v == 12 && !v11_ok(p, 128)) v = 8;
+    if (v == 13 && !v11_ok(p, 192)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
-    if (v != 1 && v != 7 && v != 8 && v != 11 && v != 12) v = 7;
+    if (v != 1 && v != 7 && v != 8 && v != 11 && v != 12 && v != 13) v = 7;
     return launch_variant(v, p, stream);
   }
   if (!big || p.N <= 128) return launch_variant(7, p, stream);
@@ -1877,7 +1910,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
-    const int cands[8] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16};   // variant | (tile_order << 4)
+    const int cands[10] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16};   // variant | (tile_order << 4)
     float best_ms = 1e30f;
     int best = 7;
     hipEvent_t e0, e1;
@@ -1885,6 +1918,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     for (int c : cands) {
       if ((c & 15) == 11 && !v11_ok(p)) continue;
       if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
+      if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;
       hipError_t e = launch_variant(c & 15, q, stream);  // warm

@@ -76,6 +76,9 @@ hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, 
 hipError_t kmb_ce_launch(const float* logits, int ldv, int V, const int64_t* labels, int rows,
                          const int32_t* count, float grad_scale, float* loss_rows, bf16_t* dlogits,
                          hipStream_t stream);
+// the same on bf16 logits (ldv <= 65536), dlogits may alias logits (in place)
+hipError_t kmb_ce_bf16_launch(const bf16_t* logits, int ldv, int V, const int64_t* labels, int rows, const int32_t* count,
+                              float grad_scale, float* loss_rows, bf16_t* dlogits, hipStream_t stream);
 // loss[0] = sum(loss_rows) / count
 hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
                                   hipStream_t stream);

@@ -1,4 +1,4 @@
-"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128) against the 128x128 variant 7 on every epilogue class and operand layout:
+"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128, 13: 256x192) against the 128x128 variant 7 on every epilogue class and operand layout:
 outputs must be bit-identical (same per-element accumulation order), column sums equal after folding their partial
 rows.  Also prints the time of each variant per case.  Re-runs itself once per variant (the variant is a per-process
 environment choice).
@@ -32,6 +32,14 @@ CASES = [
     ("tiles192", 16384, 768, 768, True, True, dict(bias=True, residual=True, drop=0.1)),   # fewer tiles than CUs
     ("tiles200_edges", 12800, 1000, 256, True, False, dict(residual=True)),               # 50 x 4 = 200 tiles, edge columns
     ("tiles147", 12500, 768, 320, True, True, dict(bias=True)),                           # 49 x 3 = 147 tiles -> grid 144
+    # the N = 768 shapes the 256x192 tile exists for (4 column tiles: 256 / 512 tiles at M = 16384 / 32768)
+    ("n768_fc2_fwd", 16384, 768, 3072, True, True, dict(bias=True, residual=True, drop=0.1)),
+    ("n768_fc1_dgrad", 16384, 768, 3072, True, False, dict(residual=True)),
+    ("n768_qkv_dgrad", 32768, 768, 2304, True, False, dict(residual=True)),
+    ("n768_out_fwd", 32768, 768, 768, True, True, dict(bias=True, residual=True, drop=0.1)),
+    ("n768_out_dgrad", 16384, 768, 768, True, False, dict()),
+    ("n2304_qkv_fwd", 16384, 2304, 768, True, True, dict(bias=True, qscale=True)),
+    ("n192_edges", 16300, 1000, 320, True, False, dict(colsum=True)),                     # 64 x 6 tiles of 192, edge rows + columns
 ]
 
 
@@ -102,12 +110,15 @@ def run_variant():
     print("JSON" + json.dumps(out))
 
 
+VARIANTS = ("7", "8", "11", "12", "13", "11o1", "12o1", "13o1", "11s", "12o1s", "13s")
+
+
 def main():
     if os.environ.get("KMB_V11_CHILD"):
         return run_variant()
     res = {}
     # o1: tile_order bit 0 = per-XCD contiguous tile ranges; s: shared-device mode (every tile from the atomic counter)
-    for v in ("7", "8", "11", "12", "11o1", "12o1", "11s", "12o1s"):
+    for v in VARIANTS:
         env = dict(os.environ, KMB_GEMM_VARIANT=v.rstrip("s").split("o")[0], KMB_V11_CHILD="1",
                    KMB_TILE_ORDER="1" if "o" in v else "0", KMB_V11_SHARED="1" if v.endswith("s") else "0")
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
@@ -120,7 +131,7 @@ def main():
     for name, *_ in CASES:
         a, c = res["7"][name], res["8"][name]
         line = f"{name:20s} v7 {a['us']:7.1f} us {a['tflops']:5.0f} TF | v8 {c['us']:7.1f} us {c['tflops']:5.0f} TF"
-        for v in ("8", "11", "12", "11o1", "12o1", "11s", "12o1s"):
+        for v in VARIANTS[1:]:
             b = res[v][name]
             ok = all(a[k] == b[k] for k in a if k not in ("us", "tflops", "colsum"))
             d = 0.0
