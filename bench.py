@@ -102,6 +102,88 @@ def loss_parity(model, dev):
     return abs(float(got) - float(ref)) / abs(float(ref)), float(got), float(ref)
 
 
+def timed_steps(step, n_warm, n_steps):
+    for _ in range(n_warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_steps
+
+
+def fine_tune_leg(model, opt, dev, batch_size, n_steps=12):
+    """The drop-in API path (reference src/training.py:96-171 as vcg_train.py drives it): `src.training.fine_tune`
+    over pinned HOST batches behind kmbart.data.DevicePrefetcher -- model.forward -> loss.backward() through autograd
+    -> optimizer.step(), per-step loss read (deferred by one step), nothing skipped.  Returns tokens/s."""
+    import types
+    from kmbart.data import DevicePrefetcher, PackedFeatures
+    from src.data.synthetic import make_batch
+    from src.training import fine_tune
+    host = []
+    for i in range(3):
+        hb = make_batch(batch_size, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=199 + i)
+        hb["image_features"] = PackedFeatures.from_list(hb["image_features"], 2052, pin=True)
+        host.append({k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in hb.items()})
+
+    class Loader:
+        def __init__(self, n):
+            self.n = n
+
+        def __iter__(self):
+            return (host[i % len(host)] for i in range(self.n))
+
+        def __len__(self):
+            return self.n
+
+    args = types.SimpleNamespace(amp=False, epochs=1)
+    fine_tune(0, model, DevicePrefetcher(Loader(4), dev), opt, dev, args)      # warm-up epoch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fine_tune(0, model, DevicePrefetcher(Loader(n_steps), dev), opt, dev, args)
+    torch.cuda.synchronize()
+    return batch_size * (S_ENC + T_DEC) * n_steps / (time.perf_counter() - t0)
+
+
+def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
+    """BASELINE config 5: beam-5 KV-cached generation (reference vcg_generate.py -> src/generation.py:22-32) on a
+    FRESH random-init vcg_base (the training legs teach the benchmark model to emit </s> at once -- it is the most
+    frequent target of the synthetic batches -- which would end every search after one step).  A decode step is
+    HBM-bound: the decoder's bf16 weights + the tied head are read once per step whatever the batch, plus the logits
+    and the K/V caches; `hbm_frac` = those bytes / measured step time / 6.3 TB/s achievable."""
+    from src.data.synthetic import make_batch
+    from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration
+    torch.manual_seed(0)
+    model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(VCG_BASE)).to(dev).eval()
+    b = make_batch(batch, seed=4321)
+    kw = dict(input_ids=b["input_ids"].to(dev), image_features=[f.to(dev) for f in b["image_features"]],
+              attention_mask=b["attention_mask"].to(dev), num_beams=beams, num_return_sequences=1,
+              max_length=max_length, early_stopping=True)
+    out = model.generate(**kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = model.generate(**kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    steps = out.shape[1] - 1
+    d, L, F, V = VCG_BASE["d_model"], VCG_BASE["decoder_layers"], VCG_BASE["decoder_ffn_dim"], VCG_BASE["vocab_size"]
+    R = batch * beams
+    weights = 2 * (L * (6 * d * d + 2 * d * F) + V * d)                    # bf16: self q/k/v/o, cross q/o, FFN, tied head
+    logits = R * ((V + 127) // 128 * 128) * model._engine.gen_logits_bytes * 2   # written by the head GEMM, read by the top-k
+    del model
+    self_kv = 2 * L * R * (steps / 2.0) * d * 2                             # average cache length
+    cross_kv = 2 * L * batch * S_ENC * d * 2                                # per batch item, shared by its beams
+    per_step = weights + logits + self_kv + cross_kv
+    return {"metric": "generate_sequences_per_sec", "value": round(batch / dt, 1), "unit": "sequences/s",
+            "ms_per_generate": round(dt * 1e3, 2), "decoder_steps": int(steps),
+            "us_per_decoder_step": round(dt / steps * 1e6, 1),
+            "hbm_bytes_per_step": int(per_step), "hbm_frac": round(per_step / (dt / steps) / 6.3e12, 4),
+            "config": {"workload": "vcg_base generate, beam search, KV cache", "batch": batch, "num_beams": beams,
+                       "max_length": max_length}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +196,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-batch (PCIe-inclusive) side measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the fine_tune (API path), batch-sweep and generation legs")
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: weight-gradient GEMMs on the main stream (no overlap), so a rocprofv3 "
                          "kernel trace shows every kernel's stand-alone duration; not the product configuration")
@@ -247,6 +331,29 @@ def main():
         torch.cuda.synchronize()
         out["pcie_inclusive_tokens_per_sec"] = round(args.batch * (S_ENC + T_DEC) * (n_host - 2) / (time.perf_counter() - th), 1)
 
+    if rank == 0 and args.gpus == 1 and not args.no_extras:
+        # (1) the drop-in API path: src.training.fine_tune over host batches (autograd loss.backward, optimizer.step)
+        out["fine_tune_tokens_per_sec"] = round(fine_tune_leg(model, opt, dev, args.batch), 1)
+        out["fine_tune_over_value"] = round(out["fine_tune_tokens_per_sec"] / value, 4)
+        # (2) other per-GPU batch sizes (the reference's default is 64, vcg_train.py:330); same step as `value`
+        sweep = {}
+        for bsz in (64, 256):
+            if bsz == args.batch:
+                continue
+            sb = make_batch(bsz, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=77)
+            sbatch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sb.items()}
+            sbatch["image_features"] = list(torch.cat([f.to(dev) for f in sb["image_features"]], 0).split(REGIONS))
+
+            def sstep():
+                model.train_step_fwd_bwd(sbatch)
+                opt.step()
+            sdt = timed_steps(sstep, 4, 10)
+            sweep[str(bsz)] = {"tokens_per_sec": round(bsz * (S_ENC + T_DEC) / sdt, 1), "ms_per_step": round(sdt * 1e3, 3)}
+        sweep[str(args.batch)] = {"tokens_per_sec": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 3)}
+        out["batch_sweep"] = sweep
+        # (3) BASELINE config 5: generation
+        out["generation"] = generation_leg(dev)
+
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the bf16 MFMA GEMM: time every launch of a few steps with HIP events on its stream
         lib = _lib.load()
@@ -297,7 +404,7 @@ def main():
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per GEMM launch",
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_n, 1)),
-            "kernel": "gemm_kernel_v7 / v8 / v11<A_KC,B_KC[,256|128]> (all GEMM launches of a step, timed serially)",
+            "kernel": "gemm_kernel_v7 / v8 / v11<A_KC,B_KC,256|128|192> (all GEMM launches of a step, timed serially)",
             "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
             "gemm_ms_per_step": round(tot_ms / n_prof, 3),
             "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),

@@ -11,6 +11,7 @@
 //           saved log-sum-exp; dK/dV live in registers across the inner loop, dQ in LDS (fp32).
 // One LDS image per tile serves both MFMA operand shapes: row reads (ds_read_b128) and
 // transposed reads (ds_read_b64_tr_b16); the XOR swizzle below makes both conflict-free.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -340,6 +341,184 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
   }
 }
 
+// ------------------------------------------ backward, single-tile shapes (Tq <= 64 and Tk <= 64: every training shape)
+// The general kernel above is latency-bound there: one (batch, head) item per workgroup, load -> barrier -> compute ->
+// store with two workgroups per CU and nothing in flight while the MFMAs run (124 us for 6144 items = 40 % of the HBM
+// rate).  Here a workgroup is PERSISTENT over items and software-pipelined: the global loads of item i+1 (Q, dO, K, V,
+// O: ten 16-byte chunks per thread, in registers) are issued before item i is computed and written to LDS after it,
+// so the HBM latency hides under the MFMA / softmax-gradient work; with one key tile the dQ accumulator in LDS (16 KB)
+// and its read-modify-write pass are gone -- dQ leaves from registers as transposed MFMA tiles (8-byte stores), like
+// dK / dV; delta = rowsum(dO * O) comes from the staged registers (no second global read of dO).
+// Same arithmetic as attn_bwd_kernel up to the summation order of delta and of the column sums (fp32, last bit).
+struct BwdRegs { u32x4 q[2], d[2], k[2], v[2], o[2]; };
+
+__device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int tid, BwdRegs& x) {
+  const int b = item / p.H, h = item % p.H;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id >> 3, c = id & 7;
+    const int tq = row < p.Tq ? row : p.Tq - 1, tk = row < p.Tk ? row : p.Tk - 1;
+    const size_t rq = (size_t)b * p.Tq + tq, rk = (size_t)b * p.Tk + tk;
+    x.q[i] = *reinterpret_cast<const u32x4*>(p.Q + rq * p.ldq + h * HD + c * 8);
+    x.d[i] = *reinterpret_cast<const u32x4*>(p.dO + rq * p.lddo + h * HD + c * 8);
+    x.o[i] = *reinterpret_cast<const u32x4*>(p.O + rq * p.ldo + h * HD + c * 8);
+    x.k[i] = *reinterpret_cast<const u32x4*>(p.K + rk * p.ldk + h * HD + c * 8);
+    x.v[i] = *reinterpret_cast<const u32x4*>(p.V + rk * p.ldv + h * HD + c * 8);
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = smem + TILE_BYTES;
+  char* Ks = smem + 2 * TILE_BYTES;
+  char* Vs = smem + 3 * TILE_BYTES;
+  char* Ps = smem + 4 * TILE_BYTES;
+  char* dSs = smem + 5 * TILE_BYTES;
+  float* lse_s = reinterpret_cast<float*>(smem + 6 * TILE_BYTES);
+  float* del_s = lse_s + 64;
+  float* colq = del_s + 64;    // [4 waves][64] column sums of dQ / dK / dV over each wave's rows (bias-gradient partials)
+  float* colk = colq + 256;
+  float* colv = colk + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int nitems = p.B * p.H;
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+  auto row16_sum = [](float v) {   // inclusive prefix sums by row_shr 1, 2, 4, 8 (zeros shifted in): lane 15 = total
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+    return v;
+  };
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  BwdRegs x;
+  bwd_load_item(p, item, tid, x);
+  for (; item < nitems; item += gridDim.x) {
+    const int b = item / p.H, h = item % p.H;
+    __syncthreads();   // everyone is done with the previous item's LDS images
+    // ---- staged registers -> LDS; delta = rowsum(dO * O) from the same registers ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i;
+      const int row = id >> 3, c = id & 7;
+      *reinterpret_cast<u32x4*>(Qs + tile_off(row, c)) = x.q[i];
+      *reinterpret_cast<u32x4*>(dOs + tile_off(row, c)) = x.d[i];
+      *reinterpret_cast<u32x4*>(Ks + tile_off(row, c)) = x.k[i];
+      *reinterpret_cast<u32x4*>(Vs + tile_off(row, c)) = x.v[i];
+      float a8[8], b8[8];
+      unpack8(x.o[i], a8);
+      unpack8(x.d[i], b8);
+      float acc = 0.f;   // this thread's 8 columns, then a tree over the row's eight chunk-lanes
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += a8[e] * b8[e];
+      acc += __shfl_xor(acc, 4, 64);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (c == 0) {
+        del_s[row] = acc;
+        const int q = row < p.Tq ? row : p.Tq - 1;
+        lse_s[row] = p.lse[((size_t)b * p.H + h) * p.Tq + q];
+      }
+    }
+    __syncthreads();
+    // ---- next item's loads go out now and land while this item is computed ----
+    const int nxt = item + (int)gridDim.x;
+    if (nxt < nitems) bwd_load_item(p, nxt, tid, x);
+    // ---- S = Q K^T and dP = dO V^T for this wave's 16 query rows x 64 keys ----
+    f32x4 s4[4], dp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s4[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 qf = frag_rows(Qs, wave, kk, r, g);
+      const bf16x8 df = frag_rows(dOs, wave, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, frag_rows(Ks, j, kk, r, g), s4[j], 0, 0, 0);
+        dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, frag_rows(Vs, j, kk, r, g), dp[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = j * 16 + r;
+      bool kv = key < p.Tk;
+      if (kv && p.key_mask != nullptr) kv = p.key_mask[(size_t)b * p.Tk + key] != 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int lrow = wave * 16 + g * 4 + q;
+        const bool ok = kv && lrow < p.Tq && (!p.causal || key <= lrow);
+        const float lse = lse_s[lrow];
+        const float pv = (ok && lse != -INFINITY) ? __expf(s4[j][q] - lse) : 0.f;
+        const float ds = pv * (dp[j][q] - del_s[lrow]);
+        *reinterpret_cast<bf16_t*>(Ps + elem_off(lrow, j * 16 + r)) = f2bf(pv);
+        *reinterpret_cast<bf16_t*>(dSs + elem_off(lrow, j * 16 + r)) = f2bf(ds);
+      }
+    }
+    __syncthreads();
+    // ---- dQ^T, dV^T, dK^T tiles: lane (r, g) holds row r of this wave's 16 and the columns 16 j + 4 g .. + 3 ----
+    f32x4 dq[4], dk[4], dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 dsf = frag_rows(dSs, wave, kk, r, g);
+      const bf16x8 ptf = frag_cols(Ps, wave, kk, r, g);
+      const bf16x8 dstf = frag_cols(dSs, wave, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, j, kk, r, g), dsf, dq[j], 0, 0, 0);
+        dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dOs, j, kk, r, g), ptf, dv[j], 0, 0, 0);
+        dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, j, kk, r, g), dstf, dk[j], 0, 0, 0);
+      }
+    }
+    const int row = wave * 16 + r;   // query row of dQ, key row of dK / dV
+    const bool q_ok = row < p.Tq, k_ok = row < p.Tk;
+    if (p.dk_colsum != nullptr) {   // uniform branch
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float sq = row16_sum(q_ok ? dq[j][q] * p.dq_scale : 0.f);
+          const float sk = row16_sum(k_ok ? dk[j][q] : 0.f);
+          const float sv = row16_sum(k_ok ? dv[j][q] : 0.f);
+          if (r == 15) {
+            colq[wave * 64 + j * 16 + g * 4 + q] = sq;
+            colk[wave * 64 + j * 16 + g * 4 + q] = sk;
+            colv[wave * 64 + j * 16 + g * 4 + q] = sv;
+          }
+        }
+    }
+    if (q_ok) {
+      bf16_t* qr = p.dQ + ((size_t)b * p.Tq + row) * p.lddq + h * HD + g * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<u32x2*>(qr + j * 16) = u32x2{pack2bf(dq[j][0] * p.dq_scale, dq[j][1] * p.dq_scale),
+                                                       pack2bf(dq[j][2] * p.dq_scale, dq[j][3] * p.dq_scale)};
+    }
+    if (k_ok) {
+      bf16_t* kr = p.dK + ((size_t)b * p.Tk + row) * p.lddk + h * HD + g * 4;
+      bf16_t* vr = p.dV + ((size_t)b * p.Tk + row) * p.lddv + h * HD + g * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<u32x2*>(kr + j * 16) = u32x2{pack2bf(dk[j][0], dk[j][1]), pack2bf(dk[j][2], dk[j][3])};
+        *reinterpret_cast<u32x2*>(vr + j * 16) = u32x2{pack2bf(dv[j][0], dv[j][1]), pack2bf(dv[j][2], dv[j][3])};
+      }
+    }
+    if (p.dk_colsum != nullptr) {
+      __syncthreads();
+      if (tid < 64) {
+        const size_t o = (size_t)b * p.ld_colsum + h * HD + tid;
+        if (p.dq_colsum != nullptr) p.dq_colsum[o] = (colq[tid] + colq[64 + tid]) + (colq[128 + tid] + colq[192 + tid]);
+        p.dk_colsum[o] = (colk[tid] + colk[64 + tid]) + (colk[128 + tid] + colk[192 + tid]);
+        p.dv_colsum[o] = (colv[tid] + colv[64 + tid]) + (colv[128 + tid] + colv[192 + tid]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------- single-query decode step
 // one wave per (row, head): scores over the cached keys, softmax, weighted sum of cached values
 __global__ __launch_bounds__(256) void attn_decode_kernel(const KmbAttnDecode p) {
@@ -438,6 +617,20 @@ hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
 
 hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream) {
   const int nqt = (p.Tq + 63) / 64;
+  static const bool small_ok = !(getenv("KMB_ATTN_BWD_SMALL") && getenv("KMB_ATTN_BWD_SMALL")[0] == '0');
+  if (small_ok && p.Tq <= 64 && p.Tk <= 64) {   // one query tile, one key tile: the persistent, software-pipelined form
+    const size_t lds_s = 6 * TILE_BYTES + (128 + 768) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    const int items = p.B * p.H;
+    const int grid = items < 768 ? items : 768;   // three workgroups per CU (165 VGPRs, 52.6 KB of LDS each)
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(grid), dim3(256), lds_s, stream, p);
+    return hipGetLastError();
+  }
   const size_t lds = 6 * TILE_BYTES + (128 + 512) * sizeof(float) + (size_t)nqt * 64 * 64 * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {

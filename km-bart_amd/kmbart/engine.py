@@ -88,6 +88,7 @@ class Engine:
         self._keep = []  # tensors the in-flight kernels read
         self.step_count = 0
         self.fwd_serial = 0      # bumped by every call that rewrites the workspace (LazyLogits validity)
+        self.gen_logits_bytes = 4   # bytes per element of the decode step's logits buffer
         self.fp32_mode = False
 
     def __del__(self):
