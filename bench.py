@@ -246,6 +246,8 @@ def main():
     ddp.train()
     opt = AdamW(model.parameters(), lr=args.lr)
     opt.allow_overlap(True)   # train_step_fwd_bwd + step run back to back: nothing touches the gradients in between
+    if use_dist:
+        ddp.attach_optimizer(opt)   # each piece's AdamW right behind its all-reduce on the communication stream
 
     parity = None
     if rank == 0 and args.gpus == 1:

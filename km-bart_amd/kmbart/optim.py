@@ -50,6 +50,31 @@ class AdamW(torch.optim.Optimizer):
         if not self._overlap_locked:
             self.overlap = bool(on)
 
+    # ---- data-parallel fused tail (kmbart.parallel.DistributedDataParallel.attach_optimizer) -------------------------
+    def begin_fused_step(self, engine):
+        """Called by the data-parallel wrapper before it launches a step's all-reduces: True if this optimizer will
+        update each gradient piece right behind its all-reduce (one parameter group covering the whole engine arena,
+        overlap allowed, no gradient scaling)."""
+        if not (self.overlap and self.grad_scale == 1.0 and len(self.param_groups) == 1):
+            return False
+        params = self.param_groups[0]["params"]
+        # every parameter of this engine and nothing else: the pieces then tile the whole arena (alignment gaps between
+        # parameters hold zeros in all four arenas: their update is exactly zero)
+        if len(params) != len(engine.index) or any(getattr(q, "_kmb_engine", None) is not engine for q in params):
+            return False
+        engine.step_count += 1
+        self._fused_done = set()
+        return True
+
+    def fused_piece_step(self, engine, off, cnt):
+        g = self.param_groups[0]
+        engine.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], g["correct_bias"], 1.0, offset=off,
+                          count=cnt, bump=False)
+        self._fused_done.add(id(engine))
+
+    def end_fused_step(self, engine):
+        self._fused_pending = True
+
     def _engines(self):
         engines = {}
         for g in self.param_groups:
@@ -60,6 +85,11 @@ class AdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        if getattr(self, "_fused_pending", False):
+            # the data-parallel wrapper already enqueued every piece's update behind its all-reduce and made the compute
+            # stream wait for the communication stream (BucketedAllReducer.finish)
+            self._fused_pending = False
+            return loss
         all_ranges = [self._engine_ranges(group) for group in self.param_groups]
         # ONE bias-correction step per optimizer.step(), whatever the number of parameter groups
         for e in self._engines():

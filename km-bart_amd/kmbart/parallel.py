@@ -12,6 +12,16 @@ projection, tied matrix).  kmb_backward records an event per bucket on the compu
 reducer makes the communication stream wait on that event and issues the bucket's all-reduce, so
 the collectives run while the rest of backward is still computing.  `find_unused_parameters` is
 not needed: every gradient is written every step (no per-step bitmap collective).
+
+The optimizer tail.  With `attach_optimizer(opt)` (training loops that run `loss.backward()` and `opt.step()` back to
+back: src.training.fine_tune / pretrain, bench.py) each piece's fused AdamW is enqueued on the COMMUNICATION stream
+right behind that piece's all-reduce, so the HBM-bound update of a bucket runs while later buckets are still being
+reduced and while backward is still computing; `opt.step()` then only makes the compute stream wait for the
+communication stream.  The tied matrix (154 MB, complete last) travels in <= 64 MB pieces, each followed by its own
+update, so the un-overlapped tail is one piece, not 564 MB of all-reduce plus a 1.1 ms optimizer launch.
+`grad_dtype="bf16"` halves the bytes on the wire (282 MB): a piece is cast into a bf16 staging buffer, reduced, and
+cast back (fp32 accumulation inside the optimizer is unchanged); off by default -- xGMI has the bandwidth at the
+benchmark batch, SURVEY.md section 5 prices when it does not.
 """
 import torch
 import torch.distributed as dist
@@ -25,8 +35,10 @@ class BucketedAllReducer:
     """
 
     def __init__(self, flat, buckets, process_group=None, wait_ready=None, comm_stream=None, max_bucket_elems=None,
-                 always=False):
+                 always=False, grad_dtype=None, after_piece=None):
         self.flat = flat
+        self.grad_dtype = grad_dtype     # None: reduce the fp32 slices in place; torch.bfloat16: staged bf16 pieces
+        self.after_piece = after_piece   # callable(offset, count) run on the communication stream behind each piece
         self.always = always   # issue the collectives even in a one-rank group (single-GPU test of the RCCL path)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -38,7 +50,7 @@ class BucketedAllReducer:
         for i, (off, cnt) in enumerate(buckets):
             if max_bucket_elems and cnt > max_bucket_elems:
                 n = (cnt + max_bucket_elems - 1) // max_bucket_elems
-                step = (cnt + n - 1) // n
+                step = ((cnt + n - 1) // n + 63) // 64 * 64   # piece boundaries stay 64-element aligned (fused AdamW)
                 for s in range(0, cnt, step):
                     self.pieces.append((i, off + s, min(step, cnt - s)))
             else:
@@ -62,17 +74,37 @@ class BucketedAllReducer:
                     self.wait_ready(i, stream)
                     waited.add(i)
                 piece = self.flat[off: off + cnt]
-                w = dist.all_reduce(piece, op=op, group=self.group, async_op=True)
-                self._works.append((w, piece, use_avg))
+                if self.grad_dtype is not None and self.grad_dtype != piece.dtype:
+                    staged = piece.to(self.grad_dtype)
+                    w = dist.all_reduce(staged, op=op, group=self.group, async_op=True)
+                    self._works.append((w, piece, use_avg, staged, off, cnt))
+                else:
+                    w = dist.all_reduce(piece, op=op, group=self.group, async_op=True)
+                    self._works.append((w, piece, use_avg, None, off, cnt))
+                if use_avg and self.after_piece is not None:
+                    # RCCL work is stream-ordered: wait() only orders this stream behind the collective
+                    self._complete(self._works.pop())
+
+    def _complete(self, item):
+        w, piece, use_avg, staged, off, cnt = item
+        w.wait()
+        if staged is not None:
+            piece.copy_(staged)
+        if not use_avg:
+            piece.div_(self.world)
+        if self.after_piece is not None:
+            self.after_piece(off, cnt)
 
     def finish(self):
-        """Makes the current stream (GPU) or the host (CPU) wait for every outstanding all-reduce."""
-        for w, piece, use_avg in self._works:
-            w.wait()
-            if not use_avg:
-                piece.div_(self.world)
+        """Makes the current stream (GPU) or the host (CPU) wait for every outstanding all-reduce (and for the
+        per-piece work chained behind them)."""
+        on_gpu = self.flat.is_cuda and self.comm_stream is not None
+        ctx = torch.cuda.stream(self.comm_stream) if on_gpu else _Null()
+        with ctx:
+            for item in self._works:
+                self._complete(item)
         self._works = []
-        if self.flat.is_cuda and self.comm_stream is not None:
+        if on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
@@ -86,7 +118,7 @@ class _Null:
 
 class DistributedDataParallel(torch.nn.Module):
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None,
-                 max_bucket_mb=64, reduce_single_rank=False):
+                 max_bucket_mb=64, reduce_single_rank=False, grad_dtype=None):
         super().__init__()
         self.__dict__["module"] = module  # not a registered child: parameters() must not be re-wrapped
         eng = module._need_engine()
@@ -99,16 +131,36 @@ class DistributedDataParallel(torch.nn.Module):
             dist.broadcast(eng.final_logits_bias, src=0, group=process_group)
             eng.sync_params()
             comm = torch.cuda.Stream(device=eng.device)
+            if grad_dtype in ("bf16", "bfloat16"):
+                grad_dtype = torch.bfloat16
             self.reducer = BucketedAllReducer(
                 eng.grads, eng.buckets(), process_group,
                 wait_ready=lambda i, stream: eng.stream_wait_bucket(i, stream), comm_stream=comm,
-                max_bucket_elems=max_bucket_mb * (1 << 20) // 4, always=reduce_single_rank)
+                max_bucket_elems=max_bucket_mb * (1 << 20) // 4, always=reduce_single_rank, grad_dtype=grad_dtype,
+                after_piece=self._step_piece)
+            self._opt = None          # attach_optimizer(): fused AdamW behind each piece's all-reduce
             module._post_backward = self._reduce
             # RCCL's kernel holds CUs while backward runs: the persistent GEMMs hand out every tile dynamically
             from . import _lib
             _lib.load().kmb_gemm_shared_device(1)
             self._first_reduce = True
+            self._fusing = False
             eng.adamw_overlap_ok = False   # gradients are final only after the all-reduce, not at the bucket events
+
+    def attach_optimizer(self, optimizer):
+        """Chains `optimizer`'s fused AdamW behind every gradient piece's all-reduce on the communication stream (module
+        docstring).  Only for loops that call `optimizer.step()` right after `loss.backward()` with nothing touching the
+        gradients in between: the parameters of a bucket are already updated when backward returns, `step()` becomes
+        the point where the compute stream waits for the communication stream."""
+        if self.reducer is None or not hasattr(optimizer, "fused_piece_step"):
+            return False
+        self._opt = optimizer
+        optimizer._ddp_fused = self
+        return True
+
+    def _step_piece(self, off, cnt):
+        if self._opt is not None and self._fusing:
+            self._opt.fused_piece_step(self.engine, off, cnt)
 
     def _reduce(self):
         if self._first_reduce:
@@ -116,8 +168,12 @@ class DistributedDataParallel(torch.nn.Module):
             self._first_reduce = False
             if self.reducer.comm_stream is not None:
                 self.reducer.comm_stream.wait_stream(torch.cuda.current_stream())
+        self._fusing = self._opt is not None and self._opt.begin_fused_step(self.engine)
         self.reducer.launch()
         self.reducer.finish()
+        if self._fusing:
+            self._opt.end_fused_step(self.engine)
+        self._fusing = False
 
     def forward(self, *args, **kwargs):
         return self.module.forward(*args, **kwargs)

@@ -23,6 +23,12 @@ def _allow_overlap(optimizer, ok):
         optimizer.allow_overlap(ok)
 
 
+def _attach(model, optimizer, ok):
+    """Data-parallel wrapper: chain each gradient piece's optimizer update behind its all-reduce (kmbart.parallel)."""
+    if ok and hasattr(model, "attach_optimizer"):
+        model.attach_optimizer(optimizer)
+
+
 def _features(feats, device):
     """list of per-sample tensors (reference collator) or a kmbart.data.PackedFeatures"""
     return feats.to(device) if hasattr(feats, "packed") else [f.to(device) for f in feats]
@@ -35,6 +41,7 @@ def fine_tune(epoch, model, train_loader, optimizer, device, args, logger=None, 
     t0 = datetime.now()
     use_amp = bool(getattr(args, "amp", False))
     _allow_overlap(optimizer, not (use_amp and scaler is not None))
+    _attach(model, optimizer, not (use_amp and scaler is not None))
     pending = None
     state = {"sum": 0.0}
 
@@ -97,6 +104,7 @@ def pretrain(epoch, model, train_loader, optimizer, device, args, logger=None, c
     t0 = datetime.now()
     use_amp = bool(getattr(args, "amp", False))
     _allow_overlap(optimizer, not (use_amp and scaler is not None))
+    _attach(model, optimizer, not (use_amp and scaler is not None))
     pending = None
     state = {"sum": 0.0}
 

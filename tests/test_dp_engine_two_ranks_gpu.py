@@ -76,15 +76,36 @@ def _worker(rank, world, port, out):
             same[off: off + rows * cols] = True      # tied matrix: fp32 atomics of the embedding scatter-add (last bit)
             results.append(bool(same.all()) and torch.allclose(got[off: off + rows * cols], mean[off: off + rows * cols],
                                                                rtol=1e-5, atol=1e-7))
-        # and the optimizer step on the reduced gradients keeps the replicas identical
+        # the fused tail: each piece's AdamW enqueued on the communication stream behind its all-reduce
+        # (DistributedDataParallel.attach_optimizer); the result must be ONE optimizer step on the mean gradients
+        ref_opt = AdamW(ref_model.parameters(), lr=1e-3)
+        ref_model._engine.grads.copy_(mean)
+        ref_opt.step()
         opt = AdamW(model.parameters(), lr=1e-3)
+        opt.allow_overlap(True)
+        fused = ddp.attach_optimizer(opt)
+        ddp.train_step_fwd_bwd(batches[rank])
+        stepped_inside = model._engine.step_count == 1
         opt.step()
         torch.cuda.synchronize()
+        off, rows, cols = model._engine.index["model.shared.weight"]
+        same = model._engine.params == ref_model._engine.params
+        same[off: off + rows * cols] = True
+        matches_ref = bool(same.all()) and torch.allclose(model._engine.params[off: off + rows * cols],
+                                                          ref_model._engine.params[off: off + rows * cols], rtol=0, atol=2e-6)
         mine = model._engine.params.detach().cpu()
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         # tied rows touched by the atomics may differ in the last bit between ranks -> allclose
-        in_sync = torch.allclose(gathered[0], gathered[1], rtol=0, atol=2e-6)
+        in_sync = fused and stepped_inside and model._engine.step_count == 1 and matches_ref and \
+            torch.allclose(gathered[0], gathered[1], rtol=0, atol=2e-6)
+        # bf16 gradient buckets (282 MB on the wire instead of 564): same mean within bf16 rounding
+        model2 = build(ocfg, G.golden_state_dict(ocfg, seed=7)).train()
+        ddp2 = DistributedDataParallel(model2, device_ids=[0], grad_dtype="bf16")
+        ddp2.train_step_fwd_bwd(batches[rank])
+        torch.cuda.synchronize()
+        g2 = model2._engine.grads
+        in_sync = in_sync and float((g2 - mean).norm() / mean.norm()) < 4e-3
         out[rank] = (ok, results, in_sync)
     finally:
         dist.destroy_process_group()

@@ -41,6 +41,9 @@ def test_single_rank_rccl_reducer_matches_plain_step():
             model = build(ocfg, sd).train()
             ddp = DistributedDataParallel(model, device_ids=[0], reduce_single_rank=True) if wrap else model
             opt = AdamW(model.parameters(), lr=1e-3)
+            opt.allow_overlap(True)
+            if wrap:   # the production tail: AdamW of every piece behind its all-reduce on the communication stream
+                assert ddp.attach_optimizer(opt)
             losses, grads = [], None
             for i in range(3):
                 losses.append(float(ddp.train_step_fwd_bwd(batch)))
@@ -52,10 +55,11 @@ def test_single_rank_rccl_reducer_matches_plain_step():
             if wrap:
                 assert ddp.reducer is not None and len(ddp.reducer.pieces) >= len(model._engine.buckets())
                 assert ddp.module is model
-            return losses, grads, model._engine
+            assert model._engine.step_count == 3
+            return losses, grads, model._engine, model._engine.params.clone()
 
-        plain_losses, plain_grads, eng = run(False)
-        rccl_losses, rccl_grads, _ = run(True)
+        plain_losses, plain_grads, eng, plain_params = run(False)
+        rccl_losses, rccl_grads, _, rccl_params = run(True)
         # AVG over one rank is the identity: every gradient slice comes back bit for bit -- except the tied embedding
         # matrix, whose token-gradient scatter uses fp32 atomics and differs run to run in the last bit either way
         off, rows, cols = eng.index["model.shared.weight"]
@@ -65,5 +69,10 @@ def test_single_rank_rccl_reducer_matches_plain_step():
         assert torch.allclose(plain_grads[off: off + rows * cols], rccl_grads[off: off + rows * cols], rtol=0, atol=1e-6)
         for a, b_ in zip(plain_losses, rccl_losses):
             assert abs(a - b_) <= 1e-4 * abs(a)
+        # three fused (all-reduce -> AdamW per piece) steps land on the same parameters as three plain steps
+        same = plain_params == rccl_params
+        same[off: off + rows * cols] = True
+        assert bool(same.all())
+        assert torch.allclose(plain_params[off: off + rows * cols], rccl_params[off: off + rows * cols], rtol=0, atol=1e-5)
     finally:
         dist.destroy_process_group()
