@@ -113,7 +113,7 @@ def timed_steps(step, n_warm, n_steps):
     return (time.perf_counter() - t0) / n_steps
 
 
-def fine_tune_leg(model, opt, dev, batch_size, n_steps=12):
+def fine_tune_leg(model, opt, dev, batch_size, n_steps=24):
     """The drop-in API path (reference src/training.py:96-171 as vcg_train.py drives it): `src.training.fine_tune`
     over pinned HOST batches behind kmbart.data.DevicePrefetcher -- model.forward -> loss.backward() through autograd
     -> optimizer.step(), per-step loss read (deferred by one step), nothing skipped.  Returns tokens/s."""
@@ -256,8 +256,10 @@ def main():
     b = make_batch(args.batch, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=1234 + rank)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
     batch["image_features"] = [f.to(dev) for f in b["image_features"]]
-    # packed once: the timed region starts with inputs resident in HBM (the list-of-tensors H2D + cat is row (f))
-    batch["image_features"] = list(torch.cat(batch["image_features"], 0).split(REGIONS))
+    # packed once: the timed region starts with inputs resident in HBM as ONE [Ntot, 2052] buffer + CSR offsets, the form
+    # the collator / DevicePrefetcher deliver (the list-of-tensors H2D + cat of the reference is row (f), not the step)
+    from kmbart.data import PackedFeatures
+    batch["image_features"] = PackedFeatures.from_list(b["image_features"], 2052).to(dev)
 
     def step():
         loss = ddp.train_step_fwd_bwd(batch)
@@ -344,7 +346,7 @@ def main():
                 continue
             sb = make_batch(bsz, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=77)
             sbatch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sb.items()}
-            sbatch["image_features"] = list(torch.cat([f.to(dev) for f in sb["image_features"]], 0).split(REGIONS))
+            sbatch["image_features"] = PackedFeatures.from_list(sb["image_features"], 2052).to(dev)
 
             def sstep():
                 model.train_step_fwd_bwd(sbatch)
@@ -391,12 +393,14 @@ def main():
             lib.kmb_profile_gemm(0)
         lib.kmb_set_side_stream(model._engine.h, 1)
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):   # HBM bytes come from rocprofv3 --pmc passes of this workload (tools/r2_profile.sh)
+        # HBM bytes come from rocprofv3 --pmc passes of this workload (tools/r2_profile.sh): the newest committed round
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             rec = json.load(open(pmc))
             if rec.get("per_gpu_batch") == args.batch:
                 traffic = rec["gemm_hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01_pmc_traffic.json: " + rec["method"]
+                traffic_src = "profiles/%s: %s" % (os.path.basename(pmc), rec["method"])
+                break
         tot_ms = sum(a[1] for a in agg.values())
         tot_fl = sum(a[2] for a in agg.values())
         launches = sum(a[0] for a in agg.values())

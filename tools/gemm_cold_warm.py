@@ -38,6 +38,25 @@ def timed(cold):
     return ts[len(ts) // 2]
 
 
+def timed_after_write():
+    """A is (re)written by an ordinary streaming kernel right before the launch, after a cache flush: is a freshly
+    WRITTEN operand served from the Infinity Cache?"""
+    A2 = A.clone()
+    ts = []
+    for _ in range(10):
+        junk.fill_(1)
+        A.copy_(A2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 w, c = timed(False), timed(True)
+print(f"  A just written by a plain-store kernel after the flush: {timed_after_write():.1f} us")
 fl = 2.0 * M * N * K
 print(f"{M}x{N}x{K} akc={int(akc)} bkc={int(bkc)}: warm {w:.1f} us ({fl / w * 1e-6:.0f} TF)  cold {c:.1f} us ({fl / c * 1e-6:.0f} TF)")
