@@ -62,9 +62,9 @@ typedef struct KmbGemm {
   int32_t M, N, K;
   const float* bias;
   float col_scale; int32_t col_scale_n;
-  int32_t act;
-  kmb_bf16* preact; int32_t ld_preact;
-  const kmb_bf16* aux; int32_t ld_aux;
+  int32_t act;                    /* 0 none, 1 GeLU (erf form), 2 multiply by aux (the stored GeLU'), 3 tanh, 4 multiply by 1 - aux^2 */
+  kmb_bf16* preact; int32_t ld_preact;   /* act 1, optional: receives GeLU'(pre-activation) -- what the backward pass needs */
+  const kmb_bf16* aux; int32_t ld_aux;   /* act 2: the tensor act 1 stored; act 4: tanh output */
   uint32_t drop_thr16; uint32_t drop_seed; float drop_scale;
   const kmb_bf16* residual; int32_t ld_res;
   kmb_bf16* out_bf16; int32_t ld_out_bf16;

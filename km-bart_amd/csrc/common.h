@@ -99,6 +99,15 @@ __device__ __forceinline__ kmb_f32x2 gelu2(kmb_f32x2 x) {
   gelu_parts2(x, cdf, e);
   return x * cdf;
 }
+// GeLU and its derivative from ONE evaluation of (cdf, e): the forward FFN epilogue stores the derivative (bf16) instead
+// of the pre-activation, so the backward epilogue of the fc2 data gradient is a single multiply -- the erf / exp work of
+// GeLU'(u) is done once, where cdf and e are already in registers, instead of a second time per element in backward.
+__device__ __forceinline__ void gelu_both2(kmb_f32x2 x, kmb_f32x2& y, kmb_f32x2& dy) {
+  kmb_f32x2 cdf, e;
+  gelu_parts2(x, cdf, e);
+  y = x * cdf;
+  dy = cdf + x * 0.39894228040143268f * e;
+}
 __device__ __forceinline__ kmb_f32x2 gelu_grad2(kmb_f32x2 x) {
   kmb_f32x2 cdf, e;
   gelu_parts2(x, cdf, e);

@@ -56,8 +56,10 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(KmbGemm p) {
     if (gm >= p.M) continue;
     float v = (acc[reg] + bias) * scale;   // (x W^T + b) * scale: the reference's order for q
     if (p.act == 1) {
-      if (p.preact != nullptr) reinterpret_cast<float*>(p.preact)[(size_t)gm * p.ld_preact + gn] = v;
-      v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+      const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+      if (p.preact != nullptr)   // GeLU'(v), the tensor the bf16 path stores for backward
+        reinterpret_cast<float*>(p.preact)[(size_t)gm * p.ld_preact + gn] = cdf + v * 0.39894228040143268f * expf(-0.5f * v * v);
+      v = v * cdf;
     } else if (p.act == 3) {
       v = tanhf(v);
     }

@@ -236,17 +236,26 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * scale8[e];
     if (act == 1) {
-      if (p.preact != nullptr) {
-        if (full8) {
-          *reinterpret_cast<u32x4*>(p.preact + (size_t)grow * p.ld_preact + gcol) = pack8(v);
-        } else {
-          for (int e = 0; e < nvalid; ++e) p.preact[(size_t)grow * p.ld_preact + gcol + e] = f2bf(v[e]);
-        }
-      }
+      if (p.preact != nullptr) {   // GeLU and GeLU' from one evaluation; the DERIVATIVE is what backward needs (act 2)
+        float dv[8];
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const kmb_f32x2 y = gelu2(kmb_f32x2{v[e], v[e + 1]});
-        v[e] = y[0]; v[e + 1] = y[1];
+        for (int e = 0; e < 8; e += 2) {
+          kmb_f32x2 y, dy;
+          gelu_both2(kmb_f32x2{v[e], v[e + 1]}, y, dy);
+          v[e] = y[0]; v[e + 1] = y[1];
+          dv[e] = dy[0]; dv[e + 1] = dy[1];
+        }
+        if (full8) {
+          *reinterpret_cast<u32x4*>(p.preact + (size_t)grow * p.ld_preact + gcol) = pack8(dv);
+        } else {
+          for (int e = 0; e < nvalid; ++e) p.preact[(size_t)grow * p.ld_preact + gcol + e] = f2bf(dv[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const kmb_f32x2 y = gelu2(kmb_f32x2{v[e], v[e + 1]});
+          v[e] = y[0]; v[e + 1] = y[1];
+        }
       }
     } else if (AUX && (act == 2 || act == 4)) {
       float u[8];
@@ -255,12 +264,9 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
       } else {
         for (int e = 0; e < 8; ++e) u[e] = e < nvalid ? bf2f(p.aux[(size_t)grow * p.ld_aux + gcol + e]) : 0.f;
       }
-      if (act == 2) {
+      if (act == 2) {   // aux = GeLU'(pre-activation), stored by the forward epilogue (act 1 with preact)
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const kmb_f32x2 d = gelu_grad2(kmb_f32x2{u[e], u[e + 1]});
-          v[e] *= d[0]; v[e + 1] *= d[1];
-        }
+        for (int e = 0; e < 8; ++e) v[e] *= u[e];
       } else {  // tanh'(.) = 1 - y^2, aux = y
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= (1.f - u[e] * u[e]);
@@ -1104,17 +1110,25 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
       }
       const size_t roff = (size_t)(16 * i + 4 * it);
       if (ACT == 1) {
-        if (pre != nullptr) {
-          const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
-          KMB_NT_STORE(pk, reinterpret_cast<u32x4*>(pre + roff * p.ld_preact));
-        }
+        if (pre != nullptr) {   // GeLU and GeLU' from one evaluation; the derivative is stored for backward (ACT 2)
+          kmb_f32x2 dv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu2(v[e]);
+          for (int e = 0; e < 4; ++e) {
+            kmb_f32x2 y;
+            gelu_both2(v[e], y, dv[e]);
+            v[e] = y;
+          }
+          const u32x4 pk = {pack2bf(dv[0][0], dv[0][1]), pack2bf(dv[1][0], dv[1][1]), pack2bf(dv[2][0], dv[2][1]), pack2bf(dv[3][0], dv[3][1])};
+          KMB_NT_STORE(pk, reinterpret_cast<u32x4*>(pre + roff * p.ld_preact));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu2(v[e]);
+        }
       } else if (ACT == 2) {
         float u[8];
         unpack8(s0[it], u);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_grad2(kmb_f32x2{u[2 * e], u[2 * e + 1]});
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * kmb_f32x2{u[2 * e], u[2 * e + 1]};
       }
       if (DROP) {
         const uint32_t grow = (uint32_t)(row0w + lr + 16 * i + 4 * it);

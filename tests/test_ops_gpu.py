@@ -89,10 +89,11 @@ def test_gemm_epilogue_column_sums(M, N, K):
     u = bf(rnd(M, N, seed=19))
     out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     parts = torch.full(((M + 63) // 64, N), 5.0, dtype=torch.float32, device=DEV)
-    gemm(A, B, a_kc=True, b_kc=False, act=2, aux=u, out_bf16=out, colsum=parts)
     uu = u.float().requires_grad_(True)
     F.gelu(uu).sum().backward()
-    ref = (A.float() @ B.float()) * uu.grad
+    dg = bf(uu.grad)                      # act 2 multiplies by the STORED derivative (what the forward epilogue wrote)
+    gemm(A, B, a_kc=True, b_kc=False, act=2, aux=dg, out_bf16=out, colsum=parts)
+    ref = (A.float() @ B.float()) * dg.float()
     assert rel_err(out, ref) < BF_TOL
     assert rel_err(parts.sum(0), ref.sum(0)) < 1e-3
 
@@ -117,17 +118,19 @@ def test_gemm_epilogues():
     ref = base.clone()
     ref[:, :64] *= 0.125
     assert rel_err(out, ref) < F32_TOL
-    # exact GeLU + stored pre-activation
+    # exact GeLU + stored DERIVATIVE GeLU'(pre-activation) (one erf / exp evaluation serves both; backward multiplies)
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     gemm(A, B, bias=bias, act=1, preact=pre, out_f32=out)
     assert rel_err(out, F.gelu(base)) < F32_TOL
-    assert rel_err(pre, base) < BF_TOL
-    # multiply by GeLU'(aux)
-    u = bf(rnd(M, N, seed=13))
-    gemm(A, B, act=2, aux=u, out_f32=out)
-    uu = u.float().requires_grad_(True)
-    F.gelu(uu).sum().backward()
-    assert rel_err(out, (A.float() @ B.float().t()) * uu.grad) < F32_TOL
+    bb = base.clone().requires_grad_(True)
+    F.gelu(bb).sum().backward()
+    assert rel_err(pre, bb.grad) < BF_TOL
+    out2 = torch.empty_like(out)
+    gemm(A, B, bias=bias, act=1, out_f32=out2)          # without the side output: same GeLU
+    assert torch.equal(out, out2)
+    # multiply by the stored derivative
+    gemm(A, B, act=2, aux=pre, out_f32=out)
+    assert rel_err(out, (A.float() @ B.float().t()) * pre.float()) < F32_TOL
     # residual
     res = bf(rnd(M, N, seed=14))
     gemm(A, B, bias=bias, residual=res, out_f32=out)
