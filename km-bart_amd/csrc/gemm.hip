@@ -1155,7 +1155,12 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
         KMB_NT_STORE((f32x4{v[2][0], v[2][1], v[3][0], v[3][1]}), reinterpret_cast<f32x4*>(o + 4));
       } else {
         const u32x4 pk = {pack2bf(v[0][0], v[0][1]), pack2bf(v[1][0], v[1][1]), pack2bf(v[2][0], v[2][1]), pack2bf(v[3][0], v[3][1])};
+#ifdef KMB_PLAIN_FFN_OUT   // experiment build: the FFN's wide activations (GeLU output, its gradient) with default-policy stores
+        if (ACT == 1 || ACT == 2) *reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16) = pk;
+        else KMB_NT_STORE(pk, reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16));
+#else
         KMB_NT_STORE(pk, reinterpret_cast<u32x4*>(out + roff * p.ld_out_bf16));
+#endif
       }
     }
     if (SIDE) {
