@@ -52,6 +52,9 @@ inline uint64_t splitmix(uint64_t x) {
 // EP() advances them by ELEMENTS of the current width.  Set for the duration of one forward call (a handle is
 // single-threaded, include/kmbart.h).
 thread_local bool g_f32 = false;
+// split-K slab of the caller's stream for small-batch forward / data-gradient GEMMs (set for the duration of one call)
+thread_local float* g_small_slab = nullptr;
+thread_local size_t g_small_floats = 0;
 inline size_t esz() { return g_f32 ? 4 : 2; }
 template <typename T> inline T* EP(T* p, size_t n) { return (T*)((char*)p + n * esz()); }
 
@@ -129,6 +132,7 @@ struct kmb_handle {
   bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr; float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
   float* losses5 = nullptr;
   float* slab = nullptr; size_t slab_floats = 0;
+  float* small_slab = nullptr; size_t small_floats = 0;
   hipEvent_t next_event() { hipEvent_t e = ring[ring_pos]; ring_pos = (ring_pos + 1) % ring.size(); return e; }
   // ---- generation state
   struct Gen {
@@ -160,7 +164,7 @@ namespace {
 
 struct PrecisionScope {   // g_f32 follows the handle for the duration of one call
   explicit PrecisionScope(const kmb_handle* h) { g_f32 = h->fp32; }
-  ~PrecisionScope() { g_f32 = false; }
+  ~PrecisionScope() { g_f32 = false; g_small_slab = nullptr; g_small_floats = 0; }
 };
 
 size_t add_param(kmb_handle* h, const std::string& name, int rows, int cols) {
@@ -215,6 +219,31 @@ int run_gemm(const KmbGemm& g, hipStream_t s) {
   }
   const char* why = kmb_gemm_check(g);
   if (why) return fail("%s (M=%d N=%d K=%d lda=%d ldb=%d akc=%d bkc=%d)", why, g.M, g.N, g.K, g.lda, g.ldb, g.a_kc, g.b_kc);
+  // Small-batch regime (the reference's default per-GPU batch is 64: M = 2048-4096 rows): a forward / data-gradient
+  // GEMM with N = 768 has 96-192 output tiles for 256 CUs and a serial K loop of up to 48 steps.  Split K over
+  // workgroups and let one pass sum the slabs and apply the linear layer's epilogue (bias, q-scale, dropout, residual).
+  // 2048x768x3072: 51 -> ~20 us stand-alone; inside a step the idle CUs were already running the side stream's weight
+  // gradients, so the whole step gains 2 % at b = 64 (8.06 -> 7.87 ms).  Large batches never take this path.
+  static const bool small_ok = !(getenv("KMB_SMALL_SPLIT") && getenv("KMB_SMALL_SPLIT")[0] == '0');
+  if (small_ok && g_small_slab != nullptr && g.a_kc == 1 && g.split_k <= 1 && g.act == 0 && !g.preact && !g.colsum && !g.aux &&
+      !g.out_f32 && g.out_bf16 && g.beta == 0.f && (g.N & 7) == 0 && (g.K % 64) == 0 && g.M > 512) {
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int nt = g.K / 64;
+    int S = tiles > 0 ? 512 / tiles : 1;
+    if (S > 8) S = 8;
+    if (S > nt / 4) S = nt / 4;
+    while (S > 1 && (size_t)S * g.M * g.N > g_small_floats) --S;
+    if (S >= 3) {   // two slices do not pay for the extra pass (b = 128: 10.98 vs 10.92 ms); 96-tile shapes get five
+      KmbGemm q = g;
+      q.split_k = S; q.slab = g_small_slab; q.out_bf16 = nullptr; q.bias = nullptr; q.residual = nullptr;
+      q.drop_thr16 = 0u; q.col_scale = 1.f; q.col_scale_n = 0;
+      KCHK(run_gemm(q, s));
+      const KmbDrop dr{g.drop_thr16, g.drop_seed, g.drop_scale};
+      HIPCHK(kmb_reduce_slabs_epi_launch(g_small_slab, S, (size_t)g.M * g.N, g.bias, g.col_scale, g.col_scale_n, dr, g.residual,
+                                         g.ld_res, g.out_bf16, g.ld_out_bf16, g.M, g.N, s));
+      return 0;
+    }
+  }
   if (g_prof.on) {
     if (g_prof.used + 2 > g_prof.ev.size()) {
       const size_t old = g_prof.ev.size();
@@ -419,6 +448,9 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   bf16_t* dlogits_c = bp.act(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
   const size_t slab_floats = (size_t)20 << 20;          // split-K partial slabs of the weight-gradient GEMMs (80 MB)
   float* slab = bp.take<float>(slab_floats);
+  // slabs of the small-batch split-K forward / dgrad GEMMs (run_gemm) on the caller's stream; only small batches use them
+  const size_t small_floats = Mmax <= 8192 ? (size_t)8 * Mmax * d : 1024;
+  float* small_slab = bp.take<float>(small_floats);
   float* loss_rows = bp.take<float>(Md);
   bf16_t* dhdec = bp.act(Md * d);
   bf16_t* dyA = bp.act(Mmax * d); bf16_t* dyB = bp.act(Mmax * d);
@@ -456,7 +488,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     H->xe = xe; H->xd = xd; H->ea = ea; H->da = da; H->logits_c = logits_c; H->logits_c_floats = lc_floats; H->dlogits_c = dlogits_c;
     H->loss_rows = loss_rows; H->dhdec = dhdec; H->dyA = dyA; H->dyB = dyB; H->dz = dz;
     H->bb[0] = bb[0]; H->bb[1] = bb[1]; H->dob = dob; H->denc = denc; H->parts = parts;
-    H->slab = slab; H->slab_floats = slab_floats;
+    H->slab = slab; H->slab_floats = slab_floats; H->small_slab = small_slab; H->small_floats = small_floats;
     H->hx = hx; H->hy = hy; H->hdy = hdy; H->hdx = hdx; H->hdlg = hdlg; H->hlg = hlg; H->hloss = hloss; H->dhead = dhead;
     H->losses5 = losses5;
   }
@@ -897,6 +929,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   const size_t need = layout_train(h, nullptr, 0, bt.B, bt.S, bt.T, bt.n_features, false);
   if (need > h->ws_bytes) return fail("kmb_forward: workspace too small (%zu > %zu bytes)", need, h->ws_bytes);
   layout_train(h, h->ws, h->ws_bytes, bt.B, bt.S, bt.T, bt.n_features, true);
+  if (!h->fp32 && h->small_floats > 1024) { g_small_slab = h->small_slab; g_small_floats = h->small_floats; }
   h->gen.active = false;
   const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = B * S, Md = B * T;
   h->bt = bt; h->Me = Me; h->Md = Md; h->Ntot = bt.n_features;
@@ -1087,6 +1120,8 @@ int kmb_backward_dev(kmb_handle* h, const float* loss_scale_dev, void* stream) {
 static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scale_dev, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   KCHK(check_bound(h));
+  PrecisionScope scope(h);
+  if (h->small_floats > 1024) { g_small_slab = h->small_slab; g_small_floats = h->small_floats; }
   if (!h->have_fwd) return fail("kmb_backward: no forward with need_grad=1 to differentiate");
   h->have_fwd = false;
   const kmb_batch& bt = h->bt;

@@ -45,6 +45,10 @@ hipError_t kmb_reduce_slabs_bf16_launch(const float* slabs, int nslabs, size_t s
                                         hipStream_t stream);
 hipError_t kmb_reduce_slabs_launch(const float* slabs, int nslabs, size_t stride, float* out, size_t n, float beta,
                                    hipStream_t stream);
+// out[M, N] (bf16, row stride ld_out) = dropout((sum of slabs + bias) * q-scale) + residual   (N % 8 == 0)
+hipError_t kmb_reduce_slabs_epi_launch(const float* slabs, int nslabs, size_t stride, const float* bias, float col_scale,
+                                       int col_scale_n, KmbDrop drop, const bf16_t* residual, int ld_res, bf16_t* out,
+                                       int ld_out, int M, int N, hipStream_t stream);
 // column sums of a bf16 matrix -> partials [nparts][N]; nparts = kmb_colsum_parts(M)
 int kmb_colsum_parts(int M);
 hipError_t kmb_colsum_launch(const bf16_t* X, int ld, int M, int N, float* partials, hipStream_t stream);

@@ -308,6 +308,42 @@ __global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __r
   }
 }
 
+// Split-K forward / data-gradient GEMMs of the small-batch regime (few output tiles, long K: M = 2048-4096 rows against
+// 256 CUs): the slabs are summed in slice order and the linear layer's epilogue is applied here -- bias, q-scale, dropout
+// (the same counter-based mask as the GEMM epilogue and the LayerNorm backward), residual -- then one bf16 store.
+__global__ __launch_bounds__(256) void reduce_slabs_epi_kernel(const float* __restrict__ slabs, int nslabs, size_t stride,
+                                                               const float* __restrict__ bias, float col_scale,
+                                                               int col_scale_n, KmbDrop drop,
+                                                               const bf16_t* __restrict__ residual, int ld_res,
+                                                               bf16_t* __restrict__ out, int ld_out, int M, int N) {
+  const int nch = N >> 3;
+  const size_t total = (size_t)M * nch;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / nch), c = (int)(i % nch) * 8;
+    const float* src = slabs + (size_t)row * N + c;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    for (int s = 1; s < nslabs; ++s) {
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride + 4);
+      a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3];
+      b[0] += b2[0]; b[1] += b2[1]; b[2] += b2[2]; b[3] += b2[3];
+    }
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = (v[e] + (bias != nullptr ? bias[c + e] : 0.f)) * ((c + e) < col_scale_n ? col_scale : 1.f);
+      if (drop.thr16 != 0u) v[e] = drop_keep(drop.seed, (uint32_t)row, (uint32_t)(c + e), drop.thr16) ? v[e] * drop.scale : 0.f;
+    }
+    if (residual != nullptr) {
+      float rr[8];
+      unpack8(*reinterpret_cast<const u32x4*>(residual + (size_t)row * ld_res + c), rr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rr[e];
+    }
+    *reinterpret_cast<u32x4*>(out + (size_t)row * ld_out + c) = pack8(v);
+  }
+}
+
 // grid (ceil(N/64), nparts); block 256 = 8 column chunks x 32 row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int ld, int M, int N,
                                                      float* __restrict__ partials, int rows_per_part) {
@@ -439,6 +475,19 @@ hipError_t kmb_reduce_slabs_bf16_launch(const float* slabs, int nslabs, size_t s
   size_t blocks = (n / 8 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, nslabs, stride, out, n / 8);
+  return hipGetLastError();
+}
+
+hipError_t kmb_reduce_slabs_epi_launch(const float* slabs, int nslabs, size_t stride, const float* bias, float col_scale,
+                                       int col_scale_n, KmbDrop drop, const bf16_t* residual, int ld_res, bf16_t* out,
+                                       int ld_out, int M, int N, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if ((N & 7) || (stride & 3) || (ld_out & 7) || ((uintptr_t)out & 15) || (residual && ((ld_res & 7) || ((uintptr_t)residual & 15))))
+    return hipErrorInvalidValue;
+  size_t blocks = ((size_t)M * (N >> 3) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(reduce_slabs_epi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, nslabs, stride, bias,
+                     col_scale, col_scale_n, drop, residual, ld_res, out, ld_out, M, N);
   return hipGetLastError();
 }
 

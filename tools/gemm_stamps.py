@@ -56,15 +56,20 @@ def main():
         gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
     torch.cuda.synchronize()
     assert lib.kmb_debug_set_stamps(C.c_void_p(stamps.data_ptr())) == 0
+    if os.environ.get("KMB_COLD") == "1":   # operands from HBM, as inside a training step (tools/gemm_cold_warm.py)
+        junk = torch.empty(600 << 20, dtype=torch.uint8, device=DEV)
+        junk.fill_(1)
+        torch.cuda.synchronize()
     gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
     torch.cuda.synchronize()
     lib.kmb_debug_set_stamps(None)
     s = stamps.cpu().numpy().astype(np.int64)
     s = s[s[:, 0] != 0]  # the 256x256 variants launch a quarter of the workgroups
-    if os.environ["KMB_GEMM_VARIANT"] == "11":   # persistent kernel: totals per workgroup over its tiles
+    if os.environ["KMB_GEMM_VARIANT"] in ("11", "12", "13"):   # persistent kernels: totals per workgroup over its tiles
         tick = 0.01
-        ntile = ((M + 255) // 256) * ((N + 255) // 256)
-        print(f"v11 M={M} N={N} K={K} workgroups={len(s)} tiles={ntile} ({ntile / len(s):.2f} per workgroup) "
+        bn = {"11": 256, "12": 128, "13": 192}[os.environ["KMB_GEMM_VARIANT"]]
+        ntile = ((M + 255) // 256) * ((N + bn - 1) // bn)
+        print(f"v{os.environ['KMB_GEMM_VARIANT']} M={M} N={N} K={K} workgroups={len(s)} tiles={ntile} ({ntile / len(s):.2f} per workgroup) "
               f"kernel span {(s[:, 4].max() - s[:, 0].min()) * tick:.1f} us")
         for name, v in (("prologue", s[:, 1] - s[:, 0]), ("k_loops (sum)", s[:, 2]), ("  of which wait+barrier", s[:, 5]),
                         ("epilogues (sum)", s[:, 3]), ("store drain (sum)", s[:, 6]), ("whole workgroup", s[:, 4] - s[:, 0])):
