@@ -106,6 +106,32 @@ typedef struct KmbAttnDecode {
   kmb_bf16* Kw; kmb_bf16* Vw;
 } KmbAttnDecode;
 
+/* One fused block of a KV-cached decode step (csrc/decode.hip): [LayerNorm ->] projection of R rows [-> attention].
+ * Replaces the GEMM + attention + LayerNorm launches of one sub-layer of the reference's DecoderLayer under use_cache
+ * (transformers 3.0.2 modeling_bart.py:386-466, reached from src/model/mixins.py:386-434).
+ *   kind 0: out[R, N] = act(LN?(in) W^T + bias) + residual                         (N % 64 == 0)
+ *   kind 1: self-attention of head h = 0..H-1: W = [q | k | v] rows (N = 3*H*64); the new key / value row is written to
+ *           the cache at position Tk-1 and attended to together with cache rows 0 .. Tk-2; out[R, H*64]
+ *   kind 2: cross-attention: W = q rows (N = H*64); keys / values Kc / Vc of batch item kv_row[row], masked by key_mask
+ * K % 768 == 0, K <= 3072 (kinds 1, 2: K = 768).  gamma != NULL: `in` holds pre-LayerNorm sums and the LayerNorm is
+ * applied on the way in; ln_out (optional, row stride K) receives the normalised rows once. */
+typedef struct KmbDecodeBlock {
+  int32_t kind;
+  const kmb_bf16* in; int32_t ld_in;
+  const float* gamma; const float* beta; float eps;
+  kmb_bf16* ln_out;
+  const kmb_bf16* W; const float* bias;     /* W [N, K] row-major, bias [N] */
+  int32_t R, K, N;
+  int32_t act;                              /* kind 0: 1 = GeLU */
+  const kmb_bf16* residual; int32_t ld_res; /* kind 0 */
+  kmb_bf16* out; int32_t ld_out;
+  int32_t H; float q_scale;                 /* kinds 1, 2: (q + bias) * q_scale */
+  kmb_bf16* Kc; kmb_bf16* Vc;               /* cache element (row,t,h,e) at X[(row*Tmax + t)*ldc + h*64 + e] */
+  int32_t Tmax, ldc, Tk;
+  const int32_t* kv_row;                    /* kind 2: cache row (batch item) of every row */
+  const int64_t* key_mask; int32_t mask_ld; /* kind 2: key t of cache row c is masked when key_mask[c*mask_ld + t] == 0 */
+} KmbDecodeBlock;
+
 typedef struct KmbDrop { uint32_t thr16; uint32_t seed; float scale; } KmbDrop;
 typedef struct KmbAdamW { double lr, beta1, beta2, eps, weight_decay; int32_t step; int32_t correct_bias; float grad_scale; } KmbAdamW;
 
@@ -233,6 +259,7 @@ int kmb_op_gemm(const KmbGemm* p, void* stream);
 int kmb_op_attn_fwd(const KmbAttn* p, void* stream);
 int kmb_op_attn_bwd(const KmbAttn* p, void* stream);
 int kmb_op_attn_decode(const KmbAttnDecode* p, void* stream);
+int kmb_op_decode_block(const KmbDecodeBlock* p, void* stream);
 int kmb_op_ln_fwd(const kmb_bf16* z, const float* gamma, const float* beta, kmb_bf16* y, float* mean, float* rstd,
                   int M, int D, float eps, void* stream);
 /* partials: device float scratch of kmb_op_ln_bwd_scratch(M, D) floats */

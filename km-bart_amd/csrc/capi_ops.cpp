@@ -38,6 +38,11 @@ int kmb_op_attn_bwd(const KmbAttn* p, void* stream) {
 int kmb_op_attn_decode(const KmbAttnDecode* p, void* stream) {
   return hipfail(kmb_attn_decode_launch(*p, (hipStream_t)stream), "attn_decode");
 }
+int kmb_op_decode_block(const KmbDecodeBlock* p, void* stream) {
+  const char* why = kmb_decode_block_check(*p);
+  if (why) return kmb_set_error(why);
+  return hipfail(kmb_decode_block_launch(*p, (hipStream_t)stream), "decode_block");
+}
 int kmb_op_ln_fwd(const kmb_bf16* z, const float* gamma, const float* beta, kmb_bf16* y, float* mean, float* rstd,
                   int M, int D, float eps, void* stream) {
   return hipfail(kmb_ln_fwd_launch(z, gamma, beta, y, mean, rstd, M, D, eps, (hipStream_t)stream), "ln_fwd");

@@ -1490,7 +1490,59 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(g_off), h->pf(be_off), out, G.mean, G.rstd, R, d, eps, s));
     return 0;
   };
-  for (int l = 0; l < h->cfg.decoder_layers; ++l) {
+  // Fused form (csrc/decode.hip): six launches per layer, the LayerNorms folded into the consumers.  Needs d_model = 768
+  // (one 768-deep weight block per attention projection) and an FFN width of 768 .. 3072 in steps of 768; other
+  // configurations, and KMB_GEN_FUSED=0, take the launch-per-operation path below.
+  const char* fused_env = getenv("KMB_GEN_FUSED");   // read per call: tests compare the two paths in one process
+  const bool fused = !(fused_env && fused_env[0] == '0') && d == 768 && h->Hd * 64 == d && (F % 768) == 0 && F <= 3072;
+  if (fused) {
+    const bf16_t* zin = G.x0;                       // layer input: normalised rows (layer 0) or pre-LayerNorm sums
+    const float *lg = nullptr, *lb = nullptr;       // ... and the LayerNorm that turns them into the layer input
+    auto block = [&](const KmbDecodeBlock& b) -> int {
+      const char* why = kmb_decode_block_check(b);
+      if (why) return fail("kmb_gen_step: %s", why);
+      HIPCHK(kmb_decode_block_launch(b, s));
+      return 0;
+    };
+    for (int l = 0; l < h->cfg.decoder_layers; ++l) {
+      const LayerP& L = h->dec[l];
+      KmbDecodeBlock b;
+      memset(&b, 0, sizeof(b));
+      b.kind = 1; b.in = zin; b.ld_in = d; b.gamma = lg; b.beta = lb; b.eps = eps; b.ln_out = lg ? G.x1 : nullptr;
+      b.W = h->wb(L.sa.qkv_w); b.bias = h->pf(L.sa.qkv_b); b.R = R; b.K = d; b.N = 3 * d; b.out = G.o; b.ld_out = d;
+      b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.kc[G.cur][l]; b.Vc = G.vc[G.cur][l]; b.Tmax = G.Tmax; b.ldc = d; b.Tk = step + 1;
+      KCHK(block(b));
+      const bf16_t* xres = lg ? G.x1 : zin;
+      memset(&b, 0, sizeof(b));
+      b.kind = 0; b.in = G.o; b.ld_in = d; b.W = h->wb(L.sa.o_w); b.bias = h->pf(L.sa.o_b); b.R = R; b.K = d; b.N = d;
+      b.residual = xres; b.ld_res = d; b.out = G.z; b.ld_out = d;
+      KCHK(block(b));
+      memset(&b, 0, sizeof(b));
+      b.kind = 2; b.in = G.z; b.ld_in = d; b.gamma = h->pf(L.sa.ln_g); b.beta = h->pf(L.sa.ln_b); b.eps = eps; b.ln_out = G.y;
+      b.W = h->wb(L.ca.qkv_w); b.bias = h->pf(L.ca.qkv_b); b.R = R; b.K = d; b.N = d; b.out = G.o; b.ld_out = d;
+      b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.ckv[l]; b.Vc = G.ckv[l] + d; b.Tmax = G.S; b.ldc = 2 * d; b.Tk = G.S;
+      b.kv_row = G.kv_row; b.key_mask = G.bt.attention_mask; b.mask_ld = G.S;
+      KCHK(block(b));
+      memset(&b, 0, sizeof(b));
+      b.kind = 0; b.in = G.o; b.ld_in = d; b.W = h->wb(L.ca.o_w); b.bias = h->pf(L.ca.o_b); b.R = R; b.K = d; b.N = d;
+      b.residual = G.y; b.ld_res = d; b.out = G.z; b.ld_out = d;
+      KCHK(block(b));
+      memset(&b, 0, sizeof(b));
+      b.kind = 0; b.in = G.z; b.ld_in = d; b.gamma = h->pf(L.ca.ln_g); b.beta = h->pf(L.ca.ln_b); b.eps = eps; b.ln_out = G.y;
+      b.W = h->wb(L.fc1_w); b.bias = h->pf(L.fc1_b); b.R = R; b.K = d; b.N = F; b.act = 1; b.out = G.hh; b.ld_out = F;
+      KCHK(block(b));
+      memset(&b, 0, sizeof(b));
+      b.kind = 0; b.in = G.hh; b.ld_in = F; b.W = h->wb(L.fc2_w); b.bias = h->pf(L.fc2_b); b.R = R; b.K = F; b.N = d;
+      b.residual = G.y; b.ld_res = d; b.out = G.z; b.ld_out = d;
+      KCHK(block(b));
+      zin = G.z; lg = h->pf(L.ln_g); lb = h->pf(L.ln_b);
+    }
+    if (lg) {
+      HIPCHK(kmb_ln_fwd_launch(G.z, lg, lb, G.x1, G.mean, G.rstd, R, d, eps, s));
+      x = G.x1;
+    }
+  }
+  for (int l = 0; !fused && l < h->cfg.decoder_layers; ++l) {
     const LayerP& L = h->dec[l];
     KmbGemm g = lin_fwd(x, d, h->wb(L.sa.qkv_w), h->pf(L.sa.qkv_b), R, 3 * d, d);
     g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = G.qkv; g.ld_out_bf16 = 3 * d;

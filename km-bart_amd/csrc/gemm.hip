@@ -43,6 +43,7 @@ extern "C" int kmb_debug_set_stamps(void* p) {
           ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);                               \
   } while (0)
 #define KMB_WAIT_BEGIN() const uint64_t kmb_w0 = __builtin_amdgcn_s_memrealtime()
+#define KMB_NOW() __builtin_amdgcn_s_memrealtime()
 #define KMB_WAIT_END(acc) (acc) += __builtin_amdgcn_s_memrealtime() - kmb_w0
 #define KMB_STAMP_VALUE(i, v)                                                                          \
   do {                                                                                                 \
@@ -52,6 +53,7 @@ extern "C" int kmb_debug_set_stamps(void* p) {
 #define KMB_STAMP(i)
 #define KMB_STAMP_ID()
 #define KMB_WAIT_BEGIN()
+#define KMB_NOW() uint64_t(0)
 #define KMB_WAIT_END(acc)
 #define KMB_STAMP_VALUE(i, v)
 #endif
@@ -1265,9 +1267,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   uint32_t offA[8], offB[NPB];
   const char *gA_d, *gB_d;
   int tile_d = first_tile, td = 0;
+  // ---- L2 prefetch of the activation operand (K-contiguous A only) ----
+  // Inside a training step A was just streamed out by the previous kernel: every LDS-DMA request of a stage is an HBM
+  // miss, and the tiles_n workgroups that share a row panel (same XCD, running in step) all miss on the same lines, each
+  // holding a request slot per line for the whole HBM latency (in-kernel stamps: 1.76 instead of 1.12 us per K step).
+  // Each of them therefore touches ITS share of the panel's rows (256 / tiles_n rows = one 128-byte line each per K
+  // step, ONE load instruction of wave 0) KMB_PFD steps ahead of the DMA cursor: the lines are in the XCD's L2 when the
+  // DMAs of all sharers ask for them.  The load's result is never used; it stays outstanding across the stage wait
+  // (vmcnt(1) instead of 0 for wave 0) and must only be complete one step later.
+#ifndef KMB_V11_PREFETCH
+#define KMB_V11_PREFETCH 1
+#endif
+#ifndef KMB_V11_PFD
+#define KMB_V11_PFD 2
+#endif
+  constexpr int KMB_PFD = KMB_V11_PFD;
+  constexpr bool PF_ON = KMB_V11_PREFETCH != 0 && A_KC;
+  const bool pf_rt = (p.tile_order & 2) != 0;   // set per launch (kmb_gemm_launch): only where A is expected to come from HBM
+  // The first KMB_PFD steps of a tile have no earlier step of the same tile to be prefetched from: they are touched
+  // from the tile `per` places earlier in the range -- the tile whose workgroup is one round ahead of the one that will
+  // take this tile (tiles are handed out in range order, so the workgroups of one round run the sharers of a panel).
+  uint32_t pf_off = 0u, pfn_off = 0u, pf_sink = 0u;
+  const char* pfn_base = reinterpret_cast<const char*>(p.A);
+  bool pf_pending = false, pfn_ok = false;
+  auto pf_row_offset = [&](int tn, int row0) {
+    int share = (BM4 + tiles_n - 1) / tiles_n;
+    share = share > 64 ? 64 : share;
+    int prow = tn * share + (lane < share ? lane : 0);
+    prow = prow < BM4 ? prow : BM4 - 1;
+    prow = row0 + prow < p.M ? prow : 0;
+    return (uint32_t)prow * (uint32_t)p.lda * 2u;
+  };
   auto set_dma_tile = [&](int tile) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int row0 = tm * BM4, col0 = tn * BNT;
+    if (PF_ON) {
+      pf_off = pf_row_offset(tn, row0);
+      const int tx = tile + per;
+      pfn_ok = tx < range1;
+      if (pfn_ok) {
+        const int tmx = tx / tiles_n, tnx = tx - tmx * tiles_n;
+        pfn_off = pf_row_offset(tnx, tmx * BM4);
+        pfn_base = uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmx * BM4 * p.lda * 2);
+      }
+    }
     dma_offsets256w4<A_KC>(offA, p.lda, row0, p.M, wave, lane);
     if constexpr (BNT == 128) dma_offsets<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
     else dma_offsets256w4<B_KC, NPB>(offB, p.ldb, col0, p.N, wave, lane);
@@ -1357,6 +1400,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 
   set_dma_tile(tile_d);
+  if (PF_ON && pf_rt && wave == 0) {   // steps 2 .. PFD + 1 of the first tile (issued before, so complete before, the stage pieces)
+#pragma unroll
+    for (int i = 2; i < 2 + KMB_PFD; ++i) {
+      if (i < nt) {
+        const char* pbase = uniform_ptr(gA_d + (size_t)i * stepA);
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_sink) : "v"(pf_off), "s"(pbase) : "memory");
+      }
+    }
+  }
   dma_stage_a(0);
   dma_stage_b(0, 2);
   advance_cursor();
@@ -1391,7 +1443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
 #endif
-    [[maybe_unused]] const uint64_t kmb_t_loop = __builtin_amdgcn_s_memrealtime();
+    [[maybe_unused]] const uint64_t kmb_t_loop = KMB_NOW();
     for (int t = 0; t < nt; ++t, ++it) {
       // publish the next tile to the other waves: written in step 1, behind step 1's barrier when the cursor reads it
       // in step nt - 2 >= 2 (the launcher hands out a counter only when nt >= 4)
@@ -1437,6 +1489,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       __builtin_amdgcn_sched_barrier(0);
       advance_cursor();
+      if (PF_ON) {
+        const int ps = td + KMB_PFD;   // td: the step the next fetch of this workgroup asks for
+        const bool in_tile = ps < nt;
+        pf_pending = pf_rt && wave == 0 && (in_tile || (pfn_ok && ps - nt < nt));
+        if (pf_pending) {
+          const char* pbase = uniform_ptr(in_tile ? gA_d + (size_t)KMB_PFD * stepA : pfn_base + (size_t)(ps - nt) * stepA);
+          const uint32_t poff = in_tile ? pf_off : pfn_off;
+          asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_sink) : "v"(poff), "s"(pbase) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- sub-phase 2: A(k1, rows 0-63) x B(k1)  ||  read A(k1, rows 64-127); stage it+1 landed, barrier ----
       read_a(cur, 1, 1, fa[1]);
       mma(0, fa[0], fb[1]);
@@ -1446,7 +1509,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_sched_barrier(0);
       {
         KMB_WAIT_BEGIN();
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        if (PF_ON && pf_pending) __builtin_amdgcn_s_waitcnt(0x0071);  // vmcnt(1): this step's L2 prefetch stays in flight
+        else __builtin_amdgcn_s_waitcnt(0x0070);                       // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         KMB_WAIT_END(kmb_wait_ticks);
       }
@@ -1516,7 +1580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = 0; e < 4; ++e) acc[i][j][e] = acc32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + e];
 #endif
     // ---- epilogue of this tile (the next tile's first two stages are in flight / resident meanwhile) ----
-    [[maybe_unused]] const uint64_t kmb_t_epi = __builtin_amdgcn_s_memrealtime();
+    [[maybe_unused]] const uint64_t kmb_t_epi = KMB_NOW();
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int row0w = tm * BM4 + wm * WROWS, col0w = tn * BNT + wn * WCOLS;
     if (row0w < p.M && col0w < p.N) {
@@ -1547,7 +1611,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
 #undef KMB_LEAN
     }
-    [[maybe_unused]] const uint64_t kmb_t_drain = __builtin_amdgcn_s_memrealtime();
+    [[maybe_unused]] const uint64_t kmb_t_drain = KMB_NOW();
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): keeps the epilogue's pending loads out of the K loop's wait state
 #ifdef KMB_GEMM_STAMP
     {
@@ -1556,6 +1620,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #endif
   }
+  if (PF_ON) asm volatile("" ::"v"(pf_sink));   // the prefetch destination stays reserved for the whole kernel
   KMB_STAMP_VALUE(2, kmb_loop_ticks);
   KMB_STAMP_VALUE(3, kmb_epi_ticks);
   KMB_STAMP_VALUE(5, kmb_wait_ticks);
@@ -1843,6 +1908,23 @@ bool v11_ok(const KmbGemm& p, int bn = BN4) {
   return p.split_k <= 1 && (p.K % BK) == 0 && p.K >= 2 * BK && tiles >= 128;   // at least half the CUs get a tile
 }
 
+// L2 prefetch of the activation operand by the persistent kernels (tile_order bit 1).  The tuning above times
+// back-to-back launches, whose operands sit in the Infinity Cache, so it cannot see what the prefetch is for; the rule
+// comes from per-shape timing inside a step (tools/gemm_shape_table.py, profiles/r02_gemm_prefetch_ab.txt): it pays
+// where A is wide (K >= 2048: the FFN's hidden activations and their gradients, the region features) and too large to
+// still be cached from its producer (forward: it was written together with the GeLU' copy; backward: >= 160 MB), and
+// costs 1-10 % where A is narrow or small (K = 768, or the operand the previous kernel just wrote).
+bool prefetch_a(const KmbGemm& p) {
+  static int mode = -1;   // KMB_GEMM_PREFETCH = 0 (never) | 1 (always) | unset (the rule)
+  if (mode < 0) {
+    const char* e = getenv("KMB_GEMM_PREFETCH");
+    mode = e ? (e[0] == '0' ? 0 : 1) : 2;
+  }
+  if (mode != 2) return mode == 1;
+  if (!p.a_kc || p.K < 2048) return false;
+  return p.b_kc || (double)p.M * p.K * 2.0 >= 160e6;
+}
+
 bool writes_an_input(const KmbGemm& p) {
   const void* outs[3] = {p.out_bf16, p.out_f32, p.preact};
   const void* ins[4] = {p.A, p.B, p.residual, p.aux};
@@ -1922,7 +2004,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (v == 13 && !v11_ok(p, 192)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
     if (v != 1 && v != 7 && v != 8 && v != 11 && v != 12 && v != 13) v = 7;
-    return launch_variant(v, p, stream);
+    KmbGemm q = p;
+    q.tile_order = p.tile_order | (prefetch_a(p) ? 2 : 0);
+    return launch_variant(v, q, stream);
   }
   if (!big || p.N <= 128) return launch_variant(7, p, stream);
   const TuneKey key{p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act};
@@ -1967,6 +2051,6 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     }
   }
   KmbGemm q = p;
-  q.tile_order = it->second >> 4;
+  q.tile_order = (it->second >> 4) | (prefetch_a(p) ? 2 : 0);
   return launch_variant(it->second & 15, q, stream);
 }

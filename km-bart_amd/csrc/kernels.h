@@ -20,6 +20,11 @@ const char* kmb_attn_check(const KmbAttn& p, int backward);
 // single-query attention over a KV cache (generation): one query row per (row, head)
 hipError_t kmb_attn_decode_launch(const KmbAttnDecode& p, hipStream_t stream);
 
+// --------------------------------------------------------------- decode.hip
+// fused [LayerNorm ->] projection [-> attention] block of a decode step (R = batch x beams rows)
+const char* kmb_decode_block_check(const KmbDecodeBlock& p);
+hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream);
+
 // ---------------------------------------------------------------- norm.hip
 
 // y = LN(z) * gamma + beta ; saves mean / rstd.  z, y bf16 [M, D]

@@ -64,6 +64,13 @@ class KmbAttnDecode(C.Structure):
                 ("O", c_p), ("ldo", i32), ("new_k", c_p), ("new_v", c_p), ("ld_new", i32), ("Kw", c_p), ("Vw", c_p)]
 
 
+class KmbDecodeBlock(C.Structure):
+    _fields_ = [("kind", i32), ("in_", c_p), ("ld_in", i32), ("gamma", c_p), ("beta", c_p), ("eps", f32), ("ln_out", c_p),
+                ("W", c_p), ("bias", c_p), ("R", i32), ("K", i32), ("N", i32), ("act", i32), ("residual", c_p),
+                ("ld_res", i32), ("out", c_p), ("ld_out", i32), ("H", i32), ("q_scale", f32), ("Kc", c_p), ("Vc", c_p),
+                ("Tmax", i32), ("ldc", i32), ("Tk", i32), ("kv_row", c_p), ("key_mask", c_p), ("mask_ld", i32)]
+
+
 class KmbDrop(C.Structure):
     _fields_ = [("thr16", u32), ("seed", u32), ("scale", f32)]
 
@@ -120,6 +127,7 @@ PROTOTYPES = {
     "kmb_op_attn_fwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_bwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_decode": (C.c_int, [C.POINTER(KmbAttnDecode), c_p]),
+    "kmb_op_decode_block": (C.c_int, [C.POINTER(KmbDecodeBlock), c_p]),
     "kmb_op_ln_fwd": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int, C.c_int, f32, c_p]),
     "kmb_op_ln_bwd_scratch": (i64, [C.c_int, C.c_int]),
     "kmb_op_ln_bwd": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(KmbDrop), C.POINTER(KmbDrop), c_p, c_p,

@@ -110,17 +110,19 @@ def run_variant():
     print("JSON" + json.dumps(out))
 
 
-VARIANTS = ("7", "8", "11", "12", "13", "11o1", "12o1", "13o1", "11s", "12o1s", "13s")
+VARIANTS = ("7", "8", "11", "12", "13", "11o1", "12o1", "13o1", "11s", "12o1s", "13s", "11o1p", "13p")
 
 
 def main():
     if os.environ.get("KMB_V11_CHILD"):
         return run_variant()
     res = {}
-    # o1: tile_order bit 0 = per-XCD contiguous tile ranges; s: shared-device mode (every tile from the atomic counter)
+    # o1: tile_order bit 0 = per-XCD contiguous tile ranges; s: shared-device mode (every tile from the atomic counter);
+    # p: the activation-panel L2 prefetch on for every shape (the others: off, so both paths of the kernel are compared)
     for v in VARIANTS:
-        env = dict(os.environ, KMB_GEMM_VARIANT=v.rstrip("s").split("o")[0], KMB_V11_CHILD="1",
-                   KMB_TILE_ORDER="1" if "o" in v else "0", KMB_V11_SHARED="1" if v.endswith("s") else "0")
+        env = dict(os.environ, KMB_GEMM_VARIANT=v.rstrip("sp").split("o")[0], KMB_V11_CHILD="1",
+                   KMB_TILE_ORDER="1" if "o" in v else "0", KMB_V11_SHARED="1" if v.endswith("s") else "0",
+                   KMB_GEMM_PREFETCH="1" if v.endswith("p") else "0")
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("JSON")]
         if r.returncode != 0 or not line:
