@@ -120,7 +120,7 @@ typedef struct KmbDecodeBlock {
   const kmb_bf16* in; int32_t ld_in;
   const float* gamma; const float* beta; float eps;
   kmb_bf16* ln_out;
-  const kmb_bf16* W; const float* bias;     /* W [N, K] row-major, bias [N] */
+  const kmb_bf16* W; const float* bias;     /* W: the [N, K] weight in fragment order (kmb_op_decode_pack), bias [N] */
   int32_t R, K, N;
   int32_t act;                              /* kind 0: 1 = GeLU */
   const kmb_bf16* residual; int32_t ld_res; /* kind 0 */
@@ -236,6 +236,13 @@ int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const floa
 /* one beam-search step's candidate selection (mixins.py beam loop: topk over num_beams * V): per batch item the best k of
  * its beams' top-k lists; out[B][k][2] int32 = {fp32 score bits, beam * V + token} */
 int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream);
+/* the same, and the beams of the next decode step chosen on the device: in candidate order the first num_beams candidates
+ * whose token is not eos_token (-1: none) -> next_scores [B*num_beams] (the `add` of the next kmb_logsoftmax_topk),
+ * next_tokens [B*num_beams] (int64, the next kmb_gen_step), next_beam_idx [B*num_beams] (kmb_gen_reorder): the selection
+ * of transformers 3.0.2 _generate_beam_search (reached from src/model/mixins.py:336-361) without its host round trip;
+ * `out` still carries every candidate for the host's hypothesis bookkeeping. */
+int kmb_beam_merge_select(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out,
+                          int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, void* stream);
 int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
 
 /* Data-parallel runs share the GPU between the GEMMs and RCCL's all-reduce kernel (reference: torch DDP's NCCL streams,
@@ -260,6 +267,8 @@ int kmb_op_attn_fwd(const KmbAttn* p, void* stream);
 int kmb_op_attn_bwd(const KmbAttn* p, void* stream);
 int kmb_op_attn_decode(const KmbAttnDecode* p, void* stream);
 int kmb_op_decode_block(const KmbDecodeBlock* p, void* stream);
+/* packed <- W ([N, K] row-major, row stride ld; N % 16 == 0, K % 64 == 0) in the order KmbDecodeBlock.W is read */
+int kmb_op_decode_pack(const kmb_bf16* W, int ld, int N, int K, kmb_bf16* packed, void* stream);
 int kmb_op_ln_fwd(const kmb_bf16* z, const float* gamma, const float* beta, kmb_bf16* y, float* mean, float* rstd,
                   int M, int D, float eps, void* stream);
 /* partials: device float scratch of kmb_op_ln_bwd_scratch(M, D) floats */

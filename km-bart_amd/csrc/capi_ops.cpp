@@ -43,6 +43,9 @@ int kmb_op_decode_block(const KmbDecodeBlock* p, void* stream) {
   if (why) return kmb_set_error(why);
   return hipfail(kmb_decode_block_launch(*p, (hipStream_t)stream), "decode_block");
 }
+int kmb_op_decode_pack(const kmb_bf16* W, int ld, int N, int K, kmb_bf16* packed, void* stream) {
+  return hipfail(kmb_decode_pack_launch(&W, &ld, &N, &K, &packed, 1, (hipStream_t)stream), "decode_pack");
+}
 int kmb_op_ln_fwd(const kmb_bf16* z, const float* gamma, const float* beta, kmb_bf16* y, float* mean, float* rstd,
                   int M, int D, float eps, void* stream) {
   return hipfail(kmb_ln_fwd_launch(z, gamma, beta, y, mean, rstd, M, D, eps, (hipStream_t)stream), "ln_fwd");
@@ -116,7 +119,13 @@ int kmb_gemm_shared_device(int on) {
   return 0;
 }
 int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream) {
-  return hipfail(kmb_beam_merge_launch(val, idx, B, num_beams, k, V, out, (hipStream_t)stream), "beam_merge");
+  return hipfail(kmb_beam_merge_launch(val, idx, B, num_beams, k, V, out, -1, nullptr, nullptr, nullptr, (hipStream_t)stream), "beam_merge");
+}
+int kmb_beam_merge_select(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out,
+                          int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, void* stream) {
+  if (!next_scores || !next_tokens || !next_beam_idx) return kmb_set_error("kmb_beam_merge_select: missing output");
+  return hipfail(kmb_beam_merge_launch(val, idx, B, num_beams, k, V, out, eos_token, next_scores, next_tokens, next_beam_idx,
+                                       (hipStream_t)stream), "beam_merge_select");
 }
 int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
                         int k, float* out_val, int32_t* out_idx, void* stream) {

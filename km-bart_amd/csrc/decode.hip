@@ -29,6 +29,24 @@
 #include "common.h"
 #include "kernels.h"
 #include <math.h>
+#include <string.h>
+
+// Diagnostic build only (tools/decode_stamps.py: -DKMB_DECODE_STAMP): per-workgroup s_memrealtime stamps (100 MHz) at
+// the phase boundaries of the last launch of each kernel type.
+#ifdef KMB_DECODE_STAMP
+__device__ unsigned long long* g_dec_stamps = nullptr;
+extern "C" int kmb_debug_set_decode_stamps(void* p) {
+  unsigned long long* v = (unsigned long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), &v, sizeof(v));
+}
+#define DSTAMP(type, i)                                                                                      \
+  do {                                                                                                       \
+    if (g_dec_stamps != nullptr && threadIdx.x == 0)                                                         \
+      g_dec_stamps[((size_t)(type) * 4096 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();       \
+  } while (0)
+#else
+#define DSTAMP(type, i)
+#endif
 
 namespace {
 
@@ -36,18 +54,23 @@ constexpr int RT = 16;      // rows per workgroup
 constexpr int KBLK = 768;   // K block whose weight fragments are in flight together
 constexpr int HD = 64;
 
+// ---- weights in fragment order ----
+// A wave-wide 16-byte-per-lane load of an MFMA weight fragment out of the row-major matrix touches 16 rows x 64 bytes:
+// 16 half-used cache lines per instruction, and the vector memory pipe of a CU retires such requests at ~7 per us
+// (in-kernel stamps: 24 of them took 2 us just to issue).  The decode blocks therefore read a copy of the decoder
+// weights laid out in the order the fragments are consumed: fragment (16-row tile n, 64-deep chunk c, half s) is ONE
+// contiguous KiB, lane l's eight elements at l*8 -- W[n*16 + (l & 15)][c*64 + (l >> 4)*16 + s*8 ...].  Packed once per
+// generate() by pack_weights_kernel (99 MB for the six decoder layers of vcg_base, 0.1 ms).
 struct WBlock { u32x4 w[24]; };   // one 16-column tile x 768 K
 
 __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-// weight rows n0 .. n0+15, K range [k0, k0 + 768)
-__device__ __forceinline__ void load_wblock(WBlock& f, const bf16_t* __restrict__ W, int ldw, int n0, int k0, int lane) {
-  const int r = lane & 15, g = lane >> 4;
-  const bf16_t* p = W + (size_t)(n0 + r) * ldw + k0 + g * 16;
+__device__ __forceinline__ void load_wblock(WBlock& f, const bf16_t* __restrict__ Wp, int K, int ntile, int k0, int lane) {
+  const bf16_t* p = Wp + ((size_t)ntile * (K >> 6) + (k0 >> 6)) * 1024 + lane * 8;
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
-    f.w[2 * c] = *reinterpret_cast<const u32x4*>(p + c * 64);
-    f.w[2 * c + 1] = *reinterpret_cast<const u32x4*>(p + c * 64 + 8);
+    f.w[2 * c] = *reinterpret_cast<const u32x4*>(p + c * 1024);
+    f.w[2 * c + 1] = *reinterpret_cast<const u32x4*>(p + c * 1024 + 512);
   }
 }
 
@@ -64,63 +87,102 @@ __device__ __forceinline__ void mma_wblock(f32x4& acc, const WBlock& f, const ch
   }
 }
 
-// 16 input rows -> LDS (row stride a_stride bytes), LayerNorm'ed on the way when gamma != null (same arithmetic as
-// ln_fwd_kernel).  Wave w stages rows 4w .. 4w+3; `keep` != null: the normalised rows are also written to memory.
+struct PackDesc { const bf16_t* src; bf16_t* dst; int ld, N, K; int first; };   // first: index of its first 16-byte chunk
+constexpr int PACK_MAX = 48;
+struct PackArgs { PackDesc m[PACK_MAX]; int n; int total; };
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.total; i += gridDim.x * 256) {
+    int mi = 0;
+    while (mi + 1 < a.n && a.m[mi + 1].first <= i) ++mi;
+    const PackDesc& d = a.m[mi];
+    const int o = i - d.first;                 // chunk index in the packed matrix
+    const int lane = o & 63, sub = (o >> 6) & 1, cc = o >> 7;
+    const int kc = d.K >> 6;
+    const int c = cc % kc, nt = cc / kc;
+    const bf16_t* src = d.src + (size_t)(nt * 16 + (lane & 15)) * d.ld + c * 64 + (lane >> 4) * 16 + sub * 8;
+    *reinterpret_cast<u32x4*>(d.dst + (size_t)o * 8) = *reinterpret_cast<const u32x4*>(src);
+  }
+}
+
+// ---- the 16 input rows of a workgroup -> LDS (row stride a_stride bytes) ----
+// Wave w stages rows 4w .. 4w+3.  The loads are issued first (rows_issue), ahead of the weight fragments in the wave's
+// in-order memory queue; rows_finish normalises (gamma != null: LayerNorm with the arithmetic of ln_fwd_kernel, the
+// four rows' reductions interleaved) and writes LDS; `keep` != null: the normalised rows also go to memory.
 template <int NCH>   // 16-byte chunks per lane: K / 8 / 64 rounded up
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ in, int ld_in, int row0, int R, int K,
-                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                           bf16_t* __restrict__ keep, char* lds_a, int a_stride, int wave, int lane) {
+struct RowRegs { u32x4 raw[4][NCH]; };
+
+template <int NCH>
+__device__ __forceinline__ void rows_issue(RowRegs<NCH>& rr, const bf16_t* __restrict__ in, int ld_in, int row0, int R, int K,
+                                           int wave, int lane) {
   const int nch = K >> 3;
-  u32x4 raw[4][NCH];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = row0 + wave * 4 + i;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
-      raw[i][j] = (row < R && c < nch) ? *reinterpret_cast<const u32x4*>(in + (size_t)row * ld_in + c * 8) : u32x4{0u, 0u, 0u, 0u};
+      rr.raw[i][j] = (row < R && c < nch) ? *reinterpret_cast<const u32x4*>(in + (size_t)row * ld_in + c * 8) : u32x4{0u, 0u, 0u, 0u};
     }
   }
+}
+
+template <int NCH>
+__device__ __forceinline__ void rows_finish(const RowRegs<NCH>& rr, int row0, int R, int K, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float eps, bf16_t* __restrict__ keep, char* lds_a,
+                                            int a_stride, int wave, int lane) {
+  const int nch = K >> 3;
+  if (NCH > 2 || gamma == nullptr) {   // the LayerNorm inputs of a decoder layer are d_model wide (NCH <= 2)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int lr = wave * 4 + i, row = row0 + lr;
-    if (gamma == nullptr) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
         const int c = lane + 64 * j;
-        if (c < nch) *reinterpret_cast<u32x4*>(lds_a + lr * a_stride + c * 16) = raw[i][j];
+        if (c < nch) *reinterpret_cast<u32x4*>(lds_a + (wave * 4 + i) * a_stride + c * 16) = rr.raw[i][j];
       }
-      continue;
+    return;
+  }
+  constexpr int NL = NCH > 2 ? 1 : NCH;   // (keeps the dead instantiation small)
+  float v[4][NL][8], s[4], q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      unpack8(rr.raw[i][j], v[i][j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[i] += v[i][j][e];   // chunks past K are zero
     }
-    float v[NCH][8];
-    float s = 0.f;
+  }
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      unpack8(raw[i][j], v[j]);
+  for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]) / (float)K;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[j][e];   // chunks past K are zero
-    }
-    const float mu = wave_sum(s) / (float)K;
-    float q = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    q[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
+    for (int j = 0; j < NL; ++j) {
       if (lane + 64 * j < nch) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float dlt = v[j][e] - mu; q += dlt * dlt; }
+        for (int e = 0; e < 8; ++e) { const float dlt = v[i][j][e] - s[i]; q[i] += dlt * dlt; }
       }
     }
-    const float rs = rsqrtf(wave_sum(q) / (float)K + eps);
+  }
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const int c = lane + 64 * j;
-      if (c < nch) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+  for (int i = 0; i < 4; ++i) q[i] = rsqrtf(wave_sum(q[i]) / (float)K + eps);
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int lr = wave * 4 + i, row = row0 + lr;
         float o[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[e] = (v[j][e] - mu) * rs * g0[e] + b0[e];
-          o[4 + e] = (v[j][4 + e] - mu) * rs * g1[e] + b1[e];
+          o[e] = (v[i][j][e] - s[i]) * q[i] * g0[e] + b0[e];
+          o[4 + e] = (v[i][j][4 + e] - s[i]) * q[i] * g1[e] + b1[e];
         }
         const u32x4 pk = pack8(o);
         *reinterpret_cast<u32x4*>(lds_a + lr * a_stride + c * 16) = pk;
@@ -141,77 +203,139 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// Which (weight slice, row tile) a workgroup takes.  The `tiles` row tiles that read the same weight slice are split
+// into RG groups; a (slice, group) unit runs on ONE XCD (workgroup b runs on XCD b % 8), so a slice crosses the fabric
+// into RG L2s instead of all eight, and the units are dealt round-robin over the XCDs.  Launch 8 * ceil(units / 8) *
+// tiles_per_group workgroups; returns false for the padding ones.
+constexpr int RG = 2;
+__device__ __forceinline__ bool unit_of(int nslices, int tiles, int& slice, int& tile) {
+  const int tpg = (tiles + RG - 1) / RG;
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int u = xcd + 8 * (i / tpg);
+  slice = u / RG;
+  tile = (u % RG) * tpg + i % tpg;
+  return slice < nslices && tile < tiles;
+}
+inline int unit_grid(int nslices, int tiles) {
+  const int tpg = (tiles + RG - 1) / RG;
+  return 8 * ((nslices * RG + 7) / 8) * tpg;
+}
+
 // ------------------------------------------------------------------------------------------ kind 0: projection
-// grid (N / 64, row tiles); wave w owns columns n0 + 16w .. +15
-template <int NCH>
+// one workgroup per (64 * NTW-column block, row tile), see unit_of; wave w owns 16-column tiles w*NTW .. of the block.
+// NTW = 2 (the wide fc1): one 768-deep K block only.
+template <int NCH, int NTW>
 __global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row0 = blockIdx.y * RT, n0 = blockIdx.x * 64 + wave * 16;
+  int nb, rt;
+  if (!unit_of(p.N / (64 * NTW), (p.R + RT - 1) / RT, nb, rt)) return;
+  const int row0 = rt * RT, nt0 = (nb * 4 + wave) * NTW;   // first 16-column tile of this wave
   const int a_stride = (p.K + 8) * 2;
   const int nblk = p.K / KBLK;
+  const int r = lane & 15, g = lane >> 4;
+  const int row = row0 + r;
+  [[maybe_unused]] const int stype = NCH == 6 ? 1 : 0;
+  DSTAMP(stype, 0);
+  RowRegs<NCH> rr;
+  rows_issue<NCH>(rr, p.in, p.ld_in, row0, p.R, p.K, wave, lane);
   WBlock wb[2];
-  load_wblock(wb[0], p.W, p.K, n0, 0, lane);
-  stage_rows<NCH>(p.in, p.ld_in, row0, p.R, p.K, p.gamma, p.beta, p.eps, blockIdx.x == 0 ? p.ln_out : nullptr, smem, a_stride,
-                  wave, lane);
+  load_wblock(wb[0], p.W, p.K, nt0, 0, lane);
+  if (NTW == 2) load_wblock(wb[1], p.W, p.K, nt0 + 1, 0, lane);
+  else if (nblk > 1) load_wblock(wb[1], p.W, p.K, nt0, KBLK, lane);
+  f32x4 bias[NTW];
+  uint2 res[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = (nt0 + t) * 16 + g * 4;
+    bias[t] = *reinterpret_cast<const f32x4*>(p.bias + col);
+    res[t] = (p.residual != nullptr && row < p.R) ? *reinterpret_cast<const uint2*>(p.residual + (size_t)row * p.ld_res + col) : uint2{0u, 0u};
+  }
+  DSTAMP(stype, 1);
+  rows_finish<NCH>(rr, row0, p.R, p.K, p.gamma, p.beta, p.eps, nb == 0 ? p.ln_out : nullptr, smem, a_stride, wave, lane);
   __syncthreads();
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < nblk; b += 2) {   // two K blocks per trip: the register arrays keep compile-time indices
-    if (b + 1 < nblk) load_wblock(wb[1], p.W, p.K, n0, (b + 1) * KBLK, lane);
-    mma_wblock(acc, wb[0], smem, a_stride, b * KBLK, lane);
-    if (b + 1 < nblk) {
-      if (b + 2 < nblk) load_wblock(wb[0], p.W, p.K, n0, (b + 2) * KBLK, lane);
-      mma_wblock(acc, wb[1], smem, a_stride, (b + 1) * KBLK, lane);
+  DSTAMP(stype, 2);
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (NTW == 2) {
+    mma_wblock(acc[0], wb[0], smem, a_stride, 0, lane);
+    mma_wblock(acc[NTW - 1], wb[1], smem, a_stride, 0, lane);
+  } else {
+    for (int b = 0; b < nblk; b += 2) {   // two K blocks per trip: the register arrays keep compile-time indices
+      if (b > 0 && b + 1 < nblk) load_wblock(wb[1], p.W, p.K, nt0, (b + 1) * KBLK, lane);
+      mma_wblock(acc[0], wb[0], smem, a_stride, b * KBLK, lane);
+      if (b + 1 < nblk) {
+        if (b + 2 < nblk) load_wblock(wb[0], p.W, p.K, nt0, (b + 2) * KBLK, lane);
+        mma_wblock(acc[0], wb[1], smem, a_stride, (b + 1) * KBLK, lane);
+      }
     }
   }
-  const int r = lane & 15, g = lane >> 4;
-  const int row = row0 + r, col = n0 + g * 4;
+  DSTAMP(stype, 3);
   if (row >= p.R) return;
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + col);
-  float v[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = acc[e] + bias[e];
-  if (p.act == 1) {
+  for (int t = 0; t < NTW; ++t) {
+    const int col = (nt0 + t) * 16 + g * 4;
+    float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = acc[t][e] + bias[t][e];
+    if (p.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (p.residual != nullptr) {
+      v[0] += lo_bf(res[t].x); v[1] += hi_bf(res[t].x); v[2] += lo_bf(res[t].y); v[3] += hi_bf(res[t].y);
+    }
+    *reinterpret_cast<uint2*>(p.out + (size_t)row * p.ld_out + col) = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
   }
-  if (p.residual != nullptr) {
-    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)row * p.ld_res + col);
-    v[0] += lo_bf(rr.x); v[1] += hi_bf(rr.x); v[2] += lo_bf(rr.y); v[3] += hi_bf(rr.y);
-  }
-  *reinterpret_cast<uint2*>(p.out + (size_t)row * p.ld_out + col) = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  DSTAMP(stype, 4);
 }
 
 // ------------------------------------------------------------------------------------------ kinds 1, 2: attention
-// grid (H, row tiles).  SELF: W rows [q | k | v] (3 x H x 64), wave w owns 16-column tiles 3w .. 3w+2 of the head's
-// 192 columns; the new key / value row goes to the cache at position Tk - 1.  Cross: W rows are the q rows only, wave w
-// owns tile w; keys / values are the cached projections of the encoder output of the row's batch item.
-// Attention: 16 lanes per row -- lane s scores keys s, s+16, ... and then owns output elements 4s .. 4s+3.
-template <bool SELF, int NCH>
+// one workgroup per (head, row tile).  SELF: W rows [q | k | v] (3 x H x 64), wave w owns 16-column tiles 3w .. 3w+2 of
+// the head's 192 columns; the new key / value row goes to the cache at position Tk - 1.  Cross: W rows are the q rows
+// only, wave w owns tile w; keys / values are the cached projections of the encoder output of the row's batch item.
+// Attention: 16 lanes per row.  Scores: 4 lanes per key (16 of the 64 dimensions each), 4 keys per step and KU steps in
+// flight; values: lane s owns output elements 4s .. 4s+3, VU value rows in flight.  (One key per lane and four value
+// rows in flight made the 100-key cross-attention a chain of 32 dependent L2 round trips: 16 us.)
+template <bool SELF>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NTW = SELF ? 3 : 1;          // 16-column tiles per wave
   constexpr int QW = SELF ? 3 * HD : HD;     // projected columns of the head
   constexpr int QS = (QW + 8) * 2;           // LDS row stride of the projected tile
+  constexpr int KU = 5, VU = 10;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.x, row0 = blockIdx.y * RT;
+  int h, rt;
+  if (!unit_of(p.H, (p.R + RT - 1) / RT, h, rt)) return;
+  const int row0 = rt * RT;
   const int d = p.H * HD;
   const int a_stride = (p.K + 8) * 2;
   char* const lds_q = smem + RT * a_stride;
   float* const sc = reinterpret_cast<float*>(lds_q + RT * QS);   // [16][Tk] scores
-  // weight row of tile t (0 .. 11 | 0 .. 3) of this head: part (q | k | v) * d + h * 64 + (t % 4) * 16
-  auto tile_row = [&](int t) { return (t >> 2) * d + h * HD + (t & 3) * 16; };
+  // tile t (0 .. 11 | 0 .. 3) of this head covers weight rows part (q | k | v) * d + h * 64 + (t % 4) * 16
+  auto tile_of = [&](int t) { return ((t >> 2) * d + h * HD) / 16 + (t & 3); };
+  [[maybe_unused]] const int stype = SELF ? 2 : 3;
+  DSTAMP(stype, 0);
+  RowRegs<2> rr;
+  rows_issue<2>(rr, p.in, p.ld_in, row0, p.R, p.K, wave, lane);
   WBlock wb[2];
-  f32x4 acc[NTW];
-  load_wblock(wb[0], p.W, p.K, tile_row(wave * NTW), 0, lane);
-  stage_rows<NCH>(p.in, p.ld_in, row0, p.R, p.K, p.gamma, p.beta, p.eps, h == 0 ? p.ln_out : nullptr, smem, a_stride, wave,
-                  lane);
+  f32x4 acc[NTW], bias[NTW];
+  load_wblock(wb[0], p.W, p.K, tile_of(wave * NTW), 0, lane);
+  if (NTW > 1) load_wblock(wb[1], p.W, p.K, tile_of(wave * NTW + 1), 0, lane);
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int tile = wave * NTW + t;
+    bias[t] = *reinterpret_cast<const f32x4*>(p.bias + (tile >> 2) * d + h * HD + (tile & 3) * 16 + (lane >> 4) * 4);
+  }
+  rows_finish<2>(rr, row0, p.R, p.K, p.gamma, p.beta, p.eps, h == 0 ? p.ln_out : nullptr, smem, a_stride, wave, lane);
   __syncthreads();
+  DSTAMP(stype, 1);
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t + 1 < NTW) load_wblock(wb[(t + 1) & 1], p.W, p.K, tile_row(wave * NTW + t + 1), 0, lane);
     mma_wblock(acc[t], wb[t & 1], smem, a_stride, 0, lane);
+    if (t + 2 < NTW) load_wblock(wb[t & 1], p.W, p.K, tile_of(wave * NTW + t + 2), 0, lane);
   }
   {
     const int r = lane & 15, g = lane >> 4;
@@ -219,10 +343,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
     for (int t = 0; t < NTW; ++t) {
       const int tile = wave * NTW + t, part = tile >> 2;
       const int col = (tile & 3) * 16 + g * 4;           // within the head
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + part * d + h * HD + col);
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[t][e] + bias[e];
+      for (int e = 0; e < 4; ++e) v[e] = acc[t][e] + bias[t][e];
       if (part == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.q_scale;
@@ -235,48 +358,69 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
       }
     }
   }
+  DSTAMP(stype, 2);
   __syncthreads();
+  DSTAMP(stype, 3);
   // ---- attention ----
   const int lr = threadIdx.x >> 4, s = threadIdx.x & 15;
   const int row = row0 + lr;
-  if (row >= p.R) return;   // no barrier below
+  if (row >= p.R) return;   // no workgroup barrier below
   const int crow = p.kv_row != nullptr ? p.kv_row[row] : row;
   const bf16_t* Kc = p.Kc + (size_t)crow * p.Tmax * p.ldc + h * HD;
   const bf16_t* Vc = p.Vc + (size_t)crow * p.Tmax * p.ldc + h * HD;
-  float q[HD];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) unpack8(*reinterpret_cast<const u32x4*>(lds_q + lr * QS + c * 16), q + c * 8);
-  const int t_new = SELF ? p.Tk - 1 : -1;
+  const int64_t* km = p.key_mask != nullptr ? p.key_mask + (size_t)crow * p.mask_ld : nullptr;
+  const int kq = s >> 2, part = s & 3;
+  float qp[16];   // this lane's 16 of the row's 64 query elements
+  unpack8(*reinterpret_cast<const u32x4*>(lds_q + lr * QS + part * 32), qp);
+  unpack8(*reinterpret_cast<const u32x4*>(lds_q + lr * QS + part * 32 + 16), qp + 8);
+  const int Tc = SELF ? p.Tk - 1 : p.Tk;   // rows that live in the cache
   float* const my = sc + (size_t)lr * p.Tk;
   float mx = -INFINITY;
-  for (int t = s; t < p.Tk; t += 16) {
-    float dot = 0.f;
-    if (t == t_new) {
+  for (int t0 = 0; t0 < Tc; t0 += 4 * KU) {
+    u32x4 k0[KU], k1[KU];
+    long long mk[KU];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float k8[8];
-        unpack8(*reinterpret_cast<const u32x4*>(lds_q + lr * QS + HD * 2 + c * 16), k8);
+    for (int u = 0; u < KU; ++u) {
+      const int t = t0 + kq + 4 * u;
+      const bool ok = t < Tc;
+      const bf16_t* kr = Kc + (size_t)(ok ? t : 0) * p.ldc + part * 16;
+      k0[u] = *reinterpret_cast<const u32x4*>(kr);
+      k1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+      mk[u] = km != nullptr ? km[ok ? t : 0] : 1;
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot += q[c * 8 + e] * k8[e];
-      }
-    } else {
-      const bf16_t* krow = Kc + (size_t)t * p.ldc;
-      u32x4 kr[8];
+    for (int u = 0; u < KU; ++u) {
+      const int t = t0 + kq + 4 * u;
+      float k8[16];
+      unpack8(k0[u], k8);
+      unpack8(k1[u], k8 + 8);
+      float dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) kr[c] = *reinterpret_cast<const u32x4*>(krow + c * 8);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float k8[8];
-        unpack8(kr[c], k8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dot += q[c * 8 + e] * k8[e];
+      for (int e = 0; e < 16; ++e) dot += qp[e] * k8[e];
+      dot += __shfl_xor(dot, 1, 16);
+      dot += __shfl_xor(dot, 2, 16);
+      if (mk[u] == 0) dot = -INFINITY;
+      if (t < Tc) {
+        if (part == 0) my[t] = dot;
+        mx = fmaxf(mx, dot);
       }
     }
-    if (p.key_mask != nullptr && p.key_mask[(size_t)crow * p.mask_ld + t] == 0) dot = -INFINITY;
-    my[t] = dot;
+  }
+  if (SELF) {   // the new key: from the projection output in LDS, 4 elements per lane
+    float q4[4], k4[4];
+    const uint2 qv = *reinterpret_cast<const uint2*>(lds_q + lr * QS + s * 8);
+    const uint2 kv = *reinterpret_cast<const uint2*>(lds_q + lr * QS + (HD + s * 4) * 2);
+    q4[0] = lo_bf(qv.x); q4[1] = hi_bf(qv.x); q4[2] = lo_bf(qv.y); q4[3] = hi_bf(qv.y);
+    k4[0] = lo_bf(kv.x); k4[1] = hi_bf(kv.x); k4[2] = lo_bf(kv.y); k4[3] = hi_bf(kv.y);
+    const float dot = group16_sum((q4[0] * k4[0] + q4[1] * k4[1]) + (q4[2] * k4[2] + q4[3] * k4[3]));
+    if (s == 0) my[Tc] = dot;
     mx = fmaxf(mx, dot);
   }
   mx = group16_max(mx);
+  DSTAMP(stype, 4);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the 16 lanes of a row are in one wave
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float l = 0.f;
   for (int t = s; t < p.Tk; t += 16) {
     const float e = (mx == -INFINITY) ? 0.f : __expf(my[t] - mx);
@@ -285,40 +429,36 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   }
   l = group16_sum(l);
   const float inv = l > 0.f ? 1.f / l : 0.f;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the 16 lanes of a row are in one wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float a[4][4];   // four partial sums (independent chains) x four output elements
+  float a[2][4];   // two partial sums (independent chains) x four output elements
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[i][e] = 0.f;
-  const int Tc = SELF ? p.Tk - 1 : p.Tk;   // rows that live in the cache
-  int t = 0;
-  for (; t + 4 <= Tc; t += 4) {
-    uint2 vv[4];
+  for (int t0 = 0; t0 < Tc; t0 += VU) {
+    uint2 vv[VU];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const uint2*>(Vc + (size_t)(t + i) * p.ldc + s * 4);
+    for (int u = 0; u < VU; ++u) vv[u] = *reinterpret_cast<const uint2*>(Vc + (size_t)(t0 + u < Tc ? t0 + u : 0) * p.ldc + s * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float w = my[t + i];
-      a[i][0] += w * lo_bf(vv[i].x); a[i][1] += w * hi_bf(vv[i].x); a[i][2] += w * lo_bf(vv[i].y); a[i][3] += w * hi_bf(vv[i].y);
+    for (int u = 0; u < VU; ++u) {
+      const float w = t0 + u < Tc ? my[t0 + u] : 0.f;
+      a[u & 1][0] += w * lo_bf(vv[u].x); a[u & 1][1] += w * hi_bf(vv[u].x);
+      a[u & 1][2] += w * lo_bf(vv[u].y); a[u & 1][3] += w * hi_bf(vv[u].y);
     }
-  }
-  for (; t < Tc; ++t) {
-    const uint2 vv = *reinterpret_cast<const uint2*>(Vc + (size_t)t * p.ldc + s * 4);
-    const float w = my[t];
-    a[0][0] += w * lo_bf(vv.x); a[0][1] += w * hi_bf(vv.x); a[0][2] += w * lo_bf(vv.y); a[0][3] += w * hi_bf(vv.y);
   }
   if (SELF) {
     const uint2 vv = *reinterpret_cast<const uint2*>(lds_q + lr * QS + (2 * HD + s * 4) * 2);
-    const float w = my[t_new];
+    const float w = my[Tc];
     a[1][0] += w * lo_bf(vv.x); a[1][1] += w * hi_bf(vv.x); a[1][2] += w * lo_bf(vv.y); a[1][3] += w * hi_bf(vv.y);
   }
   float o[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = ((a[0][e] + a[1][e]) + (a[2][e] + a[3][e])) * inv;
+  for (int e = 0; e < 4; ++e) o[e] = (a[0][e] + a[1][e]) * inv;
+  DSTAMP(stype, 5);
   *reinterpret_cast<uint2*>(p.out + (size_t)row * p.ld_out + h * HD + s * 4) = uint2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+  DSTAMP(stype, 6);
 }
 
 template <typename F>
@@ -336,6 +476,7 @@ const char* kmb_decode_block_check(const KmbDecodeBlock& p) {
   if (((uintptr_t)p.in & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.bias & 15) || ((uintptr_t)p.out & 7))
     return "decode block: alignment";
   if ((p.gamma == nullptr) != (p.beta == nullptr)) return "decode block: gamma and beta come together";
+  if (p.gamma && p.K != KBLK) return "decode block: the LayerNorm input must be 768 wide";
   if (p.ln_out && (!p.gamma || ((uintptr_t)p.ln_out & 15))) return "decode block: ln_out needs the LayerNorm";
   if (p.kind == 0) {
     if (p.N <= 0 || (p.N & 63)) return "decode block: N must be a multiple of 64";
@@ -360,15 +501,16 @@ hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream) 
   const int nch = (p.K / 8 + 63) / 64;
   hipError_t e = hipSuccess;
   if (p.kind == 0) {
-    static size_t set[7] = {0, 0, 0, 0, 0, 0, 0};
-#define KMB_PROJ(NCH)                                                                                       \
-  do {                                                                                                      \
-    if (a_bytes > set[NCH]) { e = set_lds(decode_proj_kernel<NCH>, a_bytes); if (e != hipSuccess) return e; set[NCH] = a_bytes; } \
-    hipLaunchKernelGGL((decode_proj_kernel<NCH>), dim3(p.N / 64, tiles), dim3(256), a_bytes, stream, p);    \
+    static size_t set[4] = {0, 0, 0, 0};
+#define KMB_PROJ(SLOT, NCH, NTW)                                                                                      \
+  do {                                                                                                                \
+    if (a_bytes > set[SLOT]) { e = set_lds(decode_proj_kernel<NCH, NTW>, a_bytes); if (e != hipSuccess) return e; set[SLOT] = a_bytes; } \
+    hipLaunchKernelGGL((decode_proj_kernel<NCH, NTW>), dim3(unit_grid(p.N / (64 * NTW), tiles)), dim3(256), a_bytes, stream, p); \
   } while (0)
-    if (nch <= 2) KMB_PROJ(2);
-    else if (nch <= 4) KMB_PROJ(4);
-    else KMB_PROJ(6);
+    if (nch <= 2 && (p.N % 128) == 0 && p.N >= 1536) KMB_PROJ(0, 2, 2);   // the wide fc1: half as many LayerNorm prologues
+    else if (nch <= 2) KMB_PROJ(1, 2, 1);
+    else if (nch <= 4) KMB_PROJ(2, 4, 1);
+    else KMB_PROJ(3, 6, 1);
 #undef KMB_PROJ
     return hipGetLastError();
   }
@@ -376,11 +518,34 @@ hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream) 
   const size_t lds = a_bytes + (size_t)RT * ((self ? 3 * HD : HD) + 8) * 2 + (size_t)RT * p.Tk * sizeof(float);
   static size_t set_s = 0, set_c = 0;
   if (self) {
-    if (lds > set_s) { e = set_lds(decode_attn_kernel<true, 2>, lds); if (e != hipSuccess) return e; set_s = lds; }
-    hipLaunchKernelGGL((decode_attn_kernel<true, 2>), dim3(p.H, tiles), dim3(256), lds, stream, p);
+    if (lds > set_s) { e = set_lds(decode_attn_kernel<true>, lds); if (e != hipSuccess) return e; set_s = lds; }
+    hipLaunchKernelGGL((decode_attn_kernel<true>), dim3(unit_grid(p.H, tiles)), dim3(256), lds, stream, p);
   } else {
-    if (lds > set_c) { e = set_lds(decode_attn_kernel<false, 2>, lds); if (e != hipSuccess) return e; set_c = lds; }
-    hipLaunchKernelGGL((decode_attn_kernel<false, 2>), dim3(p.H, tiles), dim3(256), lds, stream, p);
+    if (lds > set_c) { e = set_lds(decode_attn_kernel<false>, lds); if (e != hipSuccess) return e; set_c = lds; }
+    hipLaunchKernelGGL((decode_attn_kernel<false>), dim3(unit_grid(p.H, tiles)), dim3(256), lds, stream, p);
   }
+  return hipGetLastError();
+}
+
+// packed[i] <- fragment-order copy of W[i] ([N, K] row-major with row stride ld; N % 16 == 0, K % 64 == 0), all in ONE
+// launch (n <= 48 matrices)
+hipError_t kmb_decode_pack_launch(const bf16_t* const* W, const int* ld, const int* N, const int* K, bf16_t* const* packed, int n,
+                                  hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (n > PACK_MAX) return hipErrorInvalidValue;
+  PackArgs a;
+  memset(&a, 0, sizeof(a));
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    if ((N[i] & 15) || (K[i] & 63) || (ld[i] & 7) || ((uintptr_t)W[i] & 15) || ((uintptr_t)packed[i] & 15)) return hipErrorInvalidValue;
+    a.m[i] = PackDesc{W[i], packed[i], ld[i], N[i], K[i], (int)total};
+    total += (long long)N[i] * K[i] / 8;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+  }
+  a.n = n;
+  a.total = (int)total;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();
 }

@@ -143,6 +143,7 @@ struct kmb_handle {
     int cur = 0;
     int32_t *kv_row = nullptr;             // [R] -> batch item
     bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd; float* slab;
+    std::vector<bf16_t*> wp;               // fused decode blocks: fragment-order weight copies, 6 per layer (empty: not eligible)
   } gen;
 
   KmbDrop drop_site(int site, bool train) const {
@@ -1365,8 +1366,15 @@ struct GenLayout {
   std::vector<bf16_t*> ckv, kc[2], vc[2];
   int32_t* kv_row; bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd;
   float* slab;   // split-K partial sums of the residual projections of a decode step
+  std::vector<bf16_t*> wp;   // per layer: self q|k|v, self out, cross q, cross out, fc1, fc2 in fragment order (decode.hip)
 };
 constexpr int GEN_MAX_SPLIT = 12;
+
+// the fused decode blocks need d_model = 768 (one 768-deep weight block per attention projection, 64-wide heads) and an
+// FFN width of 768 .. 3072 in steps of 768
+bool gen_fused_eligible(const kmb_handle* h) {
+  return h->d == 768 && h->Hd * 64 == h->d && (h->Fd % 768) == 0 && h->Fd <= 3072 && (h->Fd % 64) == 0;
+}
 
 size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int nb, int Tmax, int Ntot, GenLayout* out) {
   const int d = h->d, Fe = h->Fe, Fd = h->Fd, Ld = h->cfg.decoder_layers;
@@ -1395,6 +1403,12 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
   g.u = bp.act(R * Fd); g.hh = bp.act(R * Fd);
   g.mean = bp.take<float>(R); g.rstd = bp.take<float>(R);
   g.slab = bp.take<float>((size_t)GEN_MAX_SPLIT * R * d);
+  if (gen_fused_eligible(h)) {
+    const size_t dd = (size_t)d * d, fd = (size_t)Fd * d;
+    const size_t sizes[6] = {3 * dd, dd, dd, dd, fd, fd};
+    for (int l = 0; l < Ld; ++l)
+      for (int i = 0; i < 6; ++i) g.wp.push_back(bp.act(sizes[i]));
+  }
   if (out) *out = g;
   return bp.used();
 }
@@ -1436,13 +1450,28 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.active = true; G.B = B; G.S = S; G.nb = num_beams; G.R = B * num_beams; G.Tmax = max_length; G.bt = bt; G.cur = 0;
   G.ckv = g.ckv; G.kc[0] = g.kc[0]; G.kc[1] = g.kc[1]; G.vc[0] = g.vc[0]; G.vc[1] = g.vc[1];
   G.kv_row = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
-  G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab;
+  G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab; G.wp = g.wp;
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam)
   for (int l = 0; l < Ld; ++l) {
     const LayerP& L = h->dec[l];
     KmbGemm gm = lin_fwd(enc, d, h->wb(L.ca.qkv_w) + (size_t)d * d, h->pf(L.ca.qkv_b) + d, Me, 2 * d, d);
     gm.out_bf16 = G.ckv[l]; gm.ld_out_bf16 = 2 * d;
     KCHK(run_gemm(gm, s));
+  }
+  if (!G.wp.empty()) {   // fragment-order copies of the decoder weights for the fused decode blocks, one launch per 48
+    std::vector<const bf16_t*> src; std::vector<bf16_t*> dst; std::vector<int> ld, nn, kk;
+    for (int l = 0; l < Ld; ++l) {
+      const LayerP& L = h->dec[l];
+      const size_t offs[6] = {L.sa.qkv_w, L.sa.o_w, L.ca.qkv_w, L.ca.o_w, L.fc1_w, L.fc2_w};
+      const int N6[6] = {3 * d, d, d, d, h->Fd, d}, K6[6] = {d, d, d, d, d, h->Fd};
+      for (int i = 0; i < 6; ++i) {
+        src.push_back(h->wb(offs[i])); dst.push_back(G.wp[(size_t)l * 6 + i]); ld.push_back(K6[i]); nn.push_back(N6[i]); kk.push_back(K6[i]);
+      }
+    }
+    for (size_t i0 = 0; i0 < src.size(); i0 += 48) {
+      const int n = (int)std::min<size_t>(48, src.size() - i0);
+      HIPCHK(kmb_decode_pack_launch(src.data() + i0, ld.data() + i0, nn.data() + i0, kk.data() + i0, dst.data() + i0, n, s));
+    }
   }
   g_kvrow_host.resize(G.R);
   for (int i = 0; i < G.R; ++i) g_kvrow_host[i] = i / num_beams;
@@ -1490,11 +1519,11 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     HIPCHK(kmb_ln_fwd_launch(G.z, h->pf(g_off), h->pf(be_off), out, G.mean, G.rstd, R, d, eps, s));
     return 0;
   };
-  // Fused form (csrc/decode.hip): six launches per layer, the LayerNorms folded into the consumers.  Needs d_model = 768
-  // (one 768-deep weight block per attention projection) and an FFN width of 768 .. 3072 in steps of 768; other
-  // configurations, and KMB_GEN_FUSED=0, take the launch-per-operation path below.
+  // Fused form (csrc/decode.hip): six launches per layer, the LayerNorms folded into the consumers, weights read from
+  // the fragment-order copies made by kmb_gen_begin.  Configurations gen_fused_eligible() rejects, and KMB_GEN_FUSED=0,
+  // take the launch-per-operation path below.
   const char* fused_env = getenv("KMB_GEN_FUSED");   // read per call: tests compare the two paths in one process
-  const bool fused = !(fused_env && fused_env[0] == '0') && d == 768 && h->Hd * 64 == d && (F % 768) == 0 && F <= 3072;
+  const bool fused = !(fused_env && fused_env[0] == '0') && !G.wp.empty();
   if (fused) {
     const bf16_t* zin = G.x0;                       // layer input: normalised rows (layer 0) or pre-LayerNorm sums
     const float *lg = nullptr, *lb = nullptr;       // ... and the LayerNorm that turns them into the layer input
@@ -1509,30 +1538,30 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       KmbDecodeBlock b;
       memset(&b, 0, sizeof(b));
       b.kind = 1; b.in = zin; b.ld_in = d; b.gamma = lg; b.beta = lb; b.eps = eps; b.ln_out = lg ? G.x1 : nullptr;
-      b.W = h->wb(L.sa.qkv_w); b.bias = h->pf(L.sa.qkv_b); b.R = R; b.K = d; b.N = 3 * d; b.out = G.o; b.ld_out = d;
+      b.W = G.wp[(size_t)l * 6 + 0]; b.bias = h->pf(L.sa.qkv_b); b.R = R; b.K = d; b.N = 3 * d; b.out = G.o; b.ld_out = d;
       b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.kc[G.cur][l]; b.Vc = G.vc[G.cur][l]; b.Tmax = G.Tmax; b.ldc = d; b.Tk = step + 1;
       KCHK(block(b));
       const bf16_t* xres = lg ? G.x1 : zin;
       memset(&b, 0, sizeof(b));
-      b.kind = 0; b.in = G.o; b.ld_in = d; b.W = h->wb(L.sa.o_w); b.bias = h->pf(L.sa.o_b); b.R = R; b.K = d; b.N = d;
+      b.kind = 0; b.in = G.o; b.ld_in = d; b.W = G.wp[(size_t)l * 6 + 1]; b.bias = h->pf(L.sa.o_b); b.R = R; b.K = d; b.N = d;
       b.residual = xres; b.ld_res = d; b.out = G.z; b.ld_out = d;
       KCHK(block(b));
       memset(&b, 0, sizeof(b));
       b.kind = 2; b.in = G.z; b.ld_in = d; b.gamma = h->pf(L.sa.ln_g); b.beta = h->pf(L.sa.ln_b); b.eps = eps; b.ln_out = G.y;
-      b.W = h->wb(L.ca.qkv_w); b.bias = h->pf(L.ca.qkv_b); b.R = R; b.K = d; b.N = d; b.out = G.o; b.ld_out = d;
+      b.W = G.wp[(size_t)l * 6 + 2]; b.bias = h->pf(L.ca.qkv_b); b.R = R; b.K = d; b.N = d; b.out = G.o; b.ld_out = d;
       b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.ckv[l]; b.Vc = G.ckv[l] + d; b.Tmax = G.S; b.ldc = 2 * d; b.Tk = G.S;
       b.kv_row = G.kv_row; b.key_mask = G.bt.attention_mask; b.mask_ld = G.S;
       KCHK(block(b));
       memset(&b, 0, sizeof(b));
-      b.kind = 0; b.in = G.o; b.ld_in = d; b.W = h->wb(L.ca.o_w); b.bias = h->pf(L.ca.o_b); b.R = R; b.K = d; b.N = d;
+      b.kind = 0; b.in = G.o; b.ld_in = d; b.W = G.wp[(size_t)l * 6 + 3]; b.bias = h->pf(L.ca.o_b); b.R = R; b.K = d; b.N = d;
       b.residual = G.y; b.ld_res = d; b.out = G.z; b.ld_out = d;
       KCHK(block(b));
       memset(&b, 0, sizeof(b));
       b.kind = 0; b.in = G.z; b.ld_in = d; b.gamma = h->pf(L.ca.ln_g); b.beta = h->pf(L.ca.ln_b); b.eps = eps; b.ln_out = G.y;
-      b.W = h->wb(L.fc1_w); b.bias = h->pf(L.fc1_b); b.R = R; b.K = d; b.N = F; b.act = 1; b.out = G.hh; b.ld_out = F;
+      b.W = G.wp[(size_t)l * 6 + 4]; b.bias = h->pf(L.fc1_b); b.R = R; b.K = d; b.N = F; b.act = 1; b.out = G.hh; b.ld_out = F;
       KCHK(block(b));
       memset(&b, 0, sizeof(b));
-      b.kind = 0; b.in = G.hh; b.ld_in = F; b.W = h->wb(L.fc2_w); b.bias = h->pf(L.fc2_b); b.R = R; b.K = F; b.N = d;
+      b.kind = 0; b.in = G.hh; b.ld_in = F; b.W = G.wp[(size_t)l * 6 + 5]; b.bias = h->pf(L.fc2_b); b.R = R; b.K = F; b.N = d;
       b.residual = G.y; b.ld_res = d; b.out = G.z; b.ld_out = d;
       KCHK(block(b));
       zin = G.z; lg = h->pf(L.ln_g); lb = h->pf(L.ln_b);

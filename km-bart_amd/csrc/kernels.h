@@ -24,6 +24,10 @@ hipError_t kmb_attn_decode_launch(const KmbAttnDecode& p, hipStream_t stream);
 // fused [LayerNorm ->] projection [-> attention] block of a decode step (R = batch x beams rows)
 const char* kmb_decode_block_check(const KmbDecodeBlock& p);
 hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream);
+// packed[i] <- copy of the row-major weight W[i] ([N, K], row stride ld) in the MFMA-fragment order the decode blocks read
+// (N % 16 == 0, K % 64 == 0), n <= 48 matrices in one launch
+hipError_t kmb_decode_pack_launch(const bf16_t* const* W, const int* ld, const int* N, const int* K, bf16_t* const* packed, int n,
+                                  hipStream_t stream);
 
 // ---------------------------------------------------------------- norm.hip
 
@@ -92,8 +96,8 @@ hipError_t kmb_ce_bf16_launch(const bf16_t* logits, int ldv, int V, const int64_
 hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
                                   hipStream_t stream);
 // generation: per row log_softmax over V then top-k of (logp + add[row]); writes k (value, index) pairs
-hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out,
-                                 hipStream_t stream);
+hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out, int eos,
+                                 float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, hipStream_t stream);
 // ban_token >= 0: that token's score is -inf AFTER the normalisation (min_length, transformers 3.0.2
 // postprocess_next_token_scores)
 hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,

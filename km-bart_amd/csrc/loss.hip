@@ -488,11 +488,20 @@ __global__ __launch_bounds__(1024) void logsoftmax_topk_reg_kernel(const float* 
 // torch.topk over the [nb * V] scores of mixins.py's beam step returns, restricted to each beam's own top k (enough:
 // the best k overall contain at most k from any beam).  Output, packed for ONE device-to-host copy:
 // out[(b*k + j)*2] = score bits (fp32), out[(b*k + j)*2 + 1] = beam * V + token.
+//
+// next_scores != null: the same launch also picks the beams of the next step, so that the decode loop needs no host
+// round trip: in candidate order, the first nb candidates whose token is not EOS (transformers 3.0.2
+// _generate_beam_search: an EOS candidate either closes a hypothesis or is skipped, it never continues a beam) ->
+// next_scores / next_tokens / next_beam_idx [b*nb + i] (beam index = row of the KV cache to continue from).  What the
+// host does with the finished hypotheses and with `done` batch items does not feed back into the other rows.
 __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx,
-                                                        int nb, int k, int V, int32_t* __restrict__ out) {
+                                                        int nb, int k, int V, int32_t* __restrict__ out, int eos,
+                                                        float* __restrict__ next_scores, int64_t* __restrict__ next_tokens,
+                                                        int32_t* __restrict__ next_beam_idx) {
   __shared__ float sv[256];
   __shared__ unsigned char taken[256];
   const int b = blockIdx.x, lane = threadIdx.x, n = nb * k;   // n <= 256
+  int n_sel = 0;   // lane 0
   for (int i = lane; i < n; i += 64) { sv[i] = val[(size_t)b * n + i]; taken[i] = 0; }
   __syncthreads();
   for (int j = 0; j < k; ++j) {
@@ -509,12 +518,22 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
       if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
     }
     if (lane == 0) {
-      const int beam = bi / k;
+      const int beam = bi / k, tok = idx[(size_t)b * n + bi];
       out[((size_t)b * k + j) * 2] = __float_as_int(bv);
-      out[((size_t)b * k + j) * 2 + 1] = beam * V + idx[(size_t)b * n + bi];
+      out[((size_t)b * k + j) * 2 + 1] = beam * V + tok;
       taken[bi] = 1;
+      if (next_scores != nullptr && n_sel < nb && tok != eos) {
+        const size_t o = (size_t)b * nb + n_sel++;
+        next_scores[o] = bv; next_tokens[o] = tok; next_beam_idx[o] = b * nb + beam;
+      }
     }
     __syncthreads();
+  }
+  if (lane == 0 && next_scores != nullptr) {
+    for (; n_sel < nb; ++n_sel) {   // cannot happen with k >= 2 * nb (at most one EOS candidate per beam); keep the rows defined
+      const size_t o = (size_t)b * nb + n_sel;
+      next_scores[o] = -1e9f; next_tokens[o] = eos >= 0 ? eos : 0; next_beam_idx[o] = b * nb;
+    }
   }
 }
 
@@ -564,10 +583,12 @@ hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int r
   return hipGetLastError();
 }
 
-hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out,
-                                 hipStream_t stream) {
+hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out, int eos,
+                                 float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, hipStream_t stream) {
   if (B <= 0) return hipSuccess;
   if (nb * k > 256 || k <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, stream, val, idx, nb, k, V, out);
+  if (next_scores != nullptr && (!next_tokens || !next_beam_idx)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, stream, val, idx, nb, k, V, out, eos, next_scores, next_tokens,
+                     next_beam_idx);
   return hipGetLastError();
 }

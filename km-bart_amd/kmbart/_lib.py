@@ -114,6 +114,7 @@ PROTOTYPES = {
     "kmb_gen_step": (C.c_int, [c_p, c_p, C.c_int, c_p, c_p]),
     "kmb_gen_reorder": (C.c_int, [c_p, c_p, C.c_int, c_p]),
     "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),
+    "kmb_beam_merge_select": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p]),
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kmb_gemm_shared_device": (C.c_int, [C.c_int]),
@@ -128,6 +129,7 @@ PROTOTYPES = {
     "kmb_op_attn_bwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_decode": (C.c_int, [C.POINTER(KmbAttnDecode), c_p]),
     "kmb_op_decode_block": (C.c_int, [C.POINTER(KmbDecodeBlock), c_p]),
+    "kmb_op_decode_pack": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, c_p]),
     "kmb_op_ln_fwd": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int, C.c_int, f32, c_p]),
     "kmb_op_ln_bwd_scratch": (i64, [C.c_int, C.c_int]),
     "kmb_op_ln_bwd": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, C.POINTER(KmbDrop), C.POINTER(KmbDrop), c_p, c_p,

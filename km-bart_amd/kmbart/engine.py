@@ -362,6 +362,30 @@ class Engine:
                                           int(self.config.vocab_size), ptr(out), _stream()))
         return out
 
+    def pinned(self, shape, dtype):
+        """A cached page-locked host tensor (asynchronous device-to-host staging)."""
+        key = (tuple(shape), dtype)
+        cache = self.__dict__.setdefault("_pinned", {})
+        if key not in cache:
+            cache[key] = torch.empty(shape, dtype=dtype, pin_memory=True)
+        return cache[key]
+
+    def beam_step(self, logits, num_beams, k, add, force_token=-1, ban_token=-1, eos_token=-1):
+        """beam_candidates plus the next step's beams chosen on the device (kmb_beam_merge_select): returns
+        (cand int32 [B, k, 2], next_scores fp32 [R], next_tokens int64 [R], next_beam_idx int32 [R]); nothing is
+        copied to the host.  `add` may be one of the returned next_scores (stream order makes that safe)."""
+        R = logits.shape[0]
+        B = R // num_beams
+        val, idx = self.logsoftmax_topk(logits, k, add=add, force_token=force_token, ban_token=ban_token)
+        cand = torch.empty((B, k, 2), dtype=torch.int32, device=self.device)
+        nscore = torch.empty((R,), dtype=torch.float32, device=self.device)
+        ntok = torch.empty((R,), dtype=torch.int64, device=self.device)
+        nidx = torch.empty((R,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_beam_merge_select(ptr(val), ptr(idx), B, int(num_beams), int(k), int(self.config.vocab_size),
+                                                 ptr(cand), int(eos_token), ptr(nscore), ptr(ntok), ptr(nidx), _stream()))
+        return cand, nscore, ntok, nidx
+
     def logsoftmax_topk(self, logits, k, add=None, force_token=-1, ban_token=-1):
         R = logits.shape[0]
         val = torch.empty((R, k), dtype=torch.float32, device=self.device)

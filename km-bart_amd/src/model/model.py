@@ -436,38 +436,11 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         done = [False] * B
         k = 2 * num_beams
         last_tokens = torch.full((R,), decoder_start_token_id, dtype=torch.long, device=dev)
-        while cur_len < max_length:
-            logits = eng.gen_step(last_tokens, cur_len - 1)
-            # min_length: transformers 3.0.2 postprocess_next_token_scores sets the EOS score to -inf AFTER log_softmax
-            ban = eos_token_id if (eos_token_id is not None and cur_len < min_length) else -1
-            add = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
-            if do_sample:
-                # beam-search multinomial sampling (HF 3.0.2 _generate_beam_search, do_sample branch, reached from
-                # mixins.py:336-361 with generate_text's --do_sample/--top_p/--top_k and --num_beams): no forced BOS/EOS;
-                # 2*num_beams draws per batch item from softmax over the beams' filtered (log-prob + beam score) / T
-                sc = torch.log_softmax(logits[:, :V].float(), dim=-1)
-                if ban >= 0:
-                    sc[:, ban] = -float("inf")
-                sc = sc + add[:, None]
-                if temperature != 1.0:
-                    sc = sc / temperature
-                sc = _top_k_top_p_filtering(sc, top_k=top_k, top_p=top_p, min_tokens_to_keep=2).view(B, num_beams * V)
-                drawn = sampler(torch.softmax(sc, dim=-1), k)
-                ns = torch.gather(sc, -1, drawn)
-                ns, order = torch.sort(ns, descending=True, dim=1)
-                next_scores = ns.cpu().tolist()
-                next_tokens = torch.gather(drawn, -1, order).cpu().tolist()
-            else:
-                force = -1
-                if cur_len == 1:
-                    force = cfg.bos_token_id          # adjust_logits_during_generation, mixins.py:400-405
-                if cur_len == max_length - 1 and eos_token_id is not None:
-                    force = eos_token_id
-                # per beam row: log_softmax + beam score, top 2*num_beams; per batch item: the best 2*num_beams of the
-                # union (== top 2*num_beams over num_beams * V: each row contributed its own best 2*num_beams); one D2H copy
-                cand = eng.beam_candidates(logits, num_beams, k, add=add, force_token=force, ban_token=ban).cpu()
-                next_scores = cand[:, :, 0].contiguous().view(torch.float32).tolist()
-                next_tokens = cand[:, :, 1].tolist()
+        eos = -1 if eos_token_id is None else int(eos_token_id)
+
+        def bookkeeping(next_scores, next_tokens, step_len):
+            """One step of the reference's host-side beam bookkeeping (transformers 3.0.2 _generate_beam_search) from the
+            step's sorted candidates; returns (new_scores, new_tokens, new_idx) and updates hyps / done."""
             new_scores, new_tokens, new_idx = [], [], []
             for b in range(B):
                 if done[b]:
@@ -491,8 +464,78 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                         n_sent += 1
                     if n_sent == num_beams:
                         break
-                done[b] = done[b] or hyps[b].is_done(max(next_scores[b]), cur_len)
+                done[b] = done[b] or hyps[b].is_done(max(next_scores[b]), step_len)
                 assert n_sent == num_beams, "Beam should always be full"
+            return new_scores, new_tokens, new_idx
+
+        if not do_sample:
+            # Greedy beam search, pipelined: the device picks the next step's beams itself (kmb_beam_merge_select: the
+            # first num_beams non-EOS candidates, exactly what the bookkeeping below sends on), so step t+1 is enqueued
+            # before the host has seen step t.  The host replays the reference's bookkeeping one step behind from the
+            # candidates (one small pinned copy per step): hypotheses, `done`, and the decision to stop -- a stop costs
+            # one decode step that is thrown away.  A `done` batch item keeps decoding on the device (the reference feeds
+            # it pad tokens); its rows feed nothing that is read.
+            staging = eng.pinned((max_length, B, k, 2), torch.int32)
+            beam_scores_dev = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
+            pending = None
+
+            def replay(item):
+                nonlocal beam_scores, seqs
+                slot, ev, step_len = item
+                ev.synchronize()
+                c = staging[slot]
+                ns = c[:, :, 0].contiguous().view(torch.float32).tolist()
+                nt = c[:, :, 1].tolist()
+                new_scores, new_tokens, new_idx = bookkeeping(ns, nt, step_len)
+                if all(done):
+                    return True
+                beam_scores = new_scores
+                seqs = [seqs[j] + [t] for j, t in zip(new_idx, new_tokens)]
+                return False
+
+            while cur_len < max_length:
+                logits = eng.gen_step(last_tokens, cur_len - 1)
+                ban = eos if (eos >= 0 and cur_len < min_length) else -1
+                force = -1
+                if cur_len == 1:
+                    force = cfg.bos_token_id          # adjust_logits_during_generation, mixins.py:400-405
+                if cur_len == max_length - 1 and eos_token_id is not None:
+                    force = eos_token_id
+                cand, beam_scores_dev, last_tokens, beam_idx = eng.beam_step(
+                    logits, num_beams, k, beam_scores_dev, force_token=force, ban_token=ban, eos_token=eos)
+                eng.gen_reorder(beam_idx, cur_len - 1)   # _reorder_cache, mixins.py:419-434
+                staging[cur_len - 1].copy_(cand, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                if pending is not None and replay(pending):
+                    pending = None
+                    break
+                pending = (cur_len - 1, ev, cur_len)
+                cur_len += 1
+            if pending is not None:
+                replay(pending)
+        while do_sample and cur_len < max_length:
+            # beam-search multinomial sampling (HF 3.0.2 _generate_beam_search, do_sample branch, reached from
+            # mixins.py:336-361 with generate_text's --do_sample/--top_p/--top_k and --num_beams): no forced BOS/EOS;
+            # 2*num_beams draws per batch item from softmax over the beams' filtered (log-prob + beam score) / T.
+            # The draw happens in torch, so this branch keeps the reference's step-by-step host loop.
+            logits = eng.gen_step(last_tokens, cur_len - 1)
+            # min_length: transformers 3.0.2 postprocess_next_token_scores sets the EOS score to -inf AFTER log_softmax
+            ban = eos_token_id if (eos_token_id is not None and cur_len < min_length) else -1
+            add = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
+            sc = torch.log_softmax(logits[:, :V].float(), dim=-1)
+            if ban >= 0:
+                sc[:, ban] = -float("inf")
+            sc = sc + add[:, None]
+            if temperature != 1.0:
+                sc = sc / temperature
+            sc = _top_k_top_p_filtering(sc, top_k=top_k, top_p=top_p, min_tokens_to_keep=2).view(B, num_beams * V)
+            drawn = sampler(torch.softmax(sc, dim=-1), k)
+            ns = torch.gather(sc, -1, drawn)
+            ns, order = torch.sort(ns, descending=True, dim=1)
+            next_scores = ns.cpu().tolist()
+            next_tokens = torch.gather(drawn, -1, order).cpu().tolist()
+            new_scores, new_tokens, new_idx = bookkeeping(next_scores, next_tokens, cur_len)
             if all(done):
                 break
             beam_scores = new_scores

@@ -32,9 +32,16 @@ def _ln(z, g, b, eps=1e-5):
     return (z - mu) * torch.rsqrt(var + eps) * g + b
 
 
+def _pack(W):
+    out = torch.empty_like(W)
+    check(_lib.load().kmb_op_decode_pack(ptr(W), W.stride(0), W.shape[0], W.shape[1], ptr(out), stream()))
+    return out
+
+
 def _block(**kw):
     b = KmbDecodeBlock()
     keep = []
+    kw["W"] = _pack(kw["W"])     # the blocks read the weight in fragment order
     for k, v in kw.items():
         if torch.is_tensor(v):
             keep.append(v)
@@ -47,7 +54,7 @@ def _block(**kw):
 
 @pytest.mark.parametrize("R,K,N,ln,act,res", [(320, 768, 768, False, 0, True), (320, 768, 3072, True, 1, False),
                                                (320, 3072, 768, False, 0, True), (37, 768, 768, True, 0, True),
-                                               (5, 1536, 128, True, 0, False)])
+                                               (5, 1536, 128, False, 0, False), (40, 768, 1536, True, 1, False)])
 def test_projection_block(R, K, N, ln, act, res):
     torch.manual_seed(R + K + N)
     x = bf(torch.randn(R, K, device=DEV) * 1.5 + 0.3)
@@ -130,7 +137,7 @@ def test_cross_attention_block(B, nb, S):
     out = torch.zeros(R, d, dtype=torch.bfloat16, device=DEV)
     ln_out = torch.zeros(R, d, dtype=torch.bfloat16, device=DEV)
     Vc = ckv.view(-1)[d:]
-    _block(kind=2, inp=z, ld_in=d, gamma=g, beta=be, eps=1e-5, ln_out=ln_out, W=W, bias=bias, R=R, K=d, N=d, out=out,
+    _block(kind=2, inp=z, ld_in=d, gamma=g, beta=be, eps=1e-5, ln_out=ln_out, W=W[:d], bias=bias, R=R, K=d, N=d, out=out,
            ld_out=d, H=H, q_scale=0.125, Kc=ckv, Vc=Vc, Tmax=S, ldc=2 * d, Tk=S, kv_row=kv_row, key_mask=mask, mask_ld=S)
     x = ln_out.float()
     q = bf((x @ W[:d].float().t() + bias[:d]) * 0.125).float().view(R, H, 64)

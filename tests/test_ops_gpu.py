@@ -491,3 +491,38 @@ def test_beam_merge_matches_torch_topk_over_all_beams():
         # every candidate is distinct
         for b in range(B):
             assert len(set(got_ids[b].tolist())) == k
+
+
+def test_beam_merge_select_picks_the_beams_the_host_bookkeeping_sends_on():
+    """kmb_beam_merge_select: same candidates as kmb_beam_merge, and the next step's (score, token, cache row) per beam
+    = the first num_beams non-EOS candidates in order -- the reference's selection loop (transformers 3.0.2
+    _generate_beam_search) -- also when EOS is the best token of several beams and on a forced-EOS step."""
+    lib = _lib.load()
+    B, nb, V, ld, eos = 6, 5, 50320, 50432, 2
+    k = 2 * nb
+    logits = torch.zeros((B * nb, ld), device=DEV)
+    logits[:, :V] = rnd(B * nb, V, seed=93) * 3
+    logits[0:3, eos] = 40.0                          # EOS on top of three beams of item 0
+    logits[7, eos] = 40.0
+    add = rnd(B * nb, seed=94)
+    for force in (-1, eos):
+        val = torch.empty((B * nb, k), device=DEV)
+        idx = torch.empty((B * nb, k), dtype=torch.int32, device=DEV)
+        check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, B * nb, ptr(add), force, -1, k, ptr(val), ptr(idx), stream()))
+        ref = torch.empty((B, k, 2), dtype=torch.int32, device=DEV)
+        check(lib.kmb_beam_merge(ptr(val), ptr(idx), B, nb, k, V, ptr(ref), stream()))
+        out = torch.empty((B, k, 2), dtype=torch.int32, device=DEV)
+        ns = torch.empty(B * nb, device=DEV)
+        nt = torch.empty(B * nb, dtype=torch.int64, device=DEV)
+        ni = torch.empty(B * nb, dtype=torch.int32, device=DEV)
+        check(lib.kmb_beam_merge_select(ptr(val), ptr(idx), B, nb, k, V, ptr(out), eos, ptr(ns), ptr(nt), ptr(ni), stream()))
+        assert torch.equal(out, ref)
+        scores = ref[:, :, 0].contiguous().view(torch.float32).cpu()
+        ids = ref[:, :, 1].cpu()
+        for b in range(B):
+            want = [(float(scores[b, r]), int(ids[b, r]) % V, b * nb + int(ids[b, r]) // V) for r in range(k)
+                    if int(ids[b, r]) % V != eos][:nb]
+            assert len(want) == nb
+            got = list(zip(ns[b * nb:(b + 1) * nb].tolist(), nt[b * nb:(b + 1) * nb].tolist(), ni[b * nb:(b + 1) * nb].tolist()))
+            for (ws, wt, wi), (gs, gt, gi) in zip(want, got):
+                assert (wt, wi) == (gt, gi) and (ws == gs or (ws != ws and gs != gs))
