@@ -130,6 +130,9 @@ typedef struct KmbDecodeBlock {
   int32_t Tmax, ldc, Tk;
   const int32_t* kv_row;                    /* kind 2: cache row (batch item) of every row */
   const int64_t* key_mask; int32_t mask_ld; /* kind 2: key t of cache row c is masked when key_mask[c*mask_ld + t] == 0 */
+  int32_t kv_group;                         /* kind 2, optional: a promise that kv_row[r] == r / kv_group (beam rows of a
+                                             * batch item are consecutive): lets a workgroup stage each item's keys /
+                                             * values once for all of its rows.  0: no promise. */
 } KmbDecodeBlock;
 
 typedef struct KmbDrop { uint32_t thr16; uint32_t seed; float scale; } KmbDrop;
@@ -233,6 +236,12 @@ int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stre
  * normalisation (min_length: transformers 3.0.2 postprocess_next_token_scores acts on the log-probabilities) */
 int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
                         int k, float* out_val, int32_t* out_idx, void* stream);
+/* the same with a scratch buffer of kmb_logsoftmax_topk_scratch(rows) floats: every row is split over four workgroups and
+ * combined by a second launch -- the form the decode loop uses (a few hundred rows); results are identical up to the
+ * rounding of the log-sum-exp */
+int64_t kmb_logsoftmax_topk_scratch(int rows);
+int kmb_logsoftmax_topk_ws(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
+                           int k, float* out_val, int32_t* out_idx, float* scratch, int64_t scratch_floats, void* stream);
 /* one beam-search step's candidate selection (mixins.py beam loop: topk over num_beams * V): per batch item the best k of
  * its beams' top-k lists; out[B][k][2] int32 = {fp32 score bits, beam * V + token} */
 int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out, void* stream);

@@ -129,7 +129,14 @@ int kmb_beam_merge_select(const float* val, const int32_t* idx, int B, int num_b
 }
 int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
                         int k, float* out_val, int32_t* out_idx, void* stream) {
-  return hipfail(kmb_logsoftmax_topk_launch(logits, ld, V, rows, add, force_token, ban_token, k, out_val, out_idx, (hipStream_t)stream), "logsoftmax_topk");
+  return hipfail(kmb_logsoftmax_topk_launch(logits, ld, V, rows, add, force_token, ban_token, k, out_val, out_idx, nullptr, 0,
+                                            (hipStream_t)stream), "logsoftmax_topk");
 }
+int kmb_logsoftmax_topk_ws(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
+                           int k, float* out_val, int32_t* out_idx, float* scratch, int64_t scratch_floats, void* stream) {
+  return hipfail(kmb_logsoftmax_topk_launch(logits, ld, V, rows, add, force_token, ban_token, k, out_val, out_idx, scratch,
+                                            scratch_floats > 0 ? (size_t)scratch_floats : 0, (hipStream_t)stream), "logsoftmax_topk");
+}
+int64_t kmb_logsoftmax_topk_scratch(int rows) { return (int64_t)kmb_logsoftmax_topk_scratch_floats(rows); }
 
 }  // extern "C"

@@ -110,12 +110,25 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
 // in-order memory queue; rows_finish normalises (gamma != null: LayerNorm with the arithmetic of ln_fwd_kernel, the
 // four rows' reductions interleaved) and writes LDS; `keep` != null: the normalised rows also go to memory.
 template <int NCH>   // 16-byte chunks per lane: K / 8 / 64 rounded up
-struct RowRegs { u32x4 raw[4][NCH]; };
+struct RowRegs {
+  u32x4 raw[4][NCH];
+  f32x4 gb[NCH <= 2 ? NCH : 1][4];   // gamma, beta of this lane's columns (requested with the rows: behind the weight
+};                                   // fragments they would wait for the whole weight stream to arrive)
 
 template <int NCH>
 __device__ __forceinline__ void rows_issue(RowRegs<NCH>& rr, const bf16_t* __restrict__ in, int ld_in, int row0, int R, int K,
-                                           int wave, int lane) {
+                                           const float* __restrict__ gamma, const float* __restrict__ beta, int wave, int lane) {
   const int nch = K >> 3;
+  if (NCH <= 2 && gamma != nullptr) {
+#pragma unroll
+    for (int j = 0; j < (NCH <= 2 ? NCH : 1); ++j) {
+      const int c = lane + 64 * j < nch ? lane + 64 * j : 0;
+      rr.gb[j][0] = *reinterpret_cast<const f32x4*>(gamma + c * 8);
+      rr.gb[j][1] = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+      rr.gb[j][2] = *reinterpret_cast<const f32x4*>(beta + c * 8);
+      rr.gb[j][3] = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = row0 + wave * 4 + i;
@@ -173,8 +186,7 @@ __device__ __forceinline__ void rows_finish(const RowRegs<NCH>& rr, int row0, in
   for (int j = 0; j < NL; ++j) {
     const int c = lane + 64 * j;
     if (c < nch) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+      const f32x4 g0 = rr.gb[j][0], g1 = rr.gb[j][1], b0 = rr.gb[j][2], b1 = rr.gb[j][3];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int lr = wave * 4 + i, row = row0 + lr;
@@ -238,11 +250,17 @@ __global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p
   [[maybe_unused]] const int stype = NCH == 6 ? 1 : 0;
   DSTAMP(stype, 0);
   RowRegs<NCH> rr;
-  rows_issue<NCH>(rr, p.in, p.ld_in, row0, p.R, p.K, wave, lane);
-  WBlock wb[2];
+  rows_issue<NCH>(rr, p.in, p.ld_in, row0, p.R, p.K, p.gamma, p.beta, wave, lane);
+  // NTW = 1: up to three K blocks are requested before anything is waited for (these launches have at most one
+  // workgroup per CU, so the 288 registers cost no occupancy).  NTW = 2 (fc1: two workgroups per CU have to fit, 256
+  // registers each): the second tile's fragments are requested after the LayerNorm, when its registers are free.
+  constexpr int NWB = NTW == 2 ? 2 : 3;
+  WBlock wb[NWB];
   load_wblock(wb[0], p.W, p.K, nt0, 0, lane);
-  if (NTW == 2) load_wblock(wb[1], p.W, p.K, nt0 + 1, 0, lane);
-  else if (nblk > 1) load_wblock(wb[1], p.W, p.K, nt0, KBLK, lane);
+  if (NTW == 1) {
+    if (nblk > 1) load_wblock(wb[1], p.W, p.K, nt0, KBLK, lane);
+    if (nblk > 2) load_wblock(wb[NWB - 1], p.W, p.K, nt0, 2 * KBLK, lane);
+  }
   f32x4 bias[NTW];
   uint2 res[NTW];
 #pragma unroll
@@ -253,6 +271,10 @@ __global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p
   }
   DSTAMP(stype, 1);
   rows_finish<NCH>(rr, row0, p.R, p.K, p.gamma, p.beta, p.eps, nb == 0 ? p.ln_out : nullptr, smem, a_stride, wave, lane);
+  if (NTW == 2) {
+    __builtin_amdgcn_sched_barrier(0);   // (keeps the second tile's 96 registers out of the LayerNorm's live range)
+    load_wblock(wb[1], p.W, p.K, nt0 + 1, 0, lane);
+  }
   __syncthreads();
   DSTAMP(stype, 2);
   f32x4 acc[NTW];
@@ -261,15 +283,12 @@ __global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p
   if (NTW == 2) {
     mma_wblock(acc[0], wb[0], smem, a_stride, 0, lane);
     mma_wblock(acc[NTW - 1], wb[1], smem, a_stride, 0, lane);
-  } else {
-    for (int b = 0; b < nblk; b += 2) {   // two K blocks per trip: the register arrays keep compile-time indices
-      if (b > 0 && b + 1 < nblk) load_wblock(wb[1], p.W, p.K, nt0, (b + 1) * KBLK, lane);
-      mma_wblock(acc[0], wb[0], smem, a_stride, b * KBLK, lane);
-      if (b + 1 < nblk) {
-        if (b + 2 < nblk) load_wblock(wb[0], p.W, p.K, nt0, (b + 2) * KBLK, lane);
-        mma_wblock(acc[0], wb[1], smem, a_stride, (b + 1) * KBLK, lane);
-      }
-    }
+  } else {   // K blocks 0 .. 3 (host: K <= 3072); slot of block b: b % 3
+    mma_wblock(acc[0], wb[0], smem, a_stride, 0, lane);
+    if (nblk > 3) load_wblock(wb[0], p.W, p.K, nt0, 3 * KBLK, lane);
+    if (nblk > 1) mma_wblock(acc[0], wb[1], smem, a_stride, KBLK, lane);
+    if (nblk > 2) mma_wblock(acc[0], wb[NWB - 1], smem, a_stride, 2 * KBLK, lane);
+    if (nblk > 3) mma_wblock(acc[0], wb[0], smem, a_stride, 3 * KBLK, lane);
   }
   DSTAMP(stype, 3);
   if (row >= p.R) return;
@@ -298,9 +317,19 @@ __global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p
 // Attention: 16 lanes per row.  Scores: 4 lanes per key (16 of the 64 dimensions each), 4 keys per step and KU steps in
 // flight; values: lane s owns output elements 4s .. 4s+3, VU value rows in flight.  (One key per lane and four value
 // rows in flight made the 100-key cross-attention a chain of 32 dependent L2 round trips: 16 us.)
-template <bool SELF>
+// KVLDS (cross-attention with kv_group >= 4 beams per batch item): the 16 rows of a tile belong to at most four batch
+// items, and the rows of an item attend to the SAME cached keys / values.  The workgroup copies those (<= 4 x Tk x 256
+// bytes of this head) into LDS once -- whole 128-byte lines, requested right behind the weight fragments so they land
+// during the projection -- instead of every row fetching its own 32-byte pieces from L2 (16 x Tk x 256 bytes in
+// quarter-line requests: the request rate of the vector memory pipe made that 19 of the block's 26 us).
+constexpr int KV_ITEMS = 4;      // batch items a 16-row tile can touch when kv_group >= 4
+constexpr int NKV = 15;          // 16-byte chunks per thread and operand: KV_ITEMS * Tk * 8 <= NKV * 256  (Tk <= 120)
+constexpr int KS = 144;          // LDS row stride of a staged key row (128 + 16: spreads the 4-keys-per-step reads)
+
+template <bool SELF, bool KVLDS>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(!(SELF && KVLDS), "the self-attention cache is per row");
   constexpr int NTW = SELF ? 3 : 1;          // 16-column tiles per wave
   constexpr int QW = SELF ? 3 * HD : HD;     // projected columns of the head
   constexpr int QS = (QW + 8) * 2;           // LDS row stride of the projected tile
@@ -318,15 +347,46 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   [[maybe_unused]] const int stype = SELF ? 2 : 3;
   DSTAMP(stype, 0);
   RowRegs<2> rr;
-  rows_issue<2>(rr, p.in, p.ld_in, row0, p.R, p.K, wave, lane);
-  WBlock wb[2];
+  rows_issue<2>(rr, p.in, p.ld_in, row0, p.R, p.K, p.gamma, p.beta, wave, lane);
+  WBlock wb[NTW];   // every tile's fragments in flight at once (one workgroup per CU: the registers are free)
   f32x4 acc[NTW], bias[NTW];
-  load_wblock(wb[0], p.W, p.K, tile_of(wave * NTW), 0, lane);
-  if (NTW > 1) load_wblock(wb[1], p.W, p.K, tile_of(wave * NTW + 1), 0, lane);
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) load_wblock(wb[t], p.W, p.K, tile_of(wave * NTW + t), 0, lane);
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int tile = wave * NTW + t;
     bias[t] = *reinterpret_cast<const f32x4*>(p.bias + (tile >> 2) * d + h * HD + (tile & 3) * 16 + (lane >> 4) * 4);
+  }
+  // KVLDS: this thread's chunks of the tile's keys / values (chunk c = tid + 256 i: staged row c / 8, 16-byte piece c % 8)
+  [[maybe_unused]] u32x4 kreg[KVLDS ? NKV : 1], vreg[KVLDS ? NKV : 1];
+  [[maybe_unused]] int first_item = 0, kv_rows = 0;
+  char* const lds_k = reinterpret_cast<char*>(sc) + (((size_t)RT * p.Tk * sizeof(float) + 15) & ~(size_t)15);
+  char* const lds_v = lds_k + (size_t)KV_ITEMS * p.Tk * KS;
+  float* const lds_m = reinterpret_cast<float*>(lds_v + (size_t)KV_ITEMS * p.Tk * 128);   // 0 / -inf per staged key
+  [[maybe_unused]] long long mreg[2] = {1, 1};   // key mask of staged rows tid, tid + 256 (KV_ITEMS * Tk <= 512)
+  if (KVLDS) {
+    const int last_row = row0 + RT - 1 < p.R ? row0 + RT - 1 : p.R - 1;
+    first_item = row0 / p.kv_group;
+    kv_rows = (last_row / p.kv_group - first_item + 1) * p.Tk;     // staged rows: item-major, Tk per item
+    int rowi = threadIdx.x >> 3;
+    int li = rowi / p.Tk, t = rowi - li * p.Tk;
+    const int seg = threadIdx.x & 7;
+#pragma unroll
+    for (int i = 0; i < NKV; ++i) {
+      const bool ok = rowi < kv_rows;
+      const size_t off = ((size_t)(first_item + (ok ? li : 0)) * p.Tmax + (ok ? t : 0)) * p.ldc + h * HD + seg * 8;
+      kreg[i] = *reinterpret_cast<const u32x4*>(p.Kc + off);
+      vreg[i] = *reinterpret_cast<const u32x4*>(p.Vc + off);
+      rowi += 32; t += 32;
+      while (t >= p.Tk) { t -= p.Tk; ++li; }
+    }
+    if (p.key_mask != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int mr = threadIdx.x + 256 * i;
+        if (mr < kv_rows) mreg[i] = p.key_mask[(size_t)(first_item + mr / p.Tk) * p.mask_ld + mr % p.Tk];
+      }
+    }
   }
   rows_finish<2>(rr, row0, p.R, p.K, p.gamma, p.beta, p.eps, h == 0 ? p.ln_out : nullptr, smem, a_stride, wave, lane);
   __syncthreads();
@@ -334,8 +394,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_wblock(acc[t], wb[t & 1], smem, a_stride, 0, lane);
-    if (t + 2 < NTW) load_wblock(wb[t & 1], p.W, p.K, tile_of(wave * NTW + t + 2), 0, lane);
+    mma_wblock(acc[t], wb[t], smem, a_stride, 0, lane);
   }
   {
     const int r = lane & 15, g = lane >> 4;
@@ -358,6 +417,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
       }
     }
   }
+  if (KVLDS) {
+    int rowi = threadIdx.x >> 3;
+    const int seg = threadIdx.x & 7;
+#pragma unroll
+    for (int i = 0; i < NKV; ++i) {
+      if (rowi < kv_rows) {
+        *reinterpret_cast<u32x4*>(lds_k + (size_t)rowi * KS + seg * 16) = kreg[i];
+        *reinterpret_cast<u32x4*>(lds_v + (size_t)rowi * 128 + seg * 16) = vreg[i];
+      }
+      rowi += 32;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (threadIdx.x + 256 * i < kv_rows) lds_m[threadIdx.x + 256 * i] = mreg[i] == 0 ? -INFINITY : 0.f;
+  }
   DSTAMP(stype, 2);
   __syncthreads();
   DSTAMP(stype, 3);
@@ -365,10 +439,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   const int lr = threadIdx.x >> 4, s = threadIdx.x & 15;
   const int row = row0 + lr;
   if (row >= p.R) return;   // no workgroup barrier below
-  const int crow = p.kv_row != nullptr ? p.kv_row[row] : row;
+  const int crow = KVLDS ? row / p.kv_group : p.kv_row != nullptr ? p.kv_row[row] : row;
   const bf16_t* Kc = p.Kc + (size_t)crow * p.Tmax * p.ldc + h * HD;
   const bf16_t* Vc = p.Vc + (size_t)crow * p.Tmax * p.ldc + h * HD;
-  const int64_t* km = p.key_mask != nullptr ? p.key_mask + (size_t)crow * p.mask_ld : nullptr;
+  [[maybe_unused]] const char* const my_k = lds_k + (size_t)(crow - first_item) * p.Tk * KS;
+  [[maybe_unused]] const char* const my_v = lds_v + (size_t)(crow - first_item) * p.Tk * 128;
+  [[maybe_unused]] const float* const my_m = lds_m + (size_t)(crow - first_item) * p.Tk;
+  const int64_t* km = (!KVLDS && p.key_mask != nullptr) ? p.key_mask + (size_t)crow * p.mask_ld : nullptr;
   const int kq = s >> 2, part = s & 3;
   float qp[16];   // this lane's 16 of the row's 64 query elements
   unpack8(*reinterpret_cast<const u32x4*>(lds_q + lr * QS + part * 32), qp);
@@ -379,13 +456,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   for (int t0 = 0; t0 < Tc; t0 += 4 * KU) {
     u32x4 k0[KU], k1[KU];
     long long mk[KU];
+    [[maybe_unused]] float madd[KU];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int t = t0 + kq + 4 * u;
       const bool ok = t < Tc;
-      const bf16_t* kr = Kc + (size_t)(ok ? t : 0) * p.ldc + part * 16;
-      k0[u] = *reinterpret_cast<const u32x4*>(kr);
-      k1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+      if (KVLDS) {
+        const char* kr = my_k + (size_t)(ok ? t : 0) * KS + part * 32;
+        k0[u] = *reinterpret_cast<const u32x4*>(kr);
+        k1[u] = *reinterpret_cast<const u32x4*>(kr + 16);
+        madd[u] = my_m[ok ? t : 0];
+      } else {
+        const bf16_t* kr = Kc + (size_t)(ok ? t : 0) * p.ldc + part * 16;
+        k0[u] = *reinterpret_cast<const u32x4*>(kr);
+        k1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+      }
       mk[u] = km != nullptr ? km[ok ? t : 0] : 1;
     }
 #pragma unroll
@@ -399,7 +484,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
       for (int e = 0; e < 16; ++e) dot += qp[e] * k8[e];
       dot += __shfl_xor(dot, 1, 16);
       dot += __shfl_xor(dot, 2, 16);
-      if (mk[u] == 0) dot = -INFINITY;
+      if (KVLDS) dot += madd[u];
+      else if (mk[u] == 0) dot = -INFINITY;
       if (t < Tc) {
         if (part == 0) my[t] = dot;
         mx = fmaxf(mx, dot);
@@ -440,7 +526,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   for (int t0 = 0; t0 < Tc; t0 += VU) {
     uint2 vv[VU];
 #pragma unroll
-    for (int u = 0; u < VU; ++u) vv[u] = *reinterpret_cast<const uint2*>(Vc + (size_t)(t0 + u < Tc ? t0 + u : 0) * p.ldc + s * 4);
+    for (int u = 0; u < VU; ++u) {
+      const int t = t0 + u < Tc ? t0 + u : 0;
+      vv[u] = KVLDS ? *reinterpret_cast<const uint2*>(my_v + (size_t)t * 128 + s * 8)
+                    : *reinterpret_cast<const uint2*>(Vc + (size_t)t * p.ldc + s * 4);
+    }
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
       const float w = t0 + u < Tc ? my[t0 + u] : 0.f;
@@ -487,7 +577,8 @@ const char* kmb_decode_block_check(const KmbDecodeBlock& p) {
     if (p.K != KBLK) return "decode block: attention kinds take K = 768";
     if (p.N != (p.kind == 1 ? 3 : 1) * p.H * HD) return "decode block: N must be the q|k|v (self) or q (cross) rows of H heads";
     if ((p.ldc & 7) || ((uintptr_t)p.Kc & 15) || ((uintptr_t)p.Vc & 15)) return "decode block: cache alignment";
-    if (p.kind == 1 && (p.kv_row || p.key_mask)) return "decode block: the self-attention cache is per row and unmasked";
+    if (p.kind == 1 && (p.kv_row || p.key_mask || p.kv_group)) return "decode block: the self-attention cache is per row and unmasked";
+    if (p.kv_group < 0) return "decode block: kv_group";
     if ((size_t)RT * p.Tk * 4 > 96 * 1024) return "decode block: Tk too large for the score tile";
   } else {
     return "decode block: kind";
@@ -515,14 +606,18 @@ hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream) 
     return hipGetLastError();
   }
   const bool self = p.kind == 1;
-  const size_t lds = a_bytes + (size_t)RT * ((self ? 3 * HD : HD) + 8) * 2 + (size_t)RT * p.Tk * sizeof(float);
-  static size_t set_s = 0, set_c = 0;
+  const size_t lds = a_bytes + (size_t)RT * ((self ? 3 * HD : HD) + 8) * 2 + (((size_t)RT * p.Tk * sizeof(float) + 15) & ~(size_t)15);
+  const size_t lds_kv = lds + (size_t)KV_ITEMS * p.Tk * (KS + 128 + sizeof(float));
+  static size_t set_s = 0, set_c = 0, set_l = 0;
   if (self) {
-    if (lds > set_s) { e = set_lds(decode_attn_kernel<true>, lds); if (e != hipSuccess) return e; set_s = lds; }
-    hipLaunchKernelGGL((decode_attn_kernel<true>), dim3(unit_grid(p.H, tiles)), dim3(256), lds, stream, p);
+    if (lds > set_s) { e = set_lds(decode_attn_kernel<true, false>, lds); if (e != hipSuccess) return e; set_s = lds; }
+    hipLaunchKernelGGL((decode_attn_kernel<true, false>), dim3(unit_grid(p.H, tiles)), dim3(256), lds, stream, p);
+  } else if (p.kv_group >= 4 && KV_ITEMS * p.Tk * 8 <= NKV * 256 && lds_kv <= 160 * 1024) {
+    if (lds_kv > set_l) { e = set_lds(decode_attn_kernel<false, true>, lds_kv); if (e != hipSuccess) return e; set_l = lds_kv; }
+    hipLaunchKernelGGL((decode_attn_kernel<false, true>), dim3(unit_grid(p.H, tiles)), dim3(256), lds_kv, stream, p);
   } else {
-    if (lds > set_c) { e = set_lds(decode_attn_kernel<false>, lds); if (e != hipSuccess) return e; set_c = lds; }
-    hipLaunchKernelGGL((decode_attn_kernel<false>), dim3(unit_grid(p.H, tiles)), dim3(256), lds, stream, p);
+    if (lds > set_c) { e = set_lds(decode_attn_kernel<false, false>, lds); if (e != hipSuccess) return e; set_c = lds; }
+    hipLaunchKernelGGL((decode_attn_kernel<false, false>), dim3(unit_grid(p.H, tiles)), dim3(256), lds, stream, p);
   }
   return hipGetLastError();
 }

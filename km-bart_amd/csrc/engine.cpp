@@ -1550,7 +1550,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       b.kind = 2; b.in = G.z; b.ld_in = d; b.gamma = h->pf(L.sa.ln_g); b.beta = h->pf(L.sa.ln_b); b.eps = eps; b.ln_out = G.y;
       b.W = G.wp[(size_t)l * 6 + 2]; b.bias = h->pf(L.ca.qkv_b); b.R = R; b.K = d; b.N = d; b.out = G.o; b.ld_out = d;
       b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.ckv[l]; b.Vc = G.ckv[l] + d; b.Tmax = G.S; b.ldc = 2 * d; b.Tk = G.S;
-      b.kv_row = G.kv_row; b.key_mask = G.bt.attention_mask; b.mask_ld = G.S;
+      b.kv_row = G.kv_row; b.key_mask = G.bt.attention_mask; b.mask_ld = G.S; b.kv_group = G.nb;   // kv_row[i] = i / nb
       KCHK(block(b));
       memset(&b, 0, sizeof(b));
       b.kind = 0; b.in = G.o; b.ld_in = d; b.W = G.wp[(size_t)l * 6 + 3]; b.bias = h->pf(L.ca.o_b); b.R = R; b.K = d; b.N = d;

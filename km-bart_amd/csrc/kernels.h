@@ -100,9 +100,12 @@ hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, in
                                  float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, hipStream_t stream);
 // ban_token >= 0: that token's score is -inf AFTER the normalisation (min_length, transformers 3.0.2
 // postprocess_next_token_scores)
+// scratch (optional, kmb_logsoftmax_topk_scratch_floats(rows) floats): rows are split over four workgroups each and
+// combined by a second launch (decode-sized problems); without it one workgroup per row
+size_t kmb_logsoftmax_topk_scratch_floats(int rows);
 hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
                                       int force_token, int ban_token, int k, float* out_val, int32_t* out_idx,
-                                      hipStream_t stream);
+                                      float* scratch, size_t scratch_floats, hipStream_t stream);
 
 // ---------------------------------------------------------------- optim.hip
 // transformers-3.0.2 AdamW on a flat fp32 arena; also refreshes the bf16 mirror of the parameters

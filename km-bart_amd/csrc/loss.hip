@@ -483,6 +483,166 @@ __global__ __launch_bounds__(1024) void logsoftmax_topk_reg_kernel(const float* 
   }
 }
 
+// ---- two-launch form for decode-sized problems (a few hundred rows x 50k columns) ----
+// One workgroup per row leaves the launch as long as the slowest CU: 320 rows on 256 CUs = 64 CUs with two 200 KB rows
+// to pull in (41 us before the first candidate is out), and every one of the k selection rounds is a workgroup-wide
+// arg-max plus a rescan of the winner's 52 registers (5.5 us per round: 90 us at k = 10).  Here a row is split into
+// TOPK_PARTS parts, one 256-thread workgroup each (1280 workgroups: every CU streams): a part computes its own
+// (max, sum-exp) and its own k best -- per wave, with no workgroup barrier in the rounds: every thread keeps its best
+// TWO keys, so popping a winner is a register move and the 52-element rescan only runs for a thread that wins a second
+// time -- and a second, tiny launch combines the parts of a row: log-sum-exp from the (max, sum) pairs, k best of the
+// TOPK_PARTS * k candidates.  Same (value desc, index asc) order, same outputs.
+constexpr int TOPK_PARTS = 4, TOPK_KMAX = 16, TOPK_PW = 2 + 2 * TOPK_KMAX;   // words per (row, part) record
+
+__device__ __forceinline__ unsigned long long topk_key(float v, int i) {
+  const uint32_t b = __float_as_uint(v);
+  const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)ord << 32) | (uint32_t)(0x7fffffff - i);
+}
+__device__ __forceinline__ float topk_key_value(unsigned long long key) {
+  const uint32_t ord = (uint32_t)(key >> 32);
+  return __uint_as_float((ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, o, 64);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+    const unsigned long long v2 = ((unsigned long long)hi << 32) | lo;
+    v = v2 > v ? v2 : v;
+  }
+  return v;
+}
+
+template <int NV>   // float4 chunks per thread: chunks per part <= NV * 256
+__global__ __launch_bounds__(256) void topk_part_kernel(const float* __restrict__ logits, int ldv, int V, int ban, int k,
+                                                        int chunks_per_part, float* __restrict__ part) {
+  __shared__ float sh[8];
+  __shared__ unsigned long long cand[4][TOPK_KMAX];
+  const int p = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* row = logits + (size_t)r * ldv;
+  f32x4 x[NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = tid + 256 * j;
+    const int i = (p * chunks_per_part + c) * 4;
+    if (c < chunks_per_part && i < ldv) {
+      x[j] = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (i + e >= V) x[j][e] = -INFINITY;
+        m = fmaxf(m, x[j][e]);
+      }
+    } else {
+      x[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) sh[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  float sum = 0.f;
+  if (m != -INFINITY) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += __expf(x[j][e] - m);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) sh[4 + wave] = sum;
+  // this thread's two best keys (0 = none); the banned token is excluded AFTER the normalisation above
+  unsigned long long b1 = 0ull, b2 = 0ull;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = (p * chunks_per_part + tid + 256 * j) * 4 + e;
+      const unsigned long long key = (tid + 256 * j < chunks_per_part && i < V && i != ban) ? topk_key(x[j][e], i) : 0ull;
+      const unsigned long long lo = key < b1 ? key : b1;
+      b1 = key > b1 ? key : b1;
+      b2 = lo > b2 ? lo : b2;
+    }
+  bool b2_known = true;
+  for (int jr = 0; jr < k; ++jr) {
+    const unsigned long long wk = wave_max_u64(b1);
+    if (lane == 0) cand[wave][jr] = wk;
+    if (wk == 0ull) continue;
+    const bool mine = b1 == wk;   // indices are unique: exactly one lane
+    if (__builtin_amdgcn_ballot_w64(mine && !b2_known) != 0ull) {   // wave-uniform: a second win of the same thread
+      unsigned long long nk = 0ull;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = (p * chunks_per_part + tid + 256 * j) * 4 + e;
+          unsigned long long key = (tid + 256 * j < chunks_per_part && i < V && i != ban) ? topk_key(x[j][e], i) : 0ull;
+          key = key < wk ? key : 0ull;
+          nk = key > nk ? key : nk;
+        }
+      if (mine) b1 = nk;
+    } else if (mine) {
+      b1 = b2;
+      b2_known = false;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = part + ((size_t)r * TOPK_PARTS + p) * TOPK_PW;
+    if (lane == 0) { out[0] = m; out[1] = (sh[4] + sh[5]) + (sh[6] + sh[7]); }
+    unsigned long long key = lane < 4 * k ? cand[lane / k][lane % k] : 0ull;   // 4 k <= 64
+    for (int jr = 0; jr < k; ++jr) {
+      const unsigned long long wk = wave_max_u64(key);
+      if (lane == 0) {
+        out[2 + 2 * jr] = wk != 0ull ? topk_key_value(wk) : -INFINITY;
+        reinterpret_cast<int32_t*>(out)[3 + 2 * jr] = wk != 0ull ? 0x7fffffff - (int)(uint32_t)wk : 0x7fffffff;
+      }
+      if (key == wk) key = 0ull;
+    }
+  }
+}
+
+// one wave per row: combine the parts
+__global__ __launch_bounds__(256) void topk_combine_kernel(const float* __restrict__ part, int rows, const float* __restrict__ add,
+                                                           int force_token, int k, float* __restrict__ out_val,
+                                                           int32_t* __restrict__ out_idx) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float a = add != nullptr ? add[r] : 0.f;
+  if (force_token >= 0) {   // every other logit is -inf: log_softmax is 0 at the forced token (ties in index order)
+    for (int j = lane; j < k; j += 64) {
+      out_val[(size_t)r * k + j] = j == 0 ? a : -INFINITY;
+      out_idx[(size_t)r * k + j] = j == 0 ? force_token : (j - 1 < force_token ? j - 1 : j);
+    }
+    return;
+  }
+  const float* rec = part + (size_t)r * TOPK_PARTS * TOPK_PW;
+  float M = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < TOPK_PARTS; ++q) M = fmaxf(M, rec[q * TOPK_PW]);
+  float S = 0.f;
+#pragma unroll
+  for (int q = 0; q < TOPK_PARTS; ++q) {
+    const float mq = rec[q * TOPK_PW];
+    if (mq != -INFINITY) S += rec[q * TOPK_PW + 1] * __expf(mq - M);
+  }
+  const float lse = M + __logf(S);
+  unsigned long long key = 0ull;
+  if (lane < TOPK_PARTS * k) {
+    const float* c = rec + (lane / k) * TOPK_PW + 2 + 2 * (lane % k);
+    const int i = reinterpret_cast<const int32_t*>(c)[1];
+    if (i != 0x7fffffff) key = topk_key(c[0], i);
+  }
+  for (int jr = 0; jr < k; ++jr) {
+    const unsigned long long wk = wave_max_u64(key);
+    if (lane == 0) {
+      out_val[(size_t)r * k + jr] = ((wk != 0ull ? topk_key_value(wk) : -INFINITY) - lse) + a;
+      out_idx[(size_t)r * k + jr] = wk != 0ull ? 0x7fffffff - (int)(uint32_t)wk : 0x7fffffff;
+    }
+    if (key == wk) key = 0ull;
+  }
+}
+
 // Beam search, per batch item: the best `k` of the nb * k candidates its beams produced (val / idx from
 // logsoftmax_topk_kernel, rows b*nb .. b*nb + nb - 1), ordered by (value desc, candidate position asc) -- what
 // torch.topk over the [nb * V] scores of mixins.py's beam step returns, restricted to each beam's own top k (enough:
@@ -572,10 +732,20 @@ hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_
   return hipGetLastError();
 }
 
+size_t kmb_logsoftmax_topk_scratch_floats(int rows) { return (size_t)(rows > 0 ? rows : 0) * TOPK_PARTS * TOPK_PW; }
+
 hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int rows, const float* add,
                                       int force_token, int ban_token, int k, float* out_val, int32_t* out_idx,
-                                      hipStream_t stream) {
+                                      float* scratch, size_t scratch_floats, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
+  const int chunks = (ldv / 4 + TOPK_PARTS - 1) / TOPK_PARTS;
+  if (scratch != nullptr && scratch_floats >= kmb_logsoftmax_topk_scratch_floats(rows) && k >= 1 && k <= TOPK_KMAX &&
+      (ldv & 3) == 0 && ((uintptr_t)logits & 15) == 0 && chunks <= 13 * 256 && rows <= 65535) {
+    if (force_token < 0)
+      hipLaunchKernelGGL((topk_part_kernel<13>), dim3(TOPK_PARTS, rows), dim3(256), 0, stream, logits, ldv, V, ban_token, k, chunks, scratch);
+    hipLaunchKernelGGL(topk_combine_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, scratch, rows, add, force_token, k, out_val, out_idx);
+    return hipGetLastError();
+  }
   if (ldv <= 13 * 4096 && (ldv & 3) == 0 && ((uintptr_t)logits & 15) == 0)
     hipLaunchKernelGGL((logsoftmax_topk_reg_kernel<13>), dim3(rows), dim3(1024), 0, stream, logits, ldv, V, add, force_token, ban_token, k, out_val, out_idx);
   else

@@ -68,7 +68,7 @@ class KmbDecodeBlock(C.Structure):
     _fields_ = [("kind", i32), ("in_", c_p), ("ld_in", i32), ("gamma", c_p), ("beta", c_p), ("eps", f32), ("ln_out", c_p),
                 ("W", c_p), ("bias", c_p), ("R", i32), ("K", i32), ("N", i32), ("act", i32), ("residual", c_p),
                 ("ld_res", i32), ("out", c_p), ("ld_out", i32), ("H", i32), ("q_scale", f32), ("Kc", c_p), ("Vc", c_p),
-                ("Tmax", i32), ("ldc", i32), ("Tk", i32), ("kv_row", c_p), ("key_mask", c_p), ("mask_ld", i32)]
+                ("Tmax", i32), ("ldc", i32), ("Tk", i32), ("kv_row", c_p), ("key_mask", c_p), ("mask_ld", i32), ("kv_group", i32)]
 
 
 class KmbDrop(C.Structure):
@@ -116,6 +116,9 @@ PROTOTYPES = {
     "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),
     "kmb_beam_merge_select": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p]),
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p]),
+    "kmb_logsoftmax_topk_scratch": (C.c_int64, [C.c_int]),
+    "kmb_logsoftmax_topk_ws": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p,
+                                         C.c_int64, c_p]),
     "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kmb_gemm_shared_device": (C.c_int, [C.c_int]),
     "kmb_debug_trace": (C.c_int, [C.c_int]),

@@ -390,8 +390,12 @@ class Engine:
         R = logits.shape[0]
         val = torch.empty((R, k), dtype=torch.float32, device=self.device)
         idx = torch.empty((R, k), dtype=torch.int32, device=self.device)
+        nscr = int(self.lib.kmb_logsoftmax_topk_scratch(R))
+        scr = self.__dict__.get("_topk_scratch")
+        if scr is None or scr.numel() < nscr:
+            scr = self._topk_scratch = torch.empty(nscr, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            check(self.lib.kmb_logsoftmax_topk(ptr(logits), logits.stride(0), int(self.config.vocab_size), R,
-                                               ptr(add), int(force_token), int(ban_token), int(k), ptr(val), ptr(idx),
-                                               _stream()))
+            check(self.lib.kmb_logsoftmax_topk_ws(ptr(logits), logits.stride(0), int(self.config.vocab_size), R,
+                                                  ptr(add), int(force_token), int(ban_token), int(k), ptr(val), ptr(idx),
+                                                  ptr(scr), scr.numel(), _stream()))
         return val, idx

@@ -120,8 +120,11 @@ def test_self_attention_block(R, Tk):
     assert e < 6e-3
 
 
-@pytest.mark.parametrize("B,nb,S", [(64, 5, 100), (3, 4, 37)])
-def test_cross_attention_block(B, nb, S):
+@pytest.mark.parametrize("B,nb,S,grouped", [(64, 5, 100, True), (64, 5, 100, False), (3, 4, 37, True), (7, 6, 120, True),
+                                            (5, 3, 50, True), (2, 5, 130, True)])
+def test_cross_attention_block(B, nb, S, grouped):
+    """grouped: kv_group = beams per item (keys / values staged once per item in LDS when the tile allows it);
+    3 beams per item and 130 keys fall back to per-row reads inside the same call."""
     torch.manual_seed(B + S)
     H, d, R = 12, 768, B * nb
     z = bf(torch.randn(R, d, device=DEV))
@@ -138,7 +141,7 @@ def test_cross_attention_block(B, nb, S):
     ln_out = torch.zeros(R, d, dtype=torch.bfloat16, device=DEV)
     Vc = ckv.view(-1)[d:]
     _block(kind=2, inp=z, ld_in=d, gamma=g, beta=be, eps=1e-5, ln_out=ln_out, W=W[:d], bias=bias, R=R, K=d, N=d, out=out,
-           ld_out=d, H=H, q_scale=0.125, Kc=ckv, Vc=Vc, Tmax=S, ldc=2 * d, Tk=S, kv_row=kv_row, key_mask=mask, mask_ld=S)
+           ld_out=d, H=H, q_scale=0.125, Kc=ckv, Vc=Vc, Tmax=S, ldc=2 * d, Tk=S, kv_row=kv_row, key_mask=mask, mask_ld=S, kv_group=nb if grouped else 0)
     x = ln_out.float()
     q = bf((x @ W[:d].float().t() + bias[:d]) * 0.125).float().view(R, H, 64)
     Kf = ckv[:, :, :d].float().view(B, S, H, 64)[kv_row.long()]
@@ -147,7 +150,7 @@ def test_cross_attention_block(B, nb, S):
     s = s.masked_fill(mask[kv_row.long()][:, None, :] == 0, float("-inf"))
     o = torch.einsum("rht,rthe->rhe", torch.softmax(s, -1), Vf).reshape(R, d)
     e = rel_err(out, o)
-    print(f"[decode cross-attention B={B} beams={nb} S={S}] rel {e:.2e}")
+    print(f"[decode cross-attention B={B} beams={nb} S={S} grouped={grouped}] rel {e:.2e}")
     assert e < 6e-3
 
 

@@ -386,10 +386,24 @@ def test_cross_entropy_and_grad():
     assert float(dl[:, V:].float().abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("V,ld", [(50320, 50432), (60000, 60032)])   # register-resident kernel / 256-thread kernel
-def test_logsoftmax_topk(V, ld):
+class _TopkWithScratch:
+    """kmb_logsoftmax_topk_ws behind kmb_logsoftmax_topk's signature (the decode loop's two-launch form)."""
+
+    def __init__(self, lib, rows):
+        self.lib = lib
+        self.scr = torch.empty(int(lib.kmb_logsoftmax_topk_scratch(rows)), device=DEV)
+
+    def kmb_logsoftmax_topk(self, *a):
+        return self.lib.kmb_logsoftmax_topk_ws(*a[:-1], ptr(self.scr), self.scr.numel(), a[-1])
+
+
+@pytest.mark.parametrize("V,ld,ws", [(50320, 50432, False), (60000, 60032, False), (50320, 50432, True)])
+def test_logsoftmax_topk(V, ld, ws):
+    """one workgroup per row: register-resident kernel / 256-thread kernel; ws: rows split over four workgroups + combine"""
     lib = _lib.load()
     rows, k = 10, 10
+    if ws:
+        lib = _TopkWithScratch(lib, rows)
     logits = torch.zeros((rows, ld), device=DEV)
     logits[:, :V] = rnd(rows, V, seed=61) * 4
     add = rnd(rows, seed=62)
@@ -430,6 +444,19 @@ def test_logsoftmax_topk(V, ld):
     logits[:, own] = 9.0 + torch.arange(12, device=DEV).float()
     logits[:, 7001] = logits[:, own[11]]
     logits[:, 301] = logits[:, own[11]]
+    logits[:, own[10]] = -float("inf")
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, -1, k, ptr(val), ptr(idx), stream()))
+    lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
+    order = torch.sort(lp, dim=1, descending=True, stable=True)[1][:, :k]
+    assert torch.equal(idx.long(), order)
+    assert torch.allclose(val, torch.gather(lp, 1, order), atol=1e-4)
+    # and for the split form's ownership (thread t of a part holds the float4 chunks t, t + 256, ... of that part): twelve
+    # winners inside ONE thread's chunks (its two cached keys run out: the rescan path), ties in other parts, a masked winner
+    logits[:, :V] = rnd(rows, V, seed=65)
+    own = torch.tensor([4 * (5 + 256 * j) + (j % 4) for j in range(12)], device=DEV)
+    logits[:, own] = 9.0 + torch.arange(12, device=DEV).float()
+    logits[:, 30001] = logits[:, own[11]]
+    logits[:, 45001] = logits[:, own[11]]
     logits[:, own[10]] = -float("inf")
     check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, -1, k, ptr(val), ptr(idx), stream()))
     lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
