@@ -237,8 +237,7 @@ inline int unit_grid(int nslices, int tiles) {
 // one workgroup per (64 * NTW-column block, row tile), see unit_of; wave w owns 16-column tiles w*NTW .. of the block.
 // NTW = 2 (the wide fc1): one 768-deep K block only.
 template <int NCH, int NTW>
-__global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void decode_proj_body(const KmbDecodeBlock& p, char* smem) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int nb, rt;
   if (!unit_of(p.N / (64 * NTW), (p.R + RT - 1) / RT, nb, rt)) return;
@@ -310,6 +309,17 @@ __global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p
   DSTAMP(stype, 4);
 }
 
+template <int NCH>
+__global__ __launch_bounds__(256) void decode_proj_kernel(const KmbDecodeBlock p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  decode_proj_body<NCH, 1>(p, smem);
+}
+// the wide fc1: 480 workgroups, two per CU -> two waves per SIMD, 256 registers each
+__global__ __launch_bounds__(256, 2) void decode_proj_wide_kernel(const KmbDecodeBlock p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  decode_proj_body<2, 2>(p, smem);
+}
+
 // ------------------------------------------------------------------------------------------ kinds 1, 2: attention
 // one workgroup per (head, row tile).  SELF: W rows [q | k | v] (3 x H x 64), wave w owns 16-column tiles 3w .. 3w+2 of
 // the head's 192 columns; the new key / value row goes to the cache at position Tk - 1.  Cross: W rows are the q rows
@@ -356,6 +366,27 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   for (int t = 0; t < NTW; ++t) {
     const int tile = wave * NTW + t;
     bias[t] = *reinterpret_cast<const f32x4*>(p.bias + (tile >> 2) * d + h * HD + (tile & 3) * 16 + (lane >> 4) * 4);
+  }
+  // SELF: the first 4 * KU cached keys and VU cached values of this thread's row (all of them for max_length <= 21 / 11)
+  // are requested now, behind the weight fragments: they do not depend on the projection, and fetched after it they
+  // were two exposed L2 round trips (5 of the block's 14.6 us)
+  const int a_lr = threadIdx.x >> 4, a_s = threadIdx.x & 15;
+  [[maybe_unused]] u32x4 pk0[SELF ? KU : 1], pk1[SELF ? KU : 1];
+  [[maybe_unused]] uint2 pv[SELF ? VU : 1];
+  if (SELF) {
+    const int prow = row0 + a_lr < p.R ? row0 + a_lr : 0;
+    const bf16_t* kc = p.Kc + (size_t)prow * p.Tmax * p.ldc + h * HD;
+    const bf16_t* vc = p.Vc + (size_t)prow * p.Tmax * p.ldc + h * HD;
+    const int tc = p.Tk - 1;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int t = (a_s >> 2) + 4 * u;
+      const bf16_t* kr = kc + (size_t)(t < tc ? t : 0) * p.ldc + (a_s & 3) * 16;
+      pk0[u] = *reinterpret_cast<const u32x4*>(kr);
+      pk1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < VU; ++u) pv[u] = *reinterpret_cast<const uint2*>(vc + (size_t)(u < tc ? u : 0) * p.ldc + a_s * 4);
   }
   // KVLDS: this thread's chunks of the tile's keys / values (chunk c = tid + 256 i: staged row c / 8, 16-byte piece c % 8)
   [[maybe_unused]] u32x4 kreg[KVLDS ? NKV : 1], vreg[KVLDS ? NKV : 1];
@@ -461,7 +492,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
     for (int u = 0; u < KU; ++u) {
       const int t = t0 + kq + 4 * u;
       const bool ok = t < Tc;
-      if (KVLDS) {
+      if (SELF && t0 == 0) {
+        k0[u] = pk0[u];
+        k1[u] = pk1[u];
+      } else if (KVLDS) {
         const char* kr = my_k + (size_t)(ok ? t : 0) * KS + part * 32;
         k0[u] = *reinterpret_cast<const u32x4*>(kr);
         k1[u] = *reinterpret_cast<const u32x4*>(kr + 16);
@@ -528,6 +562,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
       const int t = t0 + u < Tc ? t0 + u : 0;
+      if (SELF && t0 == 0) { vv[u] = pv[u]; continue; }
       vv[u] = KVLDS ? *reinterpret_cast<const uint2*>(my_v + (size_t)t * 128 + s * 8)
                     : *reinterpret_cast<const uint2*>(Vc + (size_t)t * p.ldc + s * 4);
     }
@@ -593,15 +628,15 @@ hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream) 
   hipError_t e = hipSuccess;
   if (p.kind == 0) {
     static size_t set[4] = {0, 0, 0, 0};
-#define KMB_PROJ(SLOT, NCH, NTW)                                                                                      \
+#define KMB_PROJ(SLOT, KERNEL, NTW)                                                                                   \
   do {                                                                                                                \
-    if (a_bytes > set[SLOT]) { e = set_lds(decode_proj_kernel<NCH, NTW>, a_bytes); if (e != hipSuccess) return e; set[SLOT] = a_bytes; } \
-    hipLaunchKernelGGL((decode_proj_kernel<NCH, NTW>), dim3(unit_grid(p.N / (64 * NTW), tiles)), dim3(256), a_bytes, stream, p); \
+    if (a_bytes > set[SLOT]) { e = set_lds(KERNEL, a_bytes); if (e != hipSuccess) return e; set[SLOT] = a_bytes; }     \
+    hipLaunchKernelGGL(KERNEL, dim3(unit_grid(p.N / (64 * NTW), tiles)), dim3(256), a_bytes, stream, p);              \
   } while (0)
-    if (nch <= 2 && (p.N % 128) == 0 && p.N >= 1536) KMB_PROJ(0, 2, 2);   // the wide fc1: half as many LayerNorm prologues
-    else if (nch <= 2) KMB_PROJ(1, 2, 1);
-    else if (nch <= 4) KMB_PROJ(2, 4, 1);
-    else KMB_PROJ(3, 6, 1);
+    if (nch <= 2 && (p.N % 128) == 0 && p.N >= 1536) KMB_PROJ(0, decode_proj_wide_kernel, 2);   // half as many LayerNorm prologues
+    else if (nch <= 2) KMB_PROJ(1, decode_proj_kernel<2>, 1);
+    else if (nch <= 4) KMB_PROJ(2, decode_proj_kernel<4>, 1);
+    else KMB_PROJ(3, decode_proj_kernel<6>, 1);
 #undef KMB_PROJ
     return hipGetLastError();
   }

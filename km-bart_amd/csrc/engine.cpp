@@ -1566,7 +1566,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       KCHK(block(b));
       zin = G.z; lg = h->pf(L.ln_g); lb = h->pf(L.ln_b);
     }
-    if (lg) {
+    if (lg && logits_out) {   // the last LayerNorm feeds only the vocabulary projection
       HIPCHK(kmb_ln_fwd_launch(G.z, lg, lb, G.x1, G.mean, G.rstd, R, d, eps, s));
       x = G.x1;
     }

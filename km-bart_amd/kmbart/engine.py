@@ -337,11 +337,14 @@ class Engine:
             self._gen_rows = B * num_beams
             self._gen_logits = torch.empty((self._gen_rows, self.logits_ld), dtype=torch.float32, device=self.device)
 
-    def gen_step(self, tokens, step):
-        """tokens int64 [B*num_beams] (device) at 0-based position `step` -> fp32 logits [R, V] (padded view)."""
+    def gen_step(self, tokens, step, want_logits=True):
+        """tokens int64 [B*num_beams] (device) at 0-based position `step` -> fp32 logits [R, V] (padded view).
+        want_logits=False: the decoder layers run (the KV cache gets position `step`) but the vocabulary projection is
+        skipped; the returned buffer then holds stale values (for steps whose token is forced)."""
         with torch.cuda.device(self.device):
             tokens = tokens.to(device=self.device, dtype=torch.int64).contiguous()
-            check(self.lib.kmb_gen_step(self.h, ptr(tokens), int(step), ptr(self._gen_logits), _stream()))
+            check(self.lib.kmb_gen_step(self.h, ptr(tokens), int(step), ptr(self._gen_logits) if want_logits else None,
+                                        _stream()))
             self._keep_tok = tokens
         return self._gen_logits
 

@@ -494,16 +494,24 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 return False
 
             while cur_len < max_length:
-                logits = eng.gen_step(last_tokens, cur_len - 1)
                 ban = eos if (eos >= 0 and cur_len < min_length) else -1
                 force = -1
                 if cur_len == 1:
                     force = cfg.bos_token_id          # adjust_logits_during_generation, mixins.py:400-405
-                if cur_len == max_length - 1 and eos_token_id is not None:
+                last = cur_len == max_length - 1
+                if last and eos_token_id is not None:
                     force = eos_token_id
+                # A forced step's scores are 0 at the forced token and -inf elsewhere whatever the model says
+                # (log_softmax of a row with one finite entry): the vocabulary projection is skipped, and on the LAST
+                # step, whose keys / values nobody will read, the decoder as well.
+                if force >= 0 and last:
+                    logits = eng._gen_logits
+                else:
+                    logits = eng.gen_step(last_tokens, cur_len - 1, want_logits=force < 0)
                 cand, beam_scores_dev, last_tokens, beam_idx = eng.beam_step(
                     logits, num_beams, k, beam_scores_dev, force_token=force, ban_token=ban, eos_token=eos)
-                eng.gen_reorder(beam_idx, cur_len - 1)   # _reorder_cache, mixins.py:419-434
+                if not last:
+                    eng.gen_reorder(beam_idx, cur_len - 1)   # _reorder_cache, mixins.py:419-434
                 staging[cur_len - 1].copy_(cand, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
