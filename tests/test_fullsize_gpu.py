@@ -71,7 +71,10 @@ def test_duplicating_the_batch_leaves_loss_and_gradients_unchanged(model):
     l2.backward()
     torch.cuda.synchronize()
     g2 = eng.grads.clone()
-    assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l1))
+    # 32 and 64 samples take the small-batch split-K GEMMs with different slice counts (the count follows the number of
+    # output tiles): the same fp32 sums in another order, rounded to bf16 once -- 3e-5 on the loss; 1e-5 without that
+    # path (KMB_SMALL_SPLIT=0)
+    assert abs(float(l1) - float(l2)) <= 1e-4 * abs(float(l1))
     errs = []
     for name, (off, rows, cols) in eng.index.items():
         a, c = g1[off: off + rows * cols], g2[off: off + rows * cols]

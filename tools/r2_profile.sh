@@ -25,5 +25,7 @@ timeout 300 python tools/gemm_yardstick.py $O/gemm_shapes_b512.txt 2>/dev/null >
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gen -o g -- python3 tools/gen_bench.py --reps 5 > $O/gen_bench.log 2>&1
 timeout 200 python tools/pretrain_bench.py --batch 384 2>&1 | grep -v amdgpu | tail -3 > $O/pretrain.log
 timeout 200 python tools/attn_bwd_time.py 2>&1 | grep -v amdgpu > $O/attn_bwd.txt
+timeout 200 python tools/decode_stamps.py 2>&1 | grep -v amdgpu > $O/decode_stamps.txt     # needs lib/libkmbart_hip_dstamp.so (--build)
+timeout 100 python tools/topk_time.py 2>&1 | grep -v amdgpu > $O/topk_time.txt
 tail -1 $O/bench_default.log | cut -c1-400
 find $O -name "*.csv" | head -20
