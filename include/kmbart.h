@@ -71,7 +71,9 @@ typedef struct KmbGemm {
   float* out_f32; int32_t ld_out_f32; float beta;
   int32_t split_k; float* slab;   /* split_k > 1: slice s writes raw fp32 accumulators to slab[s][M][N]; no epilogue */
   float* colsum;                  /* optional [ceil(M/64)][N]: per-64-row-block column sums of the stored values */
-  int32_t tile_order;             /* set by the launcher: 0 = linear tile ids, 1 = contiguous tile range per XCD */
+  int32_t tile_order;             /* set by the launcher (results never depend on it): bit 0 = contiguous tile range per
+                                   * XCD; bit 1 = L2 prefetch of the activation panel (persistent kernels); bit 2 = split-K
+                                   * (tile, slice) pairs enumerated slice-major: an XCD works on one or two K slices */
 } KmbGemm;
 
 /* ---- fused attention (csrc/attention.hip) -------------------------------------------------- */

@@ -292,7 +292,8 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
   if (S > 16) S = 16;
   // 128-160 tiles and a very long reduction (3072x768 over 32768 tokens): 256x256 tiles with a slice count that fills
   // the chip once beat the 128x128 kernel at S = 3 by 10-12 % (tools/wgrad_split_sweep.py); with these slices the
-  // launcher's timing picks the 256x256 kernel
+  // launcher's timing picks the 256x256 kernel.  (Slice counts rounded to the 8 XCDs -- 3 -> 4, 7 -> 8, 14 -> 16, one slice
+  // per XCD under the slice-major enumeration -- measured 18 % slower on the weight gradients: 780 -> 638 TFLOP/s.)
   if (tiles >= 128 && tiles <= 160 && nt >= 512) {   // (wider ranges gain what the longer slab reduction costs)
     const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     if (256 / tiles256 > S) S = 256 / tiles256;

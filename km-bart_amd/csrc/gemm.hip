@@ -80,6 +80,12 @@ constexpr int LDS_BYTES = ((EPI_BYTES > 2 * STAGE_BYTES) ? EPI_BYTES : 2 * STAGE
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private L2): give every XCD a contiguous range
 // of tile ids so that neighbouring tiles -- which share an A row panel -- hit the same L2 (bijective for any grid).
 // Measured need: rocprof FETCH_SIZE showed the A panel fetched ~6x its size without the remap.
+// split_order_note -- split-K launches (weight gradients: few output tiles, all tokens to reduce over): block ids
+// enumerate (tile, slice) pairs slice-minor, so with or without the remap every XCD works on every K slice and its L2
+// pulls in both operands over their whole length: a 3072x768x32768 weight gradient fetched 660 MB for 251 MB of
+// operands (rocprofv3 FETCH_SIZE; the 768-wide operand 8x, once per XCD).  tile_order bit 2 enumerates them slice-MAJOR
+// (all tiles of slice 0, then slice 1, ...); together with the remap's contiguous ranges an XCD then works on one or
+// two K slices and reads only those token ranges of the operands.  Results do not depend on the enumeration.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, loc = bid >> 3;
@@ -419,7 +425,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KmbGemm p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int tile = bid / nsl, slice = bid % nsl;
+  const int ntl = tiles_n * ((p.M + BM - 1) / BM);
+  const bool slice_major = (p.tile_order & 4) != 0 && nsl > 1;   // see split_order_note
+  const int tile = slice_major ? bid % ntl : bid / nsl, slice = slice_major ? bid / ntl : bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
@@ -526,7 +534,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int tile = bid / nsl, slice = bid % nsl;
+  const int ntl = tiles_n * ((p.M + BM - 1) / BM);
+  const bool slice_major = (p.tile_order & 4) != 0 && nsl > 1;   // see split_order_note
+  const int tile = slice_major ? bid % ntl : bid / nsl, slice = slice_major ? bid / ntl : bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
@@ -735,7 +745,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
   const int tiles_n = (p.N + BN4 - 1) / BN4;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int tile = bid / nsl, slice = bid % nsl;
+  const int ntl = tiles_n * ((p.M + BM4 - 1) / BM4);
+  const bool slice_major = (p.tile_order & 4) != 0 && nsl > 1;   // see split_order_note
+  const int tile = slice_major ? bid % ntl : bid / nsl, slice = slice_major ? bid / ntl : bid % nsl;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM4, col0 = tn * BN4;
 
@@ -2013,7 +2025,8 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
-    const int cands[10] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16};   // variant | (tile_order << 4)
+    const int cands[12] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
+                           7 + 16 * 5, 8 + 16 * 5};                                       // split-K only: slice-major
     float best_ms = 1e30f;
     int best = 7;
     hipEvent_t e0, e1;
@@ -2022,6 +2035,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       if ((c & 15) == 11 && !v11_ok(p)) continue;
       if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
+      if (((c >> 4) & 4) && p.split_k <= 1) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;
       hipError_t e = launch_variant(c & 15, q, stream);  // warm
@@ -2052,5 +2066,11 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   }
   KmbGemm q = p;
   q.tile_order = (it->second >> 4) | (prefetch_a(p) ? 2 : 0);
+  if (p.split_k > 1) {
+    static int so = -2;   // KMB_GEMM_SPLIT_ORDER = 0 | 1: force the slice-minor / slice-major enumeration (A/B measurements)
+    if (so == -2) { const char* e = getenv("KMB_GEMM_SPLIT_ORDER"); so = e ? atoi(e) : -1; }
+    if (so == 0) q.tile_order &= ~4;
+    else if (so == 1) q.tile_order |= 5;
+  }
   return launch_variant(it->second & 15, q, stream);
 }

@@ -40,6 +40,10 @@ CASES = [
     ("n768_out_dgrad", 16384, 768, 768, True, False, dict()),
     ("n2304_qkv_fwd", 16384, 2304, 768, True, True, dict(bias=True, qscale=True)),
     ("n192_edges", 16300, 1000, 320, True, False, dict(colsum=True)),                     # 64 x 6 tiles of 192, edge rows + columns
+    # split-K (raw fp32 slabs): the (tile, slice) enumeration (slice-minor / per-XCD ranges / slice-major) must not matter
+    ("wgrad_split7", 3072, 768, 8192, False, False, dict(split=7)),
+    ("wgrad_split14_edges", 700, 760, 4096, False, False, dict(split=14)),
+    ("fwd_split3", 2048, 768, 3072, True, True, dict(split=3)),
 ]
 
 
@@ -72,7 +76,10 @@ def run_variant():
         nparts = (M + 63) // 64
         if o.get("colsum"):
             kw["colsum"] = torch.full((nparts, N), 7.0, dtype=torch.float32, device=DEV)
-        if o.get("f32"):
+        if o.get("split"):
+            kw["split_k"] = o["split"]
+            kw["slab"] = torch.zeros(o["split"] * M * Np, dtype=torch.float32, device=DEV)
+        elif o.get("f32"):
             ld = o.get("ld_f32", ((N + 3) // 4) * 4)
             kw["out_f32"] = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
         else:
@@ -80,7 +87,7 @@ def run_variant():
         gemm(A, B, **kw)
         torch.cuda.synchronize()
         rec = {}
-        for k in ("out_bf16", "out_f32", "preact"):
+        for k in ("out_bf16", "out_f32", "preact", "slab"):
             if kw.get(k) is not None:
                 rec[k] = hashlib.md5(kw[k].cpu().view(torch.uint8).numpy().tobytes()).hexdigest()[:16]
         if kw.get("colsum") is not None:
@@ -94,12 +101,12 @@ def run_variant():
         rec["us"] = e0.elapsed_time(e1) * 100.0
         # a relaunch into cleared outputs must reproduce the first launch (the persistent variants' tile counters
         # have to come back to zero after every launch)
-        for k in ("out_bf16", "out_f32", "preact"):
+        for k in ("out_bf16", "out_f32", "preact", "slab"):
             if kw.get(k) is not None:
                 kw[k].zero_()
         gemm(A, B, **kw)
         torch.cuda.synchronize()
-        for k in ("out_bf16", "out_f32", "preact"):
+        for k in ("out_bf16", "out_f32", "preact", "slab"):
             if kw.get(k) is not None:
                 again = hashlib.md5(kw[k].cpu().view(torch.uint8).numpy().tobytes()).hexdigest()[:16]
                 if again != rec[k]:
@@ -110,18 +117,18 @@ def run_variant():
     print("JSON" + json.dumps(out))
 
 
-VARIANTS = ("7", "8", "11", "12", "13", "11o1", "12o1", "13o1", "11s", "12o1s", "13s", "11o1p", "13p")
+VARIANTS = ("7", "8", "11", "12", "13", "11o1", "12o1", "13o1", "11s", "12o1s", "13s", "11o1p", "13p", "7o5", "8o5")
 
 
 def main():
     if os.environ.get("KMB_V11_CHILD"):
         return run_variant()
     res = {}
-    # o1: tile_order bit 0 = per-XCD contiguous tile ranges; s: shared-device mode (every tile from the atomic counter);
+    # o1: tile_order bit 0 = per-XCD contiguous tile ranges; o5: that plus slice-major split-K enumeration (bit 2); s: shared-device mode (every tile from the atomic counter);
     # p: the activation-panel L2 prefetch on for every shape (the others: off, so both paths of the kernel are compared)
     for v in VARIANTS:
         env = dict(os.environ, KMB_GEMM_VARIANT=v.rstrip("sp").split("o")[0], KMB_V11_CHILD="1",
-                   KMB_TILE_ORDER="1" if "o" in v else "0", KMB_V11_SHARED="1" if v.endswith("s") else "0",
+                   KMB_TILE_ORDER=v.rstrip("sp").split("o")[1] if "o" in v else "0", KMB_V11_SHARED="1" if v.endswith("s") else "0",
                    KMB_GEMM_PREFETCH="1" if v.endswith("p") else "0")
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("JSON")]

@@ -29,7 +29,7 @@ def child():
         for S in cands:
             if S < 2 or S * M * N > slab.numel() or S > K // 128:
                 continue
-            for o in (0, 1):
+            for o in (0, 1, 5):   # 5: slice-major enumeration over per-XCD ranges
                 kw = dict(a_kc=False, b_kc=False, M=M, N=N, K=K, split_k=S, slab=slab, tile_order=o)
                 for _ in range(2):
                     gemm(A, B, **kw)
