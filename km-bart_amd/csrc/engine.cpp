@@ -1524,7 +1524,9 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
   // the fragment-order copies made by kmb_gen_begin.  Configurations gen_fused_eligible() rejects, and KMB_GEN_FUSED=0,
   // take the launch-per-operation path below.
   const char* fused_env = getenv("KMB_GEN_FUSED");   // read per call: tests compare the two paths in one process
-  const bool fused = !(fused_env && fused_env[0] == '0') && !G.wp.empty();
+  // the blocks work on 16-row tiles that each stream the layer's weights through L2: their time grows with the rows, while
+  // the 128-row GEMM tiles of the launch-per-operation path amortise the weights (even at 1280 rows, faster below)
+  const bool fused = !(fused_env && fused_env[0] == '0') && !G.wp.empty() && R <= 1024;
   if (fused) {
     const bf16_t* zin = G.x0;                       // layer input: normalised rows (layer 0) or pre-LayerNorm sums
     const float *lg = nullptr, *lb = nullptr;       // ... and the LayerNorm that turns them into the layer input

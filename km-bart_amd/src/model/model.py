@@ -402,29 +402,41 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         R = B * num_beams
         eng.gen_begin(input_ids, image_features, attention_mask, num_beams, max_length)
         eng.check_inputs()
-        ids = torch.full((R, 1), decoder_start_token_id, dtype=torch.long)  # host copy of the decoder inputs
         cur_len = 1
 
         if num_beams == 1:
-            unfinished = torch.ones(B, dtype=torch.long)
+            # Greedy / sampling without beams (transformers 3.0.2 _generate_no_beam_search): everything stays on the
+            # device; the "every sentence has finished" test is read one step late from a pinned flag, so step t+1 is
+            # enqueued before step t's flag is looked at, and the extra (all-pad) column of a late stop is dropped.
+            unfinished = torch.ones(B, dtype=torch.long, device=dev)
+            cols = [torch.full((B,), decoder_start_token_id, dtype=torch.long, device=dev)]
+            flags = eng.pinned((max_length + 1,), torch.long)
+            pending, keep = None, None
             while cur_len < max_length:
-                logits = eng.gen_step(ids[:, -1].to(dev), cur_len - 1)[:, :V]
+                logits = eng.gen_step(cols[-1], cur_len - 1)[:, :V]
                 if eos_token_id is not None and cur_len < min_length:
                     logits[:, eos_token_id] = -float("inf")
                 if do_sample:
                     lg = logits / temperature if temperature != 1.0 else logits
                     lg = _top_k_top_p_filtering(lg.clone(), top_k=top_k, top_p=top_p)
-                    nxt = torch.multinomial(torch.softmax(lg, dim=-1), num_samples=1).squeeze(1).cpu()
+                    nxt = torch.multinomial(torch.softmax(lg, dim=-1), num_samples=1).squeeze(1)
                 else:
-                    nxt = torch.argmax(logits, dim=-1).cpu()
+                    nxt = torch.argmax(logits, dim=-1)
                 tok = nxt * unfinished + pad_token_id * (1 - unfinished) if eos_token_id is not None else nxt
-                ids = torch.cat([ids, tok.unsqueeze(-1)], dim=-1)
+                cols.append(tok)
                 cur_len += 1
                 if eos_token_id is not None:
                     unfinished = unfinished * (tok != eos_token_id).long()
-                    if int(unfinished.max()) == 0:
-                        break
-            return ids.to(dev)
+                    flags[cur_len].copy_(unfinished.max(), non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    if pending is not None:
+                        pending[1].synchronize()
+                        if int(flags[pending[0]]) == 0:     # finished one step ago: the reference stopped there
+                            keep = pending[0]
+                            break
+                    pending = (cur_len, ev)
+            return torch.stack(cols[:keep] if keep is not None else cols, dim=1)
 
         # Host bookkeeping on plain Python lists: indexing small CPU tensors element by element (as the reference does)
         # costs ~10 us per access and made a beam step 6x longer than its GPU work.
