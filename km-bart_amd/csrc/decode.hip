@@ -13,16 +13,21 @@
 //   kind 0  LayerNorm -> fc1 + bias + GeLU
 //   kind 0  fc2 + bias + residual
 //
-// A workgroup owns 16 rows (one MFMA row tile) x 64 output columns (kind 0) or one head (kinds 1, 2).  The LayerNorm
-// of its 16 input rows is recomputed by every workgroup that needs them (12-48 times 16 x 768 elements: noise) instead
-// of being a launch of its own; the normalised rows are kept in LDS as the MFMA activation operand and written to
-// memory once (by the workgroups of column block 0) because the next projection adds them as its residual.
+// A workgroup owns 16 rows (one MFMA row tile) x 64 or 128 output columns (kind 0) or one head (kinds 1, 2).  The
+// LayerNorm of its 16 input rows is recomputed by every workgroup that needs them (12-48 times 16 x 768 elements: noise)
+// instead of being a launch of its own; the normalised rows are kept in LDS as the MFMA activation operand and written
+// to memory once (by the workgroups of column block 0) because the next projection adds them as its residual.
 //
 // Weights go global -> registers directly as MFMA fragments (no LDS staging: a workgroup reads each weight element
-// once), 32 contiguous bytes per lane per 64-deep K chunk: the 16 x 16 x 32 MFMA sums over its 32 K slots in no
-// particular order, so lane group g feeds K elements g*16 .. g*16+7 to the first MFMA of a chunk and g*16+8 .. g*16+15
-// to the second, for the weight and the activation fragment alike.  All fragments of a 768-deep K block (96 VGPRs per
-// 16-column tile) are requested before the LayerNorm prologue runs, so the weight latency hides behind it.
+// once) from a fragment-order copy (below): the 16 x 16 x 32 MFMA sums over its 32 K slots in no particular order, so
+// lane group g feeds K elements g*16 .. g*16+7 to the first MFMA of a 64-deep chunk and g*16+8 .. g*16+15 to the second,
+// for the weight and the activation fragment alike.  What bounds a block is the request rate of the CU's vector memory
+// pipe (~50 GB/s per CU, DESIGN.md section 4 "Generation"), so the order of requests is the design: activation rows and
+// LayerNorm parameters first, then every weight fragment the registers can hold (up to three 768-deep K blocks), then
+// keys / values; everything is in flight before the first wait.
+//
+// Time grows with the rows (every 16-row tile streams the layer's weights through L2); above 1024 rows the engine uses
+// the GEMM path, whose 128-row tiles amortise the weights.
 //
 // Numerics follow the unfused path: q, k, v, attention output, GeLU output and the pre-LayerNorm sums are rounded to
 // bf16 where that path stores them; sums are fp32.

@@ -503,15 +503,27 @@ __device__ __forceinline__ float topk_key_value(unsigned long long key) {
   const uint32_t ord = (uint32_t)(key >> 32);
   return __uint_as_float((ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
 }
+// Wave-wide maximum of a 64-bit key, result in every lane.  DPP moves instead of the shuffle tree (twelve dependent
+// ds_bpermute per call through the LDS crossbar: 2.3 us per selection round with five waves per SIMD): rotations by
+// 1, 2, 4, 8 inside each row of 16 lanes leave the row maximum in every lane of the row (max is idempotent), row_bcast:15
+// folds row 0 into 1 and 2 into 3, row_bcast:31 folds lane 31 into rows 2 and 3; lane 63 then holds the wave maximum.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  const unsigned long long v2 = ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;   // lanes outside ROW_MASK: v itself
+  return v2 > v ? v2 : v;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, o, 64);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
-    const unsigned long long v2 = ((unsigned long long)hi << 32) | lo;
-    v = v2 > v ? v2 : v;
-  }
-  return v;
+  v = dpp_max_step<0x121, 0xf>(v);   // row_ror:1
+  v = dpp_max_step<0x122, 0xf>(v);   // row_ror:2
+  v = dpp_max_step<0x124, 0xf>(v);   // row_ror:4
+  v = dpp_max_step<0x128, 0xf>(v);   // row_ror:8
+  v = dpp_max_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 template <int NV>   // float4 chunks per thread: chunks per part <= NV * 256
