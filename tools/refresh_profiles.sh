@@ -1,0 +1,22 @@
+# Turn the outputs of tools/r2_profile.sh (gpurun_out/$R/, merged back by gpurun) into the committed files under profiles/.
+# Run from the repo root on the build container:  bash tools/refresh_profiles.sh [r02]
+R=${1:-r02}
+O=gpurun_out/$R
+set -e
+tail -1 $O/bench_default.log > profiles/${R}_bench_b512.json
+cp $O/prof/p_kernel_stats.csv profiles/${R}_kernel_stats_b512.csv
+cp $O/profs/s_kernel_stats.csv profiles/${R}_kernel_stats_b512_serial.csv
+python tools/summarize_rocprof.py $O/prof/p_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b512.md
+python tools/summarize_rocprof.py $O/profs/s_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b512_serial.md
+python tools/summarize_pmc.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv \
+    --json profiles/${R}_pmc_traffic.json --batch 512 > profiles/${R}_pmc_hbm_traffic_b512.md
+python tools/summarize_pmc_mfma.py $O/pmc_mfma/m_counter_collection.csv > profiles/${R}_pmc_mfma_util_b512.md
+cp $O/gemm_shapes_b512.txt profiles/${R}_gemm_shape_table_b512.txt
+cp $O/yardstick.txt profiles/${R}_gemm_library_yardstick_b512.txt
+cp $O/attn_bwd.txt profiles/${R}_attn_bwd_time.txt
+cp $O/decode_stamps.txt profiles/${R}_decode_stamps.txt
+cp $O/topk_time.txt profiles/${R}_topk_time.txt
+grep '^{' $O/gen_bench.log | tail -1 > profiles/${R}_generation_bench.json
+python tools/summarize_rocprof.py $O/prof_gen/g_kernel_stats.csv 6 > profiles/${R}_generation_kernel_stats.md
+grep '^{' $O/pretrain.log | tail -1 > profiles/${R}_pretrain_bench.json
+echo "profiles/${R}_* refreshed from $O"
