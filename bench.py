@@ -160,13 +160,19 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
     kw = dict(input_ids=b["input_ids"].to(dev), image_features=[f.to(dev) for f in b["image_features"]],
               attention_mask=b["attention_mask"].to(dev), num_beams=beams, num_return_sequences=1,
               max_length=max_length, early_stopping=True)
-    out = model.generate(**kw)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        out = model.generate(**kw)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    def timed(n, **over):
+        k2 = dict(kw, **over)
+        o = model.generate(**k2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            o = model.generate(**k2)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, o
+
+    dt, out = timed(reps)
+    dt32, out32 = timed(3, max_length=32)       # the "32-token-out" variant
+    dt1, out1 = timed(3, num_beams=1)           # greedy: the reference CLI's default (vcg_generate.py:99)
     steps = out.shape[1] - 1
     d, L, F, V = VCG_BASE["d_model"], VCG_BASE["decoder_layers"], VCG_BASE["decoder_ffn_dim"], VCG_BASE["vocab_size"]
     R = batch * beams
@@ -180,6 +186,10 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
             "ms_per_generate": round(dt * 1e3, 2), "decoder_steps": int(steps),
             "us_per_decoder_step": round(dt / steps * 1e6, 1),
             "hbm_bytes_per_step": int(per_step), "hbm_frac": round(per_step / (dt / steps) / 6.3e12, 4),
+            "max_length_32": {"value": round(batch / dt32, 1), "ms_per_generate": round(dt32 * 1e3, 2),
+                              "decoder_steps": int(out32.shape[1] - 1)},
+            "greedy": {"value": round(batch / dt1, 1), "ms_per_generate": round(dt1 * 1e3, 2),
+                       "decoder_steps": int(out1.shape[1] - 1)},
             "config": {"workload": "vcg_base generate, beam search, KV cache", "batch": batch, "num_beams": beams,
                        "max_length": max_length}}
 
