@@ -1,6 +1,7 @@
 """Cold vs warm operand timing of one GEMM shape: back-to-back launches re-read A / B from the Infinity Cache; inside a
 training step the A operand was just streamed out by the previous kernel and comes from HBM.  A 600 MB fill between
-launches evicts L2 and the Infinity Cache.  python tools/gemm_cold_warm.py M N K [a_kc b_kc]"""
+launches evicts L2 and the Infinity Cache.  python tools/gemm_cold_warm.py M N K [a_kc b_kc [split_k]]
+(split_k > 1: raw fp32 slabs, the weight-gradient form, e.g. 3072 768 32768 0 0 7)"""
 import os
 import sys
 
@@ -13,13 +14,15 @@ from gpu_util import DEV, bf, gemm  # noqa: E402
 M, N, K = (int(x) for x in sys.argv[1:4])
 akc = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
 bkc = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
+split = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 torch.manual_seed(0)
 A = bf(torch.randn((M, K) if akc else (K, M), device=DEV))
 B = bf(torch.randn((N, K) if bkc else (K, N), device=DEV))
 out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+SK = dict(split_k=split, slab=torch.empty(split * M * N, dtype=torch.float32, device=DEV)) if split > 1 else dict(out_bf16=out)
 junk = torch.empty(600 << 20, dtype=torch.uint8, device=DEV)
 for _ in range(3):
-    gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
+    gemm(A, B, a_kc=akc, b_kc=bkc, **SK)
 torch.cuda.synchronize()
 
 
@@ -30,7 +33,7 @@ def timed(cold):
             junk.fill_(1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
+        gemm(A, B, a_kc=akc, b_kc=bkc, **SK)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
@@ -48,7 +51,7 @@ def timed_after_write():
         A.copy_(A2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
+        gemm(A, B, a_kc=akc, b_kc=bkc, **SK)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
