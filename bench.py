@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512,
                     help="per-GPU batch (weak scaling); 512 x 96 tokens uses ~30 of the 288 GB and fills the GEMM grids "
-                         "better than 256 (1.47 vs 1.35 M tokens/s); the reference default is 64")
+                         "better than 256; the reference default is 64; `batch_sweep` reports 64 .. 2048 (2048: +8 %)")
     ap.add_argument("--lr", type=float, default=1e-5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -351,7 +351,7 @@ def main():
         out["fine_tune_over_value"] = round(out["fine_tune_tokens_per_sec"] / value, 4)
         # (2) other per-GPU batch sizes (the reference's default is 64, vcg_train.py:330); same step as `value`
         sweep = {}
-        for bsz in (64, 256):
+        for bsz in (64, 256, 1024, 2048):   # 2048 x 96 tokens: ~120 of the 288 GB
             if bsz == args.batch:
                 continue
             sb = make_batch(bsz, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=77)
@@ -361,7 +361,7 @@ def main():
             def sstep():
                 model.train_step_fwd_bwd(sbatch)
                 opt.step()
-            sdt = timed_steps(sstep, 4, 10)
+            sdt = timed_steps(sstep, 4, 10 if bsz <= 512 else 6)
             sweep[str(bsz)] = {"tokens_per_sec": round(bsz * (S_ENC + T_DEC) / sdt, 1), "ms_per_step": round(sdt * 1e3, 3)}
         sweep[str(args.batch)] = {"tokens_per_sec": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 3)}
         out["batch_sweep"] = sweep
