@@ -1,18 +1,19 @@
 # Turn the outputs of tools/r2_profile.sh (gpurun_out/$R/, merged back by gpurun) into the committed files under profiles/.
-# Run from the repo root on the build container:  bash tools/refresh_profiles.sh [r02]
+# Run from the repo root on the build container:  bash tools/refresh_profiles.sh [r02] [1024]
 R=${1:-r02}
+B=${2:-1024}     # the per-GPU batch the evidence run used
 O=gpurun_out/$R
 set -e
-tail -1 $O/bench_default.log > profiles/${R}_bench_b512.json
-cp $O/prof/p_kernel_stats.csv profiles/${R}_kernel_stats_b512.csv
-cp $O/profs/s_kernel_stats.csv profiles/${R}_kernel_stats_b512_serial.csv
-python tools/summarize_rocprof.py $O/prof/p_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b512.md
-python tools/summarize_rocprof.py $O/profs/s_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b512_serial.md
+tail -1 $O/bench_default.log > profiles/${R}_bench_b${B}.json
+cp $O/prof/p_kernel_stats.csv profiles/${R}_kernel_stats_b${B}.csv
+cp $O/profs/s_kernel_stats.csv profiles/${R}_kernel_stats_b${B}_serial.csv
+python tools/summarize_rocprof.py $O/prof/p_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b${B}.md
+python tools/summarize_rocprof.py $O/profs/s_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b${B}_serial.md
 python tools/summarize_pmc.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv \
-    --json profiles/${R}_pmc_traffic.json --batch 512 > profiles/${R}_pmc_hbm_traffic_b512.md
-python tools/summarize_pmc_mfma.py $O/pmc_mfma/m_counter_collection.csv > profiles/${R}_pmc_mfma_util_b512.md
-cp $O/gemm_shapes_b512.txt profiles/${R}_gemm_shape_table_b512.txt
-cp $O/yardstick.txt profiles/${R}_gemm_library_yardstick_b512.txt
+    --json profiles/${R}_b${B}_pmc_traffic.json --batch ${B} > profiles/${R}_pmc_hbm_traffic_b${B}.md
+python tools/summarize_pmc_mfma.py $O/pmc_mfma/m_counter_collection.csv > profiles/${R}_pmc_mfma_util_b${B}.md
+cp $O/gemm_shapes.txt profiles/${R}_gemm_shape_table_b${B}.txt
+cp $O/yardstick.txt profiles/${R}_gemm_library_yardstick_b${B}.txt
 cp $O/attn_bwd.txt profiles/${R}_attn_bwd_time.txt
 cp $O/decode_stamps.txt profiles/${R}_decode_stamps.txt
 cp $O/topk_time.txt profiles/${R}_topk_time.txt
