@@ -294,9 +294,12 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
   // the chip once beat the 128x128 kernel at S = 3 by 10-12 % (tools/wgrad_split_sweep.py); with these slices the
   // launcher's timing picks the 256x256 kernel.  (Slice counts rounded to the 8 XCDs -- 3 -> 4, 7 -> 8, 14 -> 16, one slice
   // per XCD under the slice-major enumeration -- measured 18 % slower on the weight gradients: 780 -> 638 TFLOP/s.)
-  if (tiles >= 128 && tiles <= 160 && nt >= 512) {   // (wider ranges gain what the longer slab reduction costs)
+  // (wider ranges gain what the longer slab reduction costs -- unless the reduction is very long: 2304x768 over 65536
+  // tokens, 108 tiles: 9 slices of the 256x256 kernel 251 us against 4 of the 128x128 kernel 294)
+  if (tiles >= 96 && tiles <= 160) {
     const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    if (256 / tiles256 > S) S = 256 / tiles256;
+    const int s256 = 256 / tiles256;
+    if (s256 > S && ((tiles >= 128 && nt >= 512) || nt / s256 >= 100)) S = s256;
   }
   if (S > nt / 2) S = nt / 2;
   while (S > 1 && (size_t)S * g.M * g.N > h->slab_floats) --S;

@@ -13,6 +13,9 @@ sys.path.insert(0, os.path.join(ROOT, "km-bart_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 SHAPES = [(3072, 768, 32768), (768, 3072, 32768), (2304, 768, 32768), (1536, 768, 32768), (768, 768, 32768),
           (3072, 768, 16384), (768, 768, 16384), (2304, 768, 16384)]
+if os.environ.get("KMB_WG_TOKENS"):   # e.g. KMB_WG_TOKENS=65536: the b = 1024 encoder shapes
+    _t = int(os.environ["KMB_WG_TOKENS"])
+    SHAPES = [(3072, 768, _t), (768, 3072, _t), (2304, 768, _t), (1536, 768, _t), (768, 768, _t)]
 
 
 def child():
@@ -25,11 +28,12 @@ def child():
         B = bf(torch.randn(K, N, device=DEV))
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
         t256 = ((M + 255) // 256) * ((N + 255) // 256)
-        cands = sorted({max(1, min(16, (384 + t128 - 1) // t128)), max(1, 256 // t256), max(1, 512 // t256), max(1, 512 // t128)})
+        cands = sorted({max(1, min(16, (384 + t128 - 1) // t128)), max(1, 256 // t256), max(1, 512 // t256), max(1, 512 // t128),
+                        max(1, 768 // t128), max(1, 384 // t256)})
         for S in cands:
             if S < 2 or S * M * N > slab.numel() or S > K // 128:
                 continue
-            for o in (0, 1, 5):   # 5: slice-major enumeration over per-XCD ranges
+            for o in (1, 5):   # per-XCD ranges; 5: plus slice-major enumeration
                 kw = dict(a_kc=False, b_kc=False, M=M, N=N, K=K, split_k=S, slab=slab, tile_order=o)
                 for _ in range(2):
                     gemm(A, B, **kw)
