@@ -6,6 +6,7 @@
 //   src/training.py:118-143 -> src/model/model.py:325-405 -> src/model/modules.py:104-165
 //   + transformers 3.0.2 EncoderLayer / BartDecoder / AdamW.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -301,6 +302,19 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
     const int s256 = 256 / tiles256;
     if (s256 > S && ((tiles >= 128 && nt >= 512) || nt / s256 >= 100)) S = s256;
   }
+  // More 256x256 tiles than CUs and a poorly filled last round (the tied 50320x768 matrix: 591 tiles = 2.31 rounds, 77 %
+  // of three): two or three K slices make the rounds come out even (x 3 = 6.93 of 7).  3137 -> 2480 + 155 us of slab
+  // reduction at 32768 tokens (tools/wgrad_split_sweep.py's sibling measurement).
+  if (S <= 1 && nt >= 256) {
+    const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (tiles256 > 256) {
+      auto eff = [&](int k) { const double r = (double)tiles256 * k / 256.0; return r / std::ceil(r); };
+      int best = 1;
+      for (int k = 2; k <= 3; ++k)
+        if (eff(k) > eff(best) + 0.02) best = k;
+      if (eff(best) >= eff(1) + 0.10) S = best;
+    }
+  }
   if (S > nt / 2) S = nt / 2;
   while (S > 1 && (size_t)S * g.M * g.N > h->slab_floats) --S;
   if (S <= 1 || g.ld_out_f32 != g.N || ((size_t)g.M * g.N & 3)) return run_gemm(g, s);
@@ -451,7 +465,8 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   const size_t lc_floats = (g_f32 || h->Vpad > 65536) ? CH * h->Vpad : (size_t)8 * Md * d;
   float* logits_c = bp.take<float>(lc_floats);
   bf16_t* dlogits_c = bp.act(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
-  const size_t slab_floats = (size_t)20 << 20;          // split-K partial slabs of the weight-gradient GEMMs (80 MB)
+  // split-K partial slabs of the weight-gradient GEMMs: 14 slices of a 768x768 matrix ... 3 of the tied V x d matrix
+  const size_t slab_floats = std::max((size_t)20 << 20, (size_t)3 * h->V * d);
   float* slab = bp.take<float>(slab_floats);
   // slabs of the small-batch split-K forward / dgrad GEMMs (run_gemm) on the caller's stream; only small batches use them
   const size_t small_floats = Mmax <= 8192 ? (size_t)8 * Mmax * d : 1024;
