@@ -50,17 +50,31 @@ def main():
     A = bf(torch.randn((M, K) if akc else (K, M), device=DEV))
     B = bf(torch.randn((N, K) if bkc else (K, N), device=DEV) * 0.05)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    # KMB_STAMP_EPI = a1 (bias + GeLU + stored GeLU': the fc1 forward class) | a2 (x stored GeLU' + column sums: the fc2 data-
+    # gradient class) | res (bias + residual + dropout): the epilogue class of the stamped launches
+    epi = os.environ.get("KMB_STAMP_EPI", "")
+    EK = {}
+    if epi == "a1":
+        EK = dict(bias=torch.randn(N, device=DEV), act=1, preact=torch.empty((M, N), dtype=torch.bfloat16, device=DEV))
+    elif epi == "a2":
+        EK = dict(act=2, aux=bf(torch.randn(M, N, device=DEV)), colsum=torch.zeros(((M + 63) // 64, N), device=DEV))
+    elif epi == "bias":
+        EK = dict(bias=torch.randn(N, device=DEV))
+    elif epi == "biasres":
+        EK = dict(bias=torch.randn(N, device=DEV), residual=bf(torch.randn(M, N, device=DEV)))
+    elif epi == "res":
+        EK = dict(bias=torch.randn(N, device=DEV), residual=bf(torch.randn(M, N, device=DEV)), drop_p=0.1, drop_seed=7)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     stamps = torch.zeros((tiles, 8), dtype=torch.int64, device=DEV)
     for _ in range(5):
-        gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
+        gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out, **EK)
     torch.cuda.synchronize()
     assert lib.kmb_debug_set_stamps(C.c_void_p(stamps.data_ptr())) == 0
     if os.environ.get("KMB_COLD") == "1":   # operands from HBM, as inside a training step (tools/gemm_cold_warm.py)
         junk = torch.empty(600 << 20, dtype=torch.uint8, device=DEV)
         junk.fill_(1)
         torch.cuda.synchronize()
-    gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out)
+    gemm(A, B, a_kc=akc, b_kc=bkc, out_bf16=out, **EK)
     torch.cuda.synchronize()
     lib.kmb_debug_set_stamps(None)
     s = stamps.cpu().numpy().astype(np.int64)

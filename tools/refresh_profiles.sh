@@ -1,8 +1,10 @@
 # Turn the outputs of tools/r2_profile.sh (gpurun_out/$R/, merged back by gpurun) into the committed files under profiles/.
-# Run from the repo root on the build container:  bash tools/refresh_profiles.sh [r02] [1024]
-R=${1:-r02}
-B=${2:-1024}     # the per-GPU batch the evidence run used
-O=gpurun_out/$R
+# Run from the repo root on the build container:  bash tools/refresh_profiles.sh [r02] [1024] [r02]
+#   $1 = the R tag the evidence run wrote under (gpurun_out/$1), $2 = its per-GPU batch, $3 = prefix of the committed files
+I=${1:-r02}
+B=${2:-1024}
+R=${3:-$I}
+O=gpurun_out/$I
 set -e
 tail -1 $O/bench_default.log > profiles/${R}_bench_b${B}.json
 cp $O/prof/p_kernel_stats.csv profiles/${R}_kernel_stats_b${B}.csv
