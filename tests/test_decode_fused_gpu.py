@@ -54,7 +54,10 @@ def _block(**kw):
 
 @pytest.mark.parametrize("R,K,N,ln,act,res", [(320, 768, 768, False, 0, True), (320, 768, 3072, True, 1, False),
                                                (320, 3072, 768, False, 0, True), (37, 768, 768, True, 0, True),
-                                               (5, 1536, 128, False, 0, False), (40, 768, 1536, True, 1, False)])
+                                               (5, 1536, 128, False, 0, False), (40, 768, 1536, True, 1, False),
+                                               # more rows than one round of workgroups
+                                               (700, 768, 768, True, 0, True), (1300, 768, 3072, True, 1, False),
+                                               (1300, 2304, 768, False, 0, True), (650, 3072, 768, False, 0, True)])
 def test_projection_block(R, K, N, ln, act, res):
     torch.manual_seed(R + K + N)
     x = bf(torch.randn(R, K, device=DEV) * 1.5 + 0.3)
@@ -85,7 +88,7 @@ def test_projection_block(R, K, N, ln, act, res):
     assert e < 4e-3
 
 
-@pytest.mark.parametrize("R,Tk", [(320, 1), (320, 7), (37, 20), (16, 64)])
+@pytest.mark.parametrize("R,Tk", [(320, 1), (320, 7), (37, 20), (16, 64), (700, 9), (1290, 19)])
 def test_self_attention_block(R, Tk):
     torch.manual_seed(R * 31 + Tk)
     H, d, Tmax = 12, 768, max(Tk, 20)
@@ -121,7 +124,8 @@ def test_self_attention_block(R, Tk):
 
 
 @pytest.mark.parametrize("B,nb,S,grouped", [(64, 5, 100, True), (64, 5, 100, False), (3, 4, 37, True), (7, 6, 120, True),
-                                            (5, 3, 50, True), (2, 5, 130, True)])
+                                            (5, 3, 50, True), (2, 5, 130, True), (140, 5, 100, True), (259, 5, 100, True),
+                                            (130, 5, 100, False)])
 def test_cross_attention_block(B, nb, S, grouped):
     """grouped: kv_group = beams per item (keys / values staged once per item in LDS when the tile allows it);
     3 beams per item and 130 keys fall back to per-row reads inside the same call."""
