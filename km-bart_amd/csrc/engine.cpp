@@ -466,7 +466,8 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   float* logits_c = bp.take<float>(lc_floats);
   bf16_t* dlogits_c = bp.act(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
   // split-K partial slabs of the weight-gradient GEMMs: 14 slices of a 768x768 matrix ... 3 of the tied V x d matrix
-  const size_t slab_floats = std::max((size_t)20 << 20, (size_t)3 * h->V * d);
+  // (the latter only when the batch is long enough for run_wgrad to split it: >= 256 K steps = 16384 decoder tokens)
+  const size_t slab_floats = std::max((size_t)20 << 20, Md >= 16384 ? (size_t)3 * h->V * d : (size_t)0);
   float* slab = bp.take<float>(slab_floats);
   // slabs of the small-batch split-K forward / dgrad GEMMs (run_gemm) on the caller's stream; only small batches use them
   const size_t small_floats = Mmax <= 8192 ? (size_t)8 * Mmax * d : 1024;
