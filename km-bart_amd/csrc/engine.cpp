@@ -132,7 +132,8 @@ struct kmb_handle {
   // pre-training head scratch
   bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr; float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
   float* losses5 = nullptr;
-  float* slab = nullptr; size_t slab_floats = 0;
+  float* slab = nullptr; size_t slab_floats = 0;            // split-K partials of the side stream's weight gradients
+  float* head_slab = nullptr; size_t head_slab_floats = 0;  // ... of the pre-training heads' (caller's stream)
   float* small_slab = nullptr; size_t small_floats = 0;
   hipEvent_t next_event() { hipEvent_t e = ring[ring_pos]; ring_pos = (ring_pos + 1) % ring.size(); return e; }
   // ---- generation state
@@ -285,7 +286,10 @@ KmbGemm lin_wgrad(const bf16_t* dy, int lddy, const bf16_t* x, int ldx, float* d
 
 // Weight-gradient GEMMs have few output tiles (768x768 -> 36) and a very long reduction (all tokens):
 // split K over workgroups so that the grid fills the chip; partial slabs are summed by one pass.
-int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
+// `slab` / `slab_floats`: the partial-sum buffer of the STREAM the launch goes to.  The side stream's weight gradients use
+// h->slab; the pre-training heads (head_run, caller's stream, concurrent with the tied matrix's gradient on the side
+// stream) have their own h->head_slab -- two streams never share one.
+int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_floats) {
   const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
   const int nt = (g.K + 63) / 64;
   int S = 512 / tiles;   // two 128x128 workgroups per CU; floor: a partial last round costs more than it fills
@@ -316,13 +320,13 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s) {
     }
   }
   if (S > nt / 2) S = nt / 2;
-  while (S > 1 && (size_t)S * g.M * g.N > h->slab_floats) --S;
-  if (S <= 1 || g.ld_out_f32 != g.N || ((size_t)g.M * g.N & 3)) return run_gemm(g, s);
+  while (S > 1 && (size_t)S * g.M * g.N > slab_floats) --S;
+  if (S <= 1 || slab == nullptr || g.ld_out_f32 != g.N || ((size_t)g.M * g.N & 3)) return run_gemm(g, s);
   float* out = g.out_f32;
   const float beta = g.beta;
-  g.split_k = S; g.slab = h->slab; g.out_f32 = nullptr; g.beta = 0.f;
+  g.split_k = S; g.slab = slab; g.out_f32 = nullptr; g.beta = 0.f;
   KCHK(run_gemm(g, s));
-  HIPCHK(kmb_reduce_slabs_launch(h->slab, S, (size_t)g.M * g.N, out, (size_t)g.M * g.N, beta, s));
+  HIPCHK(kmb_reduce_slabs_launch(slab, S, (size_t)g.M * g.N, out, (size_t)g.M * g.N, beta, s));
   return 0;
 }
 
@@ -343,11 +347,11 @@ int ensure_side(kmb_handle* h) {
 // behind an event that marks "everything the main stream has produced so far".  Two different GEMMs in flight are
 // out of phase, so one's output-store burst overlaps the other's matrix work and partial waves get filled.
 int wgrad_side(kmb_handle* h, const KmbGemm& g, hipStream_t sA) {
-  if (!h->side_on || h->side == nullptr) return run_wgrad(h, g, sA);
+  if (!h->side_on || h->side == nullptr) return run_wgrad(h, g, sA, h->slab, h->slab_floats);
   hipEvent_t e = h->next_event();
   HIPCHK(hipEventRecord(e, sA));
   HIPCHK(hipStreamWaitEvent(h->side, e, 0));
-  KCHK(run_wgrad(h, g, h->side));
+  KCHK(run_wgrad(h, g, h->side, h->slab, h->slab_floats));
   // KMB_SIDE_SERIALIZE=1 (diagnostic): the caller's stream waits for every weight gradient -- the side stream's
   // launches stay where they are, nothing overlaps (run-to-run reproducibility)
   static const bool serialize = getenv("KMB_SIDE_SERIALIZE") != nullptr;
@@ -492,7 +496,8 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   float* parts = bp.take<float>(parts_floats(h, (int)Mmax, B));
   // pre-training head scratch (only when heads exist and rows were reserved)
   bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr;
-  float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
+  float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr, *head_slab = nullptr;
+  size_t head_slab_floats = 0;
   float* losses5 = bp.take<float>(8);
   if ((h->head[0].on || h->head[1].on || h->head[2].on) && h->head_rows_cap > 0) {
     const size_t n = (size_t)h->head_rows_cap;
@@ -502,6 +507,9 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     hx = bp.act(n * 2 * d); hy = bp.act(n * d); hdy = bp.act(n * d);
     hdx = bp.act(n * 2 * d); hdlg = bp.act(n * Cpad); hlg = bp.take<float>(n * Cpad);
     hloss = bp.take<float>(n); dhead = bp.take<float>(Md * d);
+    // run_wgrad picks S <= 512 / tiles128 slices: S x M x N stays under 512 x 128 x 128 floats (+ edge-tile slack)
+    head_slab_floats = (size_t)9 << 20;
+    head_slab = bp.take<float>(head_slab_floats);
   }
   if (assign) {
     H->status = status; H->count = count; H->loss_dev = loss_dev; H->xf = xf; H->img_emb = img_emb; H->dimg = dimg;
@@ -511,7 +519,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     H->bb[0] = bb[0]; H->bb[1] = bb[1]; H->dob = dob; H->denc = denc; H->parts = parts;
     H->slab = slab; H->slab_floats = slab_floats; H->small_slab = small_slab; H->small_floats = small_floats;
     H->hx = hx; H->hy = hy; H->hdy = hdy; H->hdx = hdx; H->hdlg = hdlg; H->hlg = hlg; H->hloss = hloss; H->dhead = dhead;
-    H->losses5 = losses5;
+    H->losses5 = losses5; H->head_slab = head_slab; H->head_slab_floats = head_slab_floats;
   }
   return bp.used();
 }
@@ -696,13 +704,13 @@ int head_run(kmb_handle* h, int k, const bf16_t* hdec, int n, const int32_t* row
   if (!need_grad) return 0;
   // out_proj
   KCHK(bias_grad(h, h->hdlg, Cpad, n, C, h->gf(H.ob), s));
-  KCHK(run_wgrad(h, lin_wgrad(h->hdlg, Cpad, h->hy, d, h->gf(H.ow), n, C, d, 0.f), s));
+  KCHK(run_wgrad(h, lin_wgrad(h->hdlg, Cpad, h->hy, d, h->gf(H.ow), n, C, d, 0.f), s, h->head_slab, h->head_slab_floats));
   g = lin_dgrad(h->hdlg, Cpad, h->wb(H.ow), n, Cpad, d);   // reduction over the padded class dim (pad columns are zero)
   g.N = d; g.K = Cpad; g.act = 4; g.aux = h->hy; g.ld_aux = d; g.out_bf16 = h->hdy; g.ld_out_bf16 = d;
   KCHK(run_gemm(g, s));
   // dense
   KCHK(bias_grad(h, h->hdy, d, n, d, h->gf(H.db), s));
-  KCHK(run_wgrad(h, lin_wgrad(h->hdy, d, h->hx, din, h->gf(H.dw), n, d, din, 0.f), s));
+  KCHK(run_wgrad(h, lin_wgrad(h->hdy, d, h->hx, din, h->gf(H.dw), n, d, din, 0.f), s, h->head_slab, h->head_slab_floats));
   g = lin_dgrad(h->hdy, d, h->wb(H.dw), n, d, din);
   g.out_bf16 = h->hdx; g.ld_out_bf16 = din;
   KCHK(run_gemm(g, s));
@@ -945,7 +953,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   if (bt.B <= 0 || bt.S <= 0 || bt.T <= 0) return fail("kmb_forward: empty batch");
   if (bt.S > h->cfg.max_position_embeddings || bt.T > h->cfg.max_position_embeddings)
     return fail("kmb_forward: sequence longer than max_position_embeddings");
-  if (need_grad && !bt.labels) return fail("kmb_forward: need_grad requires labels");
+  if (need_grad && !bt.labels && !extra) return fail("kmb_forward: need_grad requires labels");
   if (need_grad && (!h->G)) return fail("kmb_forward: gradient arena is not bound");
   const size_t need = layout_train(h, nullptr, 0, bt.B, bt.S, bt.T, bt.n_features, false);
   if (need > h->ws_bytes) return fail("kmb_forward: workspace too small (%zu > %zu bytes)", need, h->ws_bytes);
@@ -1064,6 +1072,13 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
     }
   }
+  if (extra && need_grad && !bt.labels) {
+    // no LM term (src/model/model.py:293-302 allows labels=None beside head labels): the decoder-state gradient and the
+    // tied matrix's gradient start from zero; the heads add into the former, backward's embedding scatter-adds into the latter
+    HIPCHK(hipMemsetAsync(h->dhdec, 0, (size_t)Md * d * sizeof(bf16_t), s));
+    HIPCHK(hipMemsetAsync(h->gf(h->shared), 0, (size_t)h->V * d * sizeof(float), s));
+    h->head_wgrad_pending = false;
+  }
   if (extra) {
     // ---- pre-training heads on the decoder states (src/model/model.py:248-289) and the weighted total (:304-307)
     const bool any = (extra->n_mrm > 0 && h->head[0].on) || (extra->n_attr > 0 && h->head[1].on) ||
@@ -1124,7 +1139,6 @@ int kmb_reserve_head_rows(kmb_handle* h, int n) {
 int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, int train, int need_grad,
                          float* logits_out, kmb_bf16* enc_out, void* stream) {
   if (!extra) return fail("kmb_forward_pretrain: extra is required");
-  if (need_grad && !batch->labels) return fail("kmb_forward_pretrain: need_grad requires labels");
   if ((extra->n_mrm > 0 && !h->head[0].on) || (extra->n_attr > 0 && !h->head[1].on) || (extra->n_rel > 0 && !h->head[2].on))
     return fail("kmb_forward_pretrain: rows given for a head this model was built without (num_labels / num_attributes / num_relations)");
   return forward_impl(h, batch, extra, nullptr, train, need_grad, nullptr, logits_out, enc_out, stream);
@@ -1192,7 +1206,14 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
     HIPCHK(kmb_scale_bf16_launch(h->dhdec, (size_t)Md * d, loss_scale, loss_scale_dev, s));
     if (h->head_wgrad_pending) {
       // the tied matrix's head gradient is being written on the side stream: scale it there, behind the GEMM, and move
-      // the completion event behind the scaling (the main stream keeps running ahead)
+      // the completion event behind the scaling (the main stream keeps running ahead).  The device scalar was written
+      // by the caller on the MAIN stream (autograd's grad_out, GradScaler's scale): the side stream must not read it
+      // before the main stream got that far -- it was last ordered behind main in the middle of forward.
+      if (loss_scale_dev) {
+        hipEvent_t e = h->next_event();
+        HIPCHK(hipEventRecord(e, s));
+        HIPCHK(hipStreamWaitEvent(h->side, e, 0));
+      }
       HIPCHK(kmb_scale_f32_launch(h->gf(h->shared), (size_t)h->V * d, loss_scale, loss_scale_dev, h->side));
       HIPCHK(hipEventRecord(h->head_wgrad_done, h->side));
     } else {

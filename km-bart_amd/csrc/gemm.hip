@@ -1847,19 +1847,25 @@ unsigned v11_grid(const KmbGemm& p, int bn) {
   return tiles >= 256 ? 256u : (unsigned)(tiles & ~7L);
 }
 
-// Tile counters of the persistent variants: 64 slots of 16 words per device, zeroed once; a launch takes the next slot
-// and its last workgroup leaves it zeroed again (kernels of one stream are ordered, a handful overlap across streams).
-uint32_t* v11_sched_slot() {
-  constexpr int NSLOT = 64, MAXDEV = 16;
-  static uint32_t* base[MAXDEV] = {};
-  static unsigned seq[MAXDEV] = {};
+// Tile counters of the persistent variants: 16 words per launch, zeroed once; the last workgroup of a launch leaves its
+// slot zeroed again.  Slots are handed out from a ring PER STREAM (and device): kernels of one stream run in order, so a
+// slot is free again long before its stream's ring comes back to it, and launches of different streams (the side
+// stream's weight gradients, the optimizer's or RCCL's stream beside them) can never share a counter however far one
+// stream runs ahead of another.
+uint32_t* v11_sched_slot(hipStream_t stream) {
+  constexpr int NSLOT = 8;
+  struct Ring { uint32_t* base; unsigned seq; };
+  static std::map<std::pair<int, hipStream_t>, Ring> rings;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
-  if (!base[dev]) {
-    if (hipMalloc(&base[dev], NSLOT * 16 * sizeof(uint32_t)) != hipSuccess) { base[dev] = nullptr; return nullptr; }
-    if (hipMemset(base[dev], 0, NSLOT * 16 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto it = rings.find({dev, stream});
+  if (it == rings.end()) {
+    uint32_t* base = nullptr;
+    if (hipMalloc(&base, NSLOT * 16 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (hipMemset(base, 0, NSLOT * 16 * sizeof(uint32_t)) != hipSuccess) return nullptr;   // synchronous: done before any launch
+    it = rings.emplace(std::make_pair(dev, stream), Ring{base, 0u}).first;
   }
-  return base[dev] + (size_t)(seq[dev]++ % NSLOT) * 16;
+  return it->second.base + (size_t)(it->second.seq++ % NSLOT) * 16;
 }
 
 // variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256;
@@ -1868,19 +1874,19 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   if (variant == 11) {
     dim3 grid(v11_grid(p, BN4)), block(256);
-    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot(stream) : nullptr;
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 256>), grid, block, LDS11, stream, p, sched, g_shared_device);
   } else if (variant == 12) {
     dim3 grid(v11_grid(p, 128)), block(256);
-    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot(stream) : nullptr;
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
     else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 128>), grid, block, LDS12, stream, p, sched, g_shared_device);
   } else if (variant == 13) {
     dim3 grid(v11_grid(p, 192)), block(256);
-    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot() : nullptr;
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot(stream) : nullptr;
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);

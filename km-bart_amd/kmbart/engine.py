@@ -1,6 +1,7 @@
 """Python host of libkmbart_hip.so: owns the device arenas (torch tensors) and forwards calls
 through the C-ABI.  torch is used for memory, streams and torch.distributed only."""
 import ctypes as C
+import os
 
 import torch
 
@@ -134,6 +135,15 @@ class Engine:
             self.workspace = None
             self.workspace = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
             check(self.lib.kmb_bind_workspace(self.h, ptr(self.workspace), self.workspace.numel()))
+            self._poison()
+
+    def _poison(self):
+        """KMB_POISON=1 (diagnostic, tests/conftest.py --poison): every byte of the workspace becomes 0xFF -- a NaN in
+        bf16 and in fp32, -1 in the integer tables -- when it is allocated and before every forward / generate, so a
+        kernel that reads activation, scratch or slab memory nobody wrote in THIS call returns NaN deterministically
+        instead of whatever the allocator's block happened to hold.  (torch.empty is the product behaviour.)"""
+        if self.workspace is not None and os.environ.get("KMB_POISON") == "1":
+            self.workspace.fill_(0xFF)
 
     def _batch(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask, labels):
         dev = self.device
@@ -167,6 +177,7 @@ class Engine:
             b, keep, (B, S, T, ntot) = self._batch(input_ids, image_features if encoder_states is None else [],
                                                    attention_mask, decoder_input_ids, decoder_attention_mask, labels)
             self._ensure_ws(self.lib.kmb_workspace_bytes(self.h, B, S, T, ntot))
+            self._poison()
             D = int(self.config.d_model)
             logits = None
             if want_logits:
@@ -237,6 +248,7 @@ class Engine:
                 nmax = max(nmax, ro.numel())
             check(self.lib.kmb_reserve_head_rows(self.h, max(nmax, 8)))
             self._ensure_ws(self.lib.kmb_workspace_bytes(self.h, B, S, T, ntot))
+            self._poison()
             losses = torch.zeros(5, dtype=torch.float32, device=dev)
             ex.losses_out = ptr(losses)
             logits = torch.empty((B * T, self.logits_ld), dtype=torch.float32, device=dev) if want_logits else None
@@ -331,6 +343,7 @@ class Engine:
         with torch.cuda.device(self.device):
             b, keep, (B, S, _, ntot) = self._batch(input_ids, image_features, attention_mask, None, None, None)
             self._ensure_ws(self.lib.kmb_gen_workspace_bytes(self.h, B, S, num_beams, max_length, ntot))
+            self._poison()
             self.fwd_serial += 1
             check(self.lib.kmb_gen_begin(self.h, C.byref(b), num_beams, max_length, _stream()))
             self._keep = keep

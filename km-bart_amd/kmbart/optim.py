@@ -4,6 +4,66 @@ weight_decay 0.0, correct_bias True) whose step() is ONE fused HIP kernel over t
 import torch
 
 
+def reference_parameter_order(names):
+    """`names` (the engine's parameter names) in the order the REFERENCE model's `parameters()` yields them, which is the
+    order a torch-format optimizer state of the reference indexes its per-parameter entries by (reference
+    vcg_train.py:100 `AdamW(model.parameters(), ...)`, saved by src/utils.py:20-39).  Module registration order:
+    src/model/model.py:29-33 (shared, encoder, decoder), src/model/modules.py:73-88 (embed_tokens = shared, embed_images,
+    embed_positions, layers, layernorm_embedding), transformers 3.0.2 EncoderLayer / DecoderLayer (self_attn,
+    self_attn_layer_norm, [encoder_attn, encoder_attn_layer_norm,] fc1, fc2, final_layer_norm) with SelfAttention
+    registering k_proj, v_proj, q_proj, out_proj in that order, BartDecoder (embed_positions, layers,
+    layernorm_embedding), then src/model/model.py:133-158 (mrm_head, attribute_head, relation_head: dense, out_proj)."""
+    have = set(names)
+    out = []
+
+    def add(n):
+        if n in have:
+            out.append(n)
+
+    def lin(prefix):
+        add(prefix + ".weight")
+        add(prefix + ".bias")
+
+    def attn(prefix):
+        for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            lin(prefix + "." + proj)
+
+    def n_layers(side):
+        k = 0
+        while "model.%s.layers.%d.fc1.weight" % (side, k) in have:
+            k += 1
+        return k
+
+    add("model.shared.weight")
+    lin("model.encoder.embed_images.linear")
+    add("model.encoder.embed_positions.weight")
+    for l in range(n_layers("encoder")):
+        p = "model.encoder.layers.%d" % l
+        attn(p + ".self_attn")
+        lin(p + ".self_attn_layer_norm")
+        lin(p + ".fc1")
+        lin(p + ".fc2")
+        lin(p + ".final_layer_norm")
+    lin("model.encoder.layernorm_embedding")
+    add("model.decoder.embed_positions.weight")
+    for l in range(n_layers("decoder")):
+        p = "model.decoder.layers.%d" % l
+        attn(p + ".self_attn")
+        lin(p + ".self_attn_layer_norm")
+        attn(p + ".encoder_attn")
+        lin(p + ".encoder_attn_layer_norm")
+        lin(p + ".fc1")
+        lin(p + ".fc2")
+        lin(p + ".final_layer_norm")
+    lin("model.decoder.layernorm_embedding")
+    for head in ("mrm_head", "attribute_head", "relation_head"):
+        lin(head + ".dense")
+        lin(head + ".out_proj")
+    if len(out) != len(have):
+        raise ValueError("parameters without a place in the reference order: %s" % sorted(have - set(out))[:4])
+    return out
+
+
 class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         if lr < 0.0:
@@ -138,7 +198,14 @@ class AdamW(torch.optim.Optimizer):
         for g, sg in zip(self.param_groups, state["param_groups"]):
             if len(sg["params"]) != len(g["params"]):
                 raise ValueError("loaded optimizer state has a parameter group of a different size")
-            for p, idx in zip(g["params"], sg["params"]):
+            # The saved indices follow the REFERENCE model's parameters() order (shared first, k/v/q with weight and bias
+            # interleaved, layernorm_embedding after the layers), not this engine's arena order: map by NAME.
+            by_name = {getattr(p, "_kmb_name", None): p for p in g["params"]}
+            if None in by_name:
+                raise RuntimeError("a parameter of this optimizer does not live in a kmbart engine arena")
+            order = reference_parameter_order(list(by_name))
+            for name, idx in zip(order, sg["params"]):
+                p = by_name[name]
                 st = state["state"].get(idx)
                 if st is None:
                     st = state["state"].get(str(idx))
@@ -147,8 +214,8 @@ class AdamW(torch.optim.Optimizer):
                 eng = p._kmb_engine
                 off, cnt = p._kmb_range
                 if st["exp_avg"].numel() != cnt:
-                    raise ValueError("optimizer state of parameter %s has %d elements, expected %d"
-                                     % (idx, st["exp_avg"].numel(), cnt))
+                    raise ValueError("optimizer state %s (%s in the reference's parameter order) has %d elements, expected %d"
+                                     % (idx, name, st["exp_avg"].numel(), cnt))
                 eng.exp_avg[off: off + cnt].copy_(st["exp_avg"].reshape(-1))
                 eng.exp_avg_sq[off: off + cnt].copy_(st["exp_avg_sq"].reshape(-1))
                 steps.append(int(st["step"]))

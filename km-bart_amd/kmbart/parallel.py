@@ -158,6 +158,14 @@ class DistributedDataParallel(torch.nn.Module):
         optimizer._ddp_fused = self
         return True
 
+    def detach_optimizer(self):
+        """Ends the fusion (the training loops call this when they return): `loss.backward()` is a plain backward +
+        all-reduce again and `optimizer.step()` a plain step."""
+        if getattr(self, "_opt", None) is not None:
+            self._opt._ddp_fused = None
+            self._opt._fused_pending = False
+        self._opt = None
+
     def _step_piece(self, off, cnt):
         if self._opt is not None and self._fusing:
             self._opt.fused_piece_step(self.engine, off, cnt)
@@ -168,6 +176,10 @@ class DistributedDataParallel(torch.nn.Module):
             self._first_reduce = False
             if self.reducer.comm_stream is not None:
                 self.reducer.comm_stream.wait_stream(torch.cuda.current_stream())
+        if self._opt is not None and getattr(self._opt, "_fused_pending", False):
+            raise RuntimeError("loss.backward() ran twice without optimizer.step() while an optimizer is attached to the "
+                               "data-parallel wrapper (attach_optimizer fuses the AdamW step into backward); call "
+                               "detach_optimizer() for gradient accumulation or custom loops")
         self._fusing = self._opt is not None and self._opt.begin_fused_step(self.engine)
         self.reducer.launch()
         self.reducer.finish()

@@ -252,6 +252,7 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             p = nn.Parameter(eng.view(eng.params, n))
             p.grad = eng.view(eng.grads, n)
             p._kmb_engine = eng
+            p._kmb_name = n
             off, rows, cols = eng.index[n]
             p._kmb_range = (off, rows * cols)
             self._p[n] = p
@@ -684,8 +685,8 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
         if labels is not None:
             lm_labels = labels.clone()
             lm_labels[lm_labels == cfg.cls_token_id] = -100   # model.py:297-298
-        if lm_labels is None:
-            raise NotImplementedError("pre-training forward without LM labels is not implemented")
+        if mrm_labels is not None and mrm_mask is None:
+            raise ValueError('"mrm_mask" cannot be None while "mrm_labels" is set')   # model.py:228-229
         need_grad = torch.is_grad_enabled()
         factors = (float(cfg.lm_loss_factor), float(cfg.mrm_loss_factor), float(cfg.attribute_loss_factor),
                    float(cfg.relation_loss_factor))
@@ -694,7 +695,9 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
                                               factors=factors, train=self.training, need_grad=need_grad,
                                               want_logits=bool(return_logits))
         total = _LossFn.apply(self._anchor, self, losses[0:1]) if need_grad else losses[0]
-        out = _DeviceLossDict(loss=total, lm_loss=losses[1])
+        out = _DeviceLossDict(loss=total)
+        if lm_labels is not None:   # model.py:293-302: without LM labels the term is 0 and the key is absent
+            out["lm_loss"] = losses[1]
         if mrm is not None and mrm[0].numel() > 0:
             out["mrm_loss"] = losses[2]
         if attr is not None and attr[0].numel() > 0:

@@ -29,6 +29,14 @@ def _attach(model, optimizer, ok):
         model.attach_optimizer(optimizer)
 
 
+def _release(model, optimizer):
+    """The fusions above hold only inside these loops: afterwards `loss.backward()` is a plain backward again (gradient
+    accumulation, clip_grad_norm_, a diagnostic backward) and `optimizer.step()` a plain step."""
+    _allow_overlap(optimizer, False)
+    if hasattr(model, "detach_optimizer"):
+        model.detach_optimizer()
+
+
 def _features(feats, device):
     """list of per-sample tensors (reference collator) or a kmbart.data.PackedFeatures"""
     return feats.to(device) if hasattr(feats, "packed") else [f.to(device) for f in feats]
@@ -36,6 +44,15 @@ def _features(feats, device):
 
 def fine_tune(epoch, model, train_loader, optimizer, device, args, logger=None, callback=None, log_interval=1,
               tb_writer=None, tb_interval=1, scaler=None):
+    try:
+        return _fine_tune(epoch, model, train_loader, optimizer, device, args, logger, callback, log_interval, tb_writer,
+                          tb_interval, scaler)
+    finally:
+        _release(model, optimizer)
+
+
+def _fine_tune(epoch, model, train_loader, optimizer, device, args, logger, callback, log_interval, tb_writer, tb_interval,
+               scaler):
     n_steps = len(train_loader)
     model.train()
     t0 = datetime.now()
@@ -99,6 +116,15 @@ def pretrain(epoch, model, train_loader, optimizer, device, args, logger=None, c
              tb_writer=None, tb_interval=1, scaler=None):
     """Multi-task pre-training loop with the reference's contract (reference src/training.py:9-93): the model
     returns a dict of losses as outputs[0]; `loss` drives backward, the others are logged."""
+    try:
+        return _pretrain(epoch, model, train_loader, optimizer, device, args, logger, callback, log_interval, tb_writer,
+                         tb_interval, scaler)
+    finally:
+        _release(model, optimizer)
+
+
+def _pretrain(epoch, model, train_loader, optimizer, device, args, logger, callback, log_interval, tb_writer, tb_interval,
+              scaler):
     n_steps = len(train_loader)
     model.train()
     t0 = datetime.now()

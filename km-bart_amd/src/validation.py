@@ -6,6 +6,7 @@ from datetime import datetime
 
 import torch
 
+from src.generation import generate_text
 from src.training import _features, _on
 
 
@@ -52,3 +53,33 @@ def validate_pretraining_loss(epoch, model, val_loader, device, args, logger=Non
             mrm_mask=_on(batch, "mrm_mask", device))   # the reference omits the mask here (validation.py:36); the rows need it
         return out[0]["loss"].item()
     return _run(epoch, model, val_loader, device, args, logger, log_interval, tb_writer, forward)
+
+
+def validate_generation_score(epoch, model, gen_loader, reference, tokenizer, device, args, logger=None, log_interval=1,
+                              tb_writer=None):
+    """Reference src/validation.py:124-165: generate with `generate_text`, score the generations against `reference` with
+    `src.evaluation.compute_metric_inference` (BLEU / METEOR / CIDEr through the pycocoevalcap Java tools), log and
+    record `score/<name>` scalars.  The generation half is the hot path and runs here; the metric package is outside it
+     and is used when an importable `src.evaluation` is on the path, otherwise this
+    raises NotImplementedError BEFORE spending the generation time."""
+    try:
+        import src.evaluation as vcg   # provided by the user (the reference's src/evaluation.py + its Java dependencies)
+    except ImportError as e:
+        raise NotImplementedError(
+            "validate_generation_score needs the reference's evaluation metrics (src/evaluation.py: BLEU / METEOR / CIDEr "
+            "via pycocoevalcap and Java), which are outside the MI355X hot path and not shipped; put that module on the "
+            "path as `src.evaluation`, or use --validate_loss") from e
+    if not getattr(args, "cpu", False) and hasattr(model, "module"):
+        model = model.module
+    generated = generate_text(model=model, gen_loader=gen_loader, tokenizer=tokenizer, device=device, args=args,
+                              logger=logger, log_interval=log_interval)
+    scores = vcg.compute_metric_inference(gens_list=generated, refs_list=reference)
+    if logger is not None:
+        logger.info("Validation scores", pad=True)
+        logger.info("Epoch: {}, BLEU2: {}, METEOR: {}, CIDEr: {}".format(epoch + 1, scores["BLEU2"], scores["METEOR"],
+                                                                         scores["CIDEr"]))
+        logger.line()
+    if tb_writer is not None:
+        for k, v in scores.items():
+            tb_writer.add_scalar("score/{}".format(k), v, epoch + 1)
+    return scores

@@ -165,16 +165,23 @@ def test_adamw_param_groups_and_torch_state_dict():
     params = list(model.parameters())
     opt = AdamW(params, lr=1e-3)
     g = torch.Generator().manual_seed(0)
-    state = {"state": {i: {"step": 7, "exp_avg": torch.randn(p.shape, generator=g),
-                           "exp_avg_sq": torch.rand(p.shape, generator=g)} for i, p in enumerate(params)},
+    # ... whose indices follow the REFERENCE model's parameters() order (shared first, k/v/q interleaved with their biases,
+    # layernorm_embedding after the layers: tests/test_host_logic_cpu.py pins that order on transformers' BART), not
+    # this engine's arena order
+    from kmbart.optim import reference_parameter_order
+    by_name = dict(model.named_parameters())
+    order = reference_parameter_order(list(by_name))
+    assert order[0] == "model.shared.weight" and order != [n for n, _ in model.named_parameters()]
+    state = {"state": {i: {"step": 7, "exp_avg": torch.randn(by_name[n].shape, generator=g),
+                           "exp_avg_sq": torch.rand(by_name[n].shape, generator=g)} for i, n in enumerate(order)},
              "param_groups": [{"lr": 5e-4, "betas": (0.9, 0.999), "eps": 1e-6, "weight_decay": 0.0,
-                               "correct_bias": True, "params": list(range(len(params)))}]}
+                               "correct_bias": True, "params": list(range(len(order)))}]}
     opt.load_state_dict(state)
     eng = model._engine
     assert eng.step_count == 7 and opt.param_groups[0]["lr"] == 5e-4
-    for i, p in enumerate(params):
-        o, n = p._kmb_range
-        assert torch.equal(eng.exp_avg[o: o + n].cpu(), state["state"][i]["exp_avg"].reshape(-1))
-        assert torch.equal(eng.exp_avg_sq[o: o + n].cpu(), state["state"][i]["exp_avg_sq"].reshape(-1))
+    for i, n in enumerate(order):
+        o, cnt = by_name[n]._kmb_range
+        assert torch.equal(eng.exp_avg[o: o + cnt].cpu(), state["state"][i]["exp_avg"].reshape(-1)), n
+        assert torch.equal(eng.exp_avg_sq[o: o + cnt].cpu(), state["state"][i]["exp_avg_sq"].reshape(-1)), n
     with pytest.raises(ValueError):
         opt.load_state_dict({"foo": 1})

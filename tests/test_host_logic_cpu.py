@@ -161,3 +161,32 @@ def test_packed_features_roundtrip():
     assert len(pf) == 3 and pf.n_total == 5 and pf.offsets.tolist() == [0, 3, 3, 5]
     packed, offs, n = pack_features(pf, 8, "cpu")
     assert n == 5 and torch.equal(packed, pf.packed) and offs.dtype == torch.int32
+
+
+def test_reference_parameter_order_matches_bart_registration_order():
+    """A torch-format optimizer state of the reference is indexed by the position of a parameter in `model.parameters()`
+    (reference vcg_train.py:100, src/utils.py:20-39).  `reference_parameter_order` restates that order; its BART part is
+    pinned here on the installed transformers' BartForConditionalGeneration, whose module registration order for these
+    modules is the one of 3.0.2 (k_proj, v_proj, q_proj, out_proj; layernorm_embedding after the layers), and the
+    KM-BART additions on the reference source: embed_images is registered right after embed_tokens
+    (src/model/modules.py:73-74), the heads after the model (src/model/model.py:131-158)."""
+    from transformers import BartConfig, BartForConditionalGeneration
+    from kmbart.optim import reference_parameter_order
+    from oracle import kmbart_oracle as O
+    ocfg = O.OracleConfig(vocab_size=64, d_model=64, encoder_layers=2, decoder_layers=3, encoder_attention_heads=1,
+                          decoder_attention_heads=1, encoder_ffn_dim=64, decoder_ffn_dim=64, max_position_embeddings=16,
+                          num_labels=7, num_attributes=5, num_relations=3)
+    names = O.param_names(ocfg) + O.head_param_names(ocfg)
+    order = reference_parameter_order(names)
+    assert sorted(order) == sorted(names)
+    hf = BartForConditionalGeneration(BartConfig(
+        vocab_size=64, d_model=64, encoder_layers=2, decoder_layers=3, encoder_attention_heads=1,
+        decoder_attention_heads=1, encoder_ffn_dim=64, decoder_ffn_dim=64, max_position_embeddings=16))
+    hf_names = [n for n, _ in hf.named_parameters()]
+    bart_part = [n for n in order if "embed_images" not in n and "_head." not in n]
+    assert bart_part == hf_names
+    i = order.index("model.encoder.embed_images.linear.weight")
+    assert order[i - 1] == "model.shared.weight" and order[i + 1] == "model.encoder.embed_images.linear.bias"
+    assert order[i + 2] == "model.encoder.embed_positions.weight"
+    assert order[-12:] == [h + s for h in ("mrm_head", "attribute_head", "relation_head")
+                           for s in (".dense.weight", ".dense.bias", ".out_proj.weight", ".out_proj.bias")]

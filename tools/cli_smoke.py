@@ -3,9 +3,12 @@ write a tiny VCG / COCO / Visual Genome corpus + a tiny model config + a small B
     vcg_train.py --data_dir ... --validate_loss      (fine-tuning from files, checkpoint written)
     pretrain.py --dataset coco_train ... --dataset vg_train ...   (multi-task pre-training from files)
     vcg_generate.py --data_dir ... --checkpoint <fine-tuned>      (beam generation, decoded text written)
-Exit code 0 and the three artefacts present = pass."""
+Pass = exit code 0, the three artefacts present, AND every loss the training drivers logged is a finite number (a NaN
+from the engine would otherwise go through: the drivers themselves only log it)."""
 import json
+import math
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -44,23 +47,32 @@ cfg_path = os.path.join(work, "tiny.json")
 json.dump(cfg, open(cfg_path, "w"))
 
 
-def run(args):
+def run(args, expect_losses=False):
     print("+", " ".join(args), flush=True)
     r = subprocess.run([sys.executable] + args, cwd=PKG, capture_output=True, text=True, timeout=600)
-    tail = (r.stdout + r.stderr).strip().splitlines()[-6:]
+    text = r.stdout + r.stderr
+    tail = text.strip().splitlines()[-6:]
     print("\n".join("    " + t[:200] for t in tail), flush=True)
     if r.returncode != 0:
         sys.exit("FAILED: " + " ".join(args))
+    losses = [float(m) for m in re.findall(r"[Ll]oss:\s*([-+]?(?:nan|inf|[0-9.]+(?:e[-+]?[0-9]+)?))", text)]
+    if expect_losses and not losses:
+        sys.exit("FAILED (no loss was logged): " + " ".join(args))
+    bad = [v for v in losses if not math.isfinite(v) or v <= 0.0]
+    if bad:
+        sys.exit("FAILED (non-finite / non-positive loss %s among %d logged): %s" % (bad[:3], len(losses), " ".join(args)))
+    print("    %d logged losses, all finite (first %.4f, last %.4f)" % (len(losses), losses[0], losses[-1]) if losses else
+          "    no losses logged", flush=True)
 
 
 ck = os.path.join(work, "ckpt")
 run(["vcg_train.py", "--model_config", cfg_path, "--checkpoint_dir", ck, "--data_dir", vcg, "--tokenizer_json", tok_json,
-     "--epochs", "2", "--batch_size", "4", "--lr", "1e-3", "--validate_loss"])
+     "--epochs", "2", "--batch_size", "4", "--lr", "1e-3", "--validate_loss"], expect_losses=True)
 assert os.path.exists(os.path.join(ck, "epoch2", "pytorch_model.bin")) and os.path.exists(os.path.join(ck, "epoch2", "training_data.pt"))
 pk = os.path.join(work, "pre")
 run(["pretrain.py", "--model_config", cfg_path, "--checkpoint_dir", pk, "--dataset", "coco_train", coco, "--dataset",
      "vg_train", vg, "--dataset", "vcg_train", vcg, "--tokenizer_json", tok_json, "--epochs", "1", "--batch_size", "4",
-     "--max_img_num", "16"])
+     "--max_img_num", "16"], expect_losses=True)
 assert os.path.exists(os.path.join(pk, "model0", "pytorch_model.bin"))
 out = os.path.join(work, "gen.json")
 run(["vcg_generate.py", "--checkpoint", os.path.join(ck, "epoch2"), "--data_dir", vcg, "--split", "val", "--output_file", out,
