@@ -102,6 +102,68 @@ def loss_parity(model, dev):
     return abs(float(got) - float(ref)) / abs(float(ref)), float(got), float(ref)
 
 
+def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
+    """The dominant kernel = the bf16 MFMA GEMM: every launch of `n_prof` steps timed with HIP events on its own stream
+    (weight gradients moved to the caller's stream for this leg, so launches do not overlap each other)."""
+    import glob
+    import tempfile
+    from kmbart import _lib
+    lib = _lib.load()
+    agg = {}
+    lib.kmb_set_side_stream(model._engine.h, 0)  # kernels timed one at a time, not overlapped with each other
+    step()
+    alg_bytes, alg_n = 0.0, 0
+    for i in range(n_prof):
+        lib.kmb_profile_gemm(1)
+        step()
+        torch.cuda.synchronize()
+        for variant, name in ((3, "fwd"), (2, "dgrad"), (0, "wgrad")):
+            n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(lib.kmb_profile_read(variant, C.byref(n), C.byref(ms), C.byref(fl)))
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += n.value
+            a[1] += ms.value
+            a[2] += fl.value
+        if i == n_prof - 1:   # minimal bytes of the same launches: A and B read once, C written once
+            dump = os.path.join(tempfile.gettempdir(), "kmb_gemm_launches_%d.txt" % os.getpid())
+            _lib.check(lib.kmb_profile_dump(dump.encode()))
+            for line in open(dump):
+                v, M, N, K, sp, act, us = line.split()
+                v, M, N, K, act = int(v), int(M), int(N), int(K), int(act)
+                out_b = 4 if v == 0 else 2                               # weight gradients are fp32, everything else bf16
+                extra = M * N * 2 if act in (1, 2) else 0                # GeLU' written / read beside the output
+                alg_bytes += 2.0 * (M * K + N * K) + out_b * M * N + extra
+                alg_n += 1
+            os.remove(dump)
+        lib.kmb_profile_gemm(0)
+    lib.kmb_set_side_stream(model._engine.h, 1)
+    traffic, traffic_src = None, None
+    # HBM bytes come from rocprofv3 --pmc passes of this workload (tools/r3_profile.sh): the newest committed round
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        rec = json.load(open(pmc))
+        if rec.get("per_gpu_batch") == per_gpu_batch:
+            traffic = rec["gemm_hbm_bytes_per_launch"]
+            traffic_src = "profiles/%s: %s" % (os.path.basename(pmc), rec["method"])
+            break
+    tot_ms = sum(a[1] for a in agg.values())
+    tot_fl = sum(a[2] for a in agg.values())
+    launches = sum(a[0] for a in agg.values())
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per GEMM launch",
+        "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_n, 1)),
+        "kernel": "gemm_kernel_v7 / v8 / v11 / v14 (all GEMM launches of a step, timed serially on their stream)",
+        "per_gpu_batch": per_gpu_batch,
+        "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
+        "gemm_ms_per_step": round(tot_ms / n_prof, 3),
+        "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),
+                           "tflops": round(a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None}
+                       for k, a in agg.items()},
+    }
+
+
 def timed_steps(step, n_warm, n_steps):
     for _ in range(n_warm):
         step()
@@ -171,6 +233,21 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
         return (time.perf_counter() - t0) / n, o
 
     dt, out = timed(reps)
+    # correctness gate on the measured path: the fused decode blocks (csrc/decode.hip, what `value` times) must return
+    # the token ids of the launch-per-operation path (KMB_GEN_FUSED=0: GEMM / attention / LayerNorm kernels that
+    # tests/test_model_gpu.py pins on the oracle) on the same inputs
+    prev = os.environ.get("KMB_GEN_FUSED")
+    os.environ["KMB_GEN_FUSED"] = "0"
+    try:
+        ref_ids = model.generate(**kw)
+    finally:
+        if prev is None:
+            del os.environ["KMB_GEN_FUSED"]
+        else:
+            os.environ["KMB_GEN_FUSED"] = prev
+    n_cmp = min(out.shape[1], ref_ids.shape[1])
+    ids_match = bool(out.shape == ref_ids.shape and torch.equal(out[:, :n_cmp], ref_ids[:, :n_cmp]))
+    rows_equal = int((out[:, :n_cmp] == ref_ids[:, :n_cmp]).all(dim=1).sum()) if out.shape[0] == ref_ids.shape[0] else 0
     dt32, out32 = timed(3, max_length=32)       # the "32-token-out" variant
     dt1, out1 = timed(3, num_beams=1)           # greedy: the reference CLI's default (vcg_generate.py:99)
     steps = out.shape[1] - 1
@@ -186,6 +263,7 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
             "ms_per_generate": round(dt * 1e3, 2), "decoder_steps": int(steps),
             "us_per_decoder_step": round(dt / steps * 1e6, 1),
             "hbm_bytes_per_step": int(per_step), "hbm_frac": round(per_step / (dt / steps) / 6.3e12, 4),
+            "gen_ids_match": ids_match, "gen_rows_identical": "%d/%d" % (rows_equal, int(out.shape[0])),
             "max_length_32": {"value": round(batch / dt32, 1), "ms_per_generate": round(dt32 * 1e3, 2),
                               "decoder_steps": int(out32.shape[1] - 1)},
             "greedy": {"value": round(batch / dt1, 1), "ms_per_generate": round(dt1 * 1e3, 2),
@@ -313,6 +391,10 @@ def main():
     if parity is not None:
         out["ce_loss_rel_delta_vs_oracle_b2"] = float("%.3e" % parity[0])
 
+    leg_steps = {}
+    if use_dist and hasattr(ddp, "comm_report"):
+        out["comm"] = ddp.comm_report()   # every rank measures (matched collectives); rank 0 prints
+
     if rank == 0 and args.gpus == 1 and not args.no_pcie:
         # side measurement, never `value`: batches start in pinned HOST memory (fp32 region features, 295 KB/sample)
         # and reach the GPU through the packed-feature prefetcher (copy of batch i+1 overlaps step i)
@@ -359,75 +441,32 @@ def main():
             sbatch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sb.items()}
             sbatch["image_features"] = PackedFeatures.from_list(sb["image_features"], 2052).to(dev)
 
-            def sstep():
+            def sstep(sbatch=sbatch):
                 model.train_step_fwd_bwd(sbatch)
                 opt.step()
             sdt = timed_steps(sstep, 4, 10 if bsz <= 512 else 6)
             sweep[str(bsz)] = {"tokens_per_sec": round(bsz * (S_ENC + T_DEC) / sdt, 1), "ms_per_step": round(sdt * 1e3, 3)}
+            if bsz in (64, 256, 512, 1024):
+                leg_steps[bsz] = (sstep, sweep[str(bsz)])
         sweep[str(args.batch)] = {"tokens_per_sec": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 3)}
         out["batch_sweep"] = sweep
+        out["legs"] = sweep   # the same objects: b = 64 / 256 / 512 / 1024 get their GEMM roofline below
         # (3) BASELINE config 5: generation
         out["generation"] = generation_leg(dev)
 
     if rank == 0 and not args.no_roofline:
-        # dominant kernel = the bf16 MFMA GEMM: time every launch of a few steps with HIP events on its stream
-        lib = _lib.load()
-        agg = {}
-        n_prof = 3
-        lib.kmb_set_side_stream(model._engine.h, 0)  # kernels timed one at a time, not overlapped with each other
         model._post_backward = None   # rank 0 only from here on: no collectives (the other ranks are at the final barrier)
-        step()
-        for _ in range(n_prof):
-            lib.kmb_profile_gemm(1)
-            step()
-            torch.cuda.synchronize()
-            for variant, name in ((3, "fwd"), (2, "dgrad"), (0, "wgrad")):
-                n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-                _lib.check(lib.kmb_profile_read(variant, C.byref(n), C.byref(ms), C.byref(fl)))
-                a = agg.setdefault(name, [0, 0.0, 0.0])
-                a[0] += n.value
-                a[1] += ms.value
-                a[2] += fl.value
-            if _ == n_prof - 1:   # minimal bytes of the same launches: A and B read once, C written once
-                import tempfile
-                dump = os.path.join(tempfile.gettempdir(), "kmb_gemm_launches_%d.txt" % os.getpid())
-                _lib.check(lib.kmb_profile_dump(dump.encode()))
-                alg_bytes, alg_n = 0.0, 0
-                for line in open(dump):
-                    v, M, N, K, sp, act, us = line.split()
-                    v, M, N, K, act = int(v), int(M), int(N), int(K), int(act)
-                    out_b = 4 if (v == 0 or N >= 50000) else 2          # weight gradients and logits are fp32
-                    extra = M * N * 2 if act in (1, 2) else 0            # pre-activation written / read (GeLU, GeLU')
-                    alg_bytes += 2.0 * (M * K + N * K) + out_b * M * N + extra
-                    alg_n += 1
-                os.remove(dump)
-            lib.kmb_profile_gemm(0)
-        lib.kmb_set_side_stream(model._engine.h, 1)
-        traffic, traffic_src = None, None
-        # HBM bytes come from rocprofv3 --pmc passes of this workload (tools/r2_profile.sh): the newest committed round
-        import glob
-        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-            rec = json.load(open(pmc))
-            if rec.get("per_gpu_batch") == args.batch:
-                traffic = rec["gemm_hbm_bytes_per_launch"]
-                traffic_src = "profiles/%s: %s" % (os.path.basename(pmc), rec["method"])
-                break
-        tot_ms = sum(a[1] for a in agg.values())
-        tot_fl = sum(a[2] for a in agg.values())
-        launches = sum(a[0] for a in agg.values())
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        out["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per GEMM launch",
-            "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_n, 1)),
-            "kernel": "gemm_kernel_v7 / v8 / v11<A_KC,B_KC,256|128|192> (all GEMM launches of a step, timed serially)",
-            "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
-            "gemm_ms_per_step": round(tot_ms / n_prof, 3),
-            "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),
-                               "tflops": round(a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None}
-                           for k, a in agg.items()},
-        }
+        out["roofline"] = gemm_roofline(model, step, args.batch)
+        if args.gpus == 1 and not args.no_extras:
+            # every named batch carries its own GEMM roofline (SURVEY section 8d names b = 64 and 256; rounds 1-2 quoted
+            # 512, round 2's default is 1024): round-to-round comparisons do not depend on the default
+            for bsz, (sstep, leg) in sorted(leg_steps.items()):
+                r = gemm_roofline(model, sstep, bsz, n_prof=2)
+                leg["roofline"] = {k: r[k] for k in ("achieved", "frac", "launches_per_step", "gemm_ms_per_step", "by_variant",
+                                                     "traffic", "algorithmic_bytes_per_launch")}
+            out["legs"][str(args.batch)]["roofline"] = {k: out["roofline"][k] for k in (
+                "achieved", "frac", "launches_per_step", "gemm_ms_per_step", "by_variant", "traffic",
+                "algorithmic_bytes_per_launch")}
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         print("[bench] GPU leg done: %.1f tokens/s, %.3f ms/step; timing the CPU baseline..." %
               (value, dt / args.steps * 1e3), file=sys.stderr, flush=True)

@@ -145,6 +145,7 @@ class DistributedDataParallel(torch.nn.Module):
             _lib.load().kmb_gemm_shared_device(1)
             self._first_reduce = True
             self._fusing = False
+            self._tail_events = []
             eng.adamw_overlap_ok = False   # gradients are final only after the all-reduce, not at the bucket events
 
     def attach_optimizer(self, optimizer):
@@ -157,6 +158,24 @@ class DistributedDataParallel(torch.nn.Module):
         self._opt = optimizer
         optimizer._ddp_fused = self
         return True
+
+    def comm_report(self):
+        """What the data-parallel exchange of a step looked like, for bench.py's JSON line: ranks, collective backend,
+        gradient buckets / pieces, bytes all-reduced per step and the exposed tail -- the time the compute stream spent
+        waiting for the communication stream after backward's last kernel (median over the last steps; syncs)."""
+        if self.reducer is None:
+            return {"rccl_ranks": self.world, "reduced": False}
+        r = self.reducer
+        esz = 2 if r.grad_dtype == torch.bfloat16 else self.engine.grads.element_size()
+        tails = []
+        if self._tail_events:
+            torch.cuda.synchronize(self.engine.device)
+            tails = sorted(a.elapsed_time(b) for a, b in self._tail_events)
+        return {"rccl_ranks": self.world, "backend": r.backend, "buckets": len(self.engine.buckets()),
+                "pieces": len(r.pieces), "bytes_reduced_per_step": int(sum(c for _, _, c in r.pieces) * esz),
+                "wire_dtype": "bf16" if esz == 2 else "fp32", "fused_optimizer": self._opt is not None,
+                "exposed_tail_ms": round(tails[len(tails) // 2], 3) if tails else None,
+                "exposed_tail_ms_max": round(tails[-1], 3) if tails else None, "steps_measured": len(tails)}
 
     def detach_optimizer(self):
         """Ends the fusion (the training loops call this when they return): `loss.backward()` is a plain backward +
@@ -181,8 +200,18 @@ class DistributedDataParallel(torch.nn.Module):
                                "data-parallel wrapper (attach_optimizer fuses the AdamW step into backward); call "
                                "detach_optimizer() for gradient accumulation or custom loops")
         self._fusing = self._opt is not None and self._opt.begin_fused_step(self.engine)
+        # exposed tail: the compute stream has nothing left to run between these two events except waiting for the
+        # communication stream (the all-reduces that did not fit under backward + the optimizer pieces chained behind them)
+        pair = None
+        if self.engine.grads.is_cuda:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
         self.reducer.launch()
         self.reducer.finish()
+        if pair is not None:
+            pair[1].record()
+            self._tail_events.append(pair)
+            del self._tail_events[:-32]
         if self._fusing:
             self._opt.end_fused_step(self.engine)
         self._fusing = False

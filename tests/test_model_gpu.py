@@ -39,10 +39,10 @@ def cfg_from_oracle(ocfg, **over):
     return MultiModalBartConfig.from_dict(d)
 
 
-def build(ocfg, sd, **over):
+def build(ocfg, sd, device=None, **over):
     model = MultiModalBartForConditionalGeneration(cfg_from_oracle(ocfg, **over))
     model.load_state_dict(sd, strict=False)
-    model.to(DEV)
+    model.to(DEV if device is None else device)
     return model
 
 
