@@ -979,13 +979,14 @@ constexpr int LDS12 = 2 * (BM4 + 128) * BK * 2 + 4 * EPW_BYTES;   // 256x128 til
 template <int ACT, bool RES, bool CS, bool FAST, int WROWS, int NJ = 8>
 __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][NJ], float* ef, int lane, int r, int g,
                                              int row0w, int col0w) {
-  constexpr int WCOLS = NJ * 16;   // columns of this wave's block (128, or 96 for the 256x192 tile)
+  constexpr int WCOLS = NJ * 16;   // columns of this wave's block (128, 96 for the 256x192 tile, 64 for the 8-wave kernel)
+  constexpr int LDE = WCOLS > 64 ? 128 : 64;   // row stride of the staging image (floats)
   float csum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   // transposed accumulators (see the MFMA operand order in the K loop): lane (r, g) holds C[16 i + r][16 j + 4 g .. +3],
   // one ds_write_b128 per MFMA tile; 16-byte groups XOR-swizzled by the row so that the 16 row-lanes spread over banks
-  float* const wbase = ef + r * 128;
+  float* const wbase = ef + r * LDE;
   const int sw = (r & 7) << 3;
   auto stage = [&](const f32x4 (&a)[NJ]) {
 #pragma unroll
@@ -1004,7 +1005,7 @@ __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][N
       case 6: stage(acc[6]); break;
       default: stage(acc[7]); break;
     }
-    gemm_epilogue_body<64, true, 4, 128, true, 128, ACT, RES, CS, FAST, true, WCOLS>(p, ef, nullptr, lane, row0w + i * 16,
+    gemm_epilogue_body<64, true, 4, LDE, true, 128, ACT, RES, CS, FAST, true, WCOLS>(p, ef, nullptr, lane, row0w + i * 16,
                                                                                     col0w, csum);
   }
   if (CS && (ACT >= 0 || p.colsum != nullptr)) {
@@ -1039,10 +1040,13 @@ template <bool BIAS, bool SCALE, int ACT, bool RES, bool DROP, bool CS, int WROW
 __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)[8][NJ], float* ef, int lane, int r, int g,
                                                   int row0w, int col0w) {
   constexpr int WCOLS = NJ * 16;
-  const int lr = lane >> 4;
+  // lane map of the row-major pass: CL column-lanes of 8 columns x RPI rows per iteration, NIT iterations per 16-row chunk
+  // (128- and 96-column blocks: 16 x 4, four iterations; the 8-wave kernel's 64-column blocks: 8 x 8, two iterations)
+  constexpr int CL = WCOLS > 64 ? 16 : 8, RPI = 64 / CL, NIT = 16 / RPI, LDE = WCOLS > 64 ? 128 : 64;
+  const int lr = lane / CL;
   // a 96-column wave block (256x192 tile) keeps the 128-column lane map: the last four column-lanes of every row group
   // redo column-lane 11's work on the same addresses (same values: harmless duplicate stores) instead of branching
-  const int c8 = WCOLS < 128 ? (((lane & 15) * 8 < WCOLS) ? (lane & 15) * 8 : WCOLS - 8) : (lane & 15) * 8;
+  const int c8 = (WCOLS < 128 && WCOLS > 64) ? (((lane & 15) * 8 < WCOLS) ? (lane & 15) * 8 : WCOLS - 8) : (lane % CL) * 8;
   const int gcol = col0w + c8;
   kmb_f32x2 bias2[4], csum2[4];
 #pragma unroll
@@ -1053,16 +1057,16 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
   const kmb_f32x2 scale2 = {p.col_scale, p.col_scale};
   const kmb_f32x2 dscale2 = {p.drop_scale, p.drop_scale};
   // staging write (transposed accumulators: lane (r, g) holds C[16 i + r][16 j + 4 g .. +3]) and read addresses
-  float* const wbase = ef + r * 128;
+  float* const wbase = ef + r * LDE;
   const int sw = (r & 7) << 3;
   auto stage = [&](const f32x4 (&a)[NJ]) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
     asm volatile("" ::: "memory");
   };
-  const float* rd[4];
+  const float* rd[NIT];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) rd[it] = ef + (lr + 4 * it) * 128 + (c8 ^ (((lr + 4 * it) & 7) << 3));
+  for (int it = 0; it < NIT; ++it) rd[it] = ef + (lr + RPI * it) * LDE + (c8 ^ (((lr + RPI * it) & 7) << 3));
   // row pointers of this lane's first row; a row-iteration is 4 rows further, a chunk 16
   bf16_t* out = F32 ? nullptr : p.out_bf16 + (size_t)(row0w + lr) * p.ld_out_bf16 + gcol;
   float* out32 = F32 ? p.out_f32 + (size_t)(row0w + lr) * p.ld_out_f32 + gcol : nullptr;   // fp32 logits (ld % 4 == 0)
@@ -1074,12 +1078,12 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
   constexpr bool SIDE = RES || ACT == 2;
   static_assert(!(RES && ACT == 2), "one side stream");
   // side loads run two chunks ahead of their use (a chunk is ~0.3 us, an HBM miss longer)
-  u32x4 s0[4], s1[4], s2[4];
+  u32x4 s0[NIT], s1[NIT], s2[NIT];
   if (SIDE) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      s0[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(4 * it) * ld_side);
-      s1[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 + 4 * it) * ld_side);
+    for (int it = 0; it < NIT; ++it) {
+      s0[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(RPI * it) * ld_side);
+      s1[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 + RPI * it) * ld_side);
     }
   }
   auto stage_chunk = [&](int i) {
@@ -1099,9 +1103,9 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
   for (int i = 0; i < WROWS / 16; ++i) {
     // this chunk's rows out of LDS first, then the next chunk's accumulators into the same image: the LDS executes
     // a wave's accesses in order, so the writes queue behind the reads and their latency hides under this chunk's math
-    f32x4 lo4[4], hi4[4];
+    f32x4 lo4[NIT], hi4[NIT];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       lo4[it] = *reinterpret_cast<const f32x4*>(rd[it]);
       hi4[it] = *reinterpret_cast<const f32x4*>(rd[it] + 4);
     }
@@ -1110,10 +1114,10 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
     if (SIDE) {
       const int ahead = i + 2 < WROWS / 16 ? i + 2 : WROWS / 16 - 1;   // the last two chunks re-read rows that are in cache (never used)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) s2[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 * ahead + 4 * it) * ld_side);
+      for (int it = 0; it < NIT; ++it) s2[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 * ahead + RPI * it) * ld_side);
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const f32x4 lo = lo4[it];
       const f32x4 hi = hi4[it];
       kmb_f32x2 v[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
@@ -1122,7 +1126,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
         if (BIAS) v[e] = v[e] + bias2[e];
         if (SCALE) v[e] = v[e] * scale2;
       }
-      const size_t roff = (size_t)(16 * i + 4 * it);
+      const size_t roff = (size_t)(16 * i + RPI * it);
       if (ACT == 1) {
         if (pre != nullptr) {   // GeLU and GeLU' from one evaluation; the derivative is stored for backward (ACT 2)
           kmb_f32x2 dv[4];
@@ -1145,7 +1149,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
         for (int e = 0; e < 4; ++e) v[e] = v[e] * kmb_f32x2{u[2 * e], u[2 * e + 1]};
       }
       if (DROP) {
-        const uint32_t grow = (uint32_t)(row0w + lr + 16 * i + 4 * it);
+        const uint32_t grow = (uint32_t)(row0w + lr + 16 * i + RPI * it);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const kmb_f32x2 kept = v[e] * dscale2;
@@ -1179,7 +1183,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
     }
     if (SIDE) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) { s0[it] = s1[it]; s1[it] = s2[it]; }
+      for (int it = 0; it < NIT; ++it) { s0[it] = s1[it]; s1[it] = s2[it]; }
     }
   }
   if (CS) {
@@ -1187,11 +1191,12 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { csum[2 * e] = csum2[e][0]; csum[2 * e + 1] = csum2[e][1]; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 8; ++e) {   // fold the row-lanes
+      if (CL == 8) csum[e] += __shfl_xor(csum[e], 8);
       csum[e] += __shfl_xor(csum[e], 16);
       csum[e] += __shfl_xor(csum[e], 32);
     }
-    if (lane < 16) {
+    if (lane < CL) {
       const int prow = row0w >> 6;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1204,8 +1209,15 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 
 // BNT = 256: waves 2x2, each 128x128.  BNT = 128 (variant 12): waves 4x1, each 64x128 -- twice as many tiles, for shapes
 // whose 256x256 tile count is not a multiple of the 256 workgroups (N = 768: 1.5 tiles per workgroup -> 3).
-template <bool A_KC, bool B_KC, int BNT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
+// NW = 8 (variant 14, BNT = 256 only): the same persistent structure with EIGHT waves, 2 x 4 of 128 x 64 (128 accumulator
+// registers each, two waves per SIMD).  One wave alone issues a vector instruction every 4 cycles, two waves sharing a
+// SIMD one every 2 (MI355X_MICROARCH.md, cycle constants): with one wave per SIMD a tile's epilogue is pure single-wave
+// VALU / store issue time with the matrix pipe idle -- the GeLU + GeLU' epilogue of a K = 768 tile costs 15.3 us against
+// an 18.8 us K loop -- and the second wave halves exactly that part.  The K loop is v8's (same fragments, same
+// accumulation order: bit-identical), MFMA-paced either way.
+template <bool A_KC, bool B_KC, int BNT, int NW = 4>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
+  static_assert(NW == 4 || (NW == 8 && BNT == 256), "eight waves: 256 x 256 tiles only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KMB_STAMP(0);
   KMB_STAMP_ID();
@@ -1214,13 +1226,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // BNT = 256: waves 2x2 of 128x128;  128: waves 4x1 of 64x128;  192: waves 2x2 of 128x96 (N = 768 = 4 x 192: 256 / 512
   // tiles at M = 16384 / 32768, one / two per CU, where 256-wide tiles leave a quarter / half round idle)
-  constexpr int WN = BNT == 128 ? 1 : 2, WM = 4 / WN, WROWS = BM4 / WM, MH = WROWS / 64;   // 2,2,128,2  or  1,4,64,1
+  constexpr int WN = NW == 8 ? 4 : BNT == 128 ? 1 : 2, WM = NW / WN, WROWS = BM4 / WM, MH = WROWS / 64;   // 2,2,128,2  or  1,4,64,1  or (NW 8) 4,2,128,2
   constexpr int WCOLS = BNT / WN, NJ = WCOLS / 16;     // columns / MFMA tile columns of a wave block: 128 / 8 or 96 / 6
   // B image: a non-KC 192-column tile keeps the 256-column row stride (the XOR swizzle of the transposing reads
   // permutes 32-byte chunks within groups of eight: 12 chunks do not close under it); its pieces cover the full stride
   // and the lanes past column 191 fetch bytes nobody reads
   constexpr int BIMG = (BNT == 192 && !B_KC) ? 256 : BNT;
-  constexpr int NPB = BIMG / 32;                       // 1 KiB LDS-DMA pieces of B per wave and stage
+  constexpr int NPA = 32 / NW;                         // 1 KiB LDS-DMA pieces of A per wave and stage
+  constexpr int NPB = BIMG / 32 * 4 / NW;              // ... of B
   constexpr int STG = (BM4 + BIMG) * BK * 2;           // one pipeline stage
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, g = lane >> 4;
@@ -1276,7 +1289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   // ---- DMA cursor: (tile, K step) of the next stage to fetch; runs two steps ahead of the MFMAs ----
-  uint32_t offA[8], offB[NPB];
+  uint32_t offA[NPA], offB[NPB];
   const char *gA_d, *gB_d;
   int tile_d = first_tile, td = 0;
   // ---- L2 prefetch of the activation operand (K-contiguous A only) ----
@@ -1323,7 +1336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         pfn_base = uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmx * BM4 * p.lda * 2);
       }
     }
-    dma_offsets256w4<A_KC>(offA, p.lda, row0, p.M, wave, lane);
+    dma_offsets256w4<A_KC, NPA>(offA, p.lda, row0, p.M, wave, lane);
     if constexpr (BNT == 128) dma_offsets<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
     else dma_offsets256w4<B_KC, NPB>(offB, p.ldb, col0, p.N, wave, lane);
     gA_d = uniform_ptr(reinterpret_cast<const char*>(p.A) + (A_KC ? (size_t)row0 * p.lda * 2 : (size_t)row0 * 2));
@@ -1338,7 +1351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       set_dma_tile(tile_d);
     }
   };
-  char* const dstA = smem + wave * 8192;
+  char* const dstA = smem + wave * (NPA * 1024);
   char* const dstB = smem + A_BYTES + wave * (NPB * 1024);
   // A stage's fetch is issued in two halves, one sub-phase apart (an LDS-DMA piece costs the issuing wave 60-180
   // cycles; sixteen of them in one 32-MFMA sub-phase made that sub-phase as long as the other three together)
@@ -1347,17 +1360,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef KMB_V11_SPLIT
 #define KMB_V11_SPLIT 1
 #endif
-  constexpr int NA3 = KMB_V11_SPLIT == 3 ? 4 : 8;
+  constexpr int NA3 = KMB_V11_SPLIT == 3 ? NPA / 2 : NPA;
   constexpr int NB3 = KMB_V11_SPLIT == 0 ? NPB : 0;
   constexpr int NB0 = KMB_V11_SPLIT == 0 ? 0 : KMB_V11_SPLIT == 2 ? NPB / 2 : NPB;
   constexpr int NB1 = NPB - NB3 - NB0;
-  constexpr int P3 = (NA3 + NB3) / 2, P0 = (8 - NA3 + NB0) / 2, P1 = NB1 / 2;   // pairs of pieces per sub-phase
+  constexpr int P3 = (NA3 + NB3) / 2, P0 = (NPA - NA3 + NB0) / 2, P1 = NB1 / 2;   // pairs of pieces per sub-phase
   auto dma_a = [&](int buf, int lo, int hi) {
     char* da = dstA + buf * STG;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NPA; ++i)
       if (i >= lo && i < hi) dma_piece(gA_d, offA[i], da + i * 1024);
-    if (hi == 8 && lo < hi) gA_d = uniform_ptr(gA_d + stepA);
+    if (hi == NPA && lo < hi) gA_d = uniform_ptr(gA_d + stepA);
   };
   auto dma_b = [&](int buf, int lo, int hi) {
     char* db = dstB + buf * STG;
@@ -1369,7 +1382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       ++td;
     }
   };
-  auto dma_stage_a = [&](int buf) { dma_a(buf, 0, 8); };
+  auto dma_stage_a = [&](int buf) { dma_a(buf, 0, NPA); };
   auto dma_stage_b = [&](int buf, int) { dma_b(buf, 0, NPB); };
 
   constexpr int NDA = A_KC ? 4 : 8;          // ds_read instructions per 4 A fragments
@@ -1439,7 +1452,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   read_a(smem, 0, 0, fa[0]);
   KMB_STAMP(1);
 
-  float* const ef = reinterpret_cast<float*>(smem + 2 * STG + wave * EPW_BYTES);
+  float* const ef = reinterpret_cast<float*>(smem + 2 * STG + wave * (WCOLS > 64 ? EPW_BYTES : EPW_BYTES / 2));
   int it = 0;   // linear K-step counter: stage buffer = it & 1
   for (int tile = first_tile; tile < range1; tile = tile_next) {
     if (dyn && tid == 0) fetched = atomicAdd(my_ctr, 1u);   // lands by the first K step's vmcnt(0)
@@ -1467,7 +1480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (MH == 2) {
       // ---- sub-phase 0: A(k0, rows 0-63) x B(k0)  ||  read A(k0, rows 64-127) ----
       read_a(cur, 0, 1, fa[1]);
-      dma_a((it + 1) & 1, NA3, 8);            // the rest of the stage whose first pieces went out in the previous
+      dma_a((it + 1) & 1, NA3, NPA);          // the rest of the stage whose first pieces went out in the previous
       dma_b((it + 1) & 1, NB3, NB3 + NB0);    // sub-phase 3
       mma(0, fa[0], fb[0]);
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 0);
@@ -1487,6 +1500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       read_a(cur, 1, 0, fa[0]);
       dma_b((it + 1) & 1, NB3 + NB0, NPB);
       mma(1, fa[1], fb[0]);
+      if constexpr (NM >= 24) {
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(6), 1);   // MFMAs first: their operands were read a sub-phase ago
       __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(5), 1);
@@ -1494,6 +1508,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(5), 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      } else {   // 16 MFMAs (64-column wave blocks)
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      }
 #pragma unroll
       for (int q = 0; q < P1; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA)
@@ -1869,7 +1892,7 @@ uint32_t* v11_sched_slot(hipStream_t stream) {
 }
 
 // variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256;
-// 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192
+// 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192 (four waves); 14: persistent 256x256, eight waves
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   if (variant == 11) {
@@ -1890,6 +1913,12 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 192>), grid, block, LDS11, stream, p, sched, g_shared_device);
+  } else if (variant == 14) {
+    dim3 grid(v11_grid(p, BN4)), block(512);
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot(stream) : nullptr;
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 256, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 256, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 256, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
   } else if (variant == 8) {
     const int tiles = ((p.M + BM4 - 1) / BM4) * ((p.N + BN4 - 1) / BN4);
     dim3 grid(tiles * nsl), block(512);
@@ -1995,6 +2024,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
   }
   const bool dma_ok = (p.K % BK) == 0;           // LDS-DMA variants have no K-edge zero fill
   const bool big = dma_ok && p.M > 128;
@@ -2020,8 +2052,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (v == 11 && !v11_ok(p)) v = 8;
     if (v == 12 && !v11_ok(p, 128)) v = 8;
     if (v == 13 && !v11_ok(p, 192)) v = 8;
+    if (v == 14 && !v11_ok(p)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
-    if (v != 1 && v != 7 && v != 8 && v != 11 && v != 12 && v != 13) v = 7;
+    if (v != 1 && v != 7 && v != 8 && v != 11 && v != 12 && v != 13 && v != 14) v = 7;
     KmbGemm q = p;
     q.tile_order = p.tile_order | (prefetch_a(p) ? 2 : 0);
     return launch_variant(v, q, stream);
@@ -2031,7 +2064,8 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
-    const int cands[12] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
+    const int cands[14] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
+                           14, 14 + 16,
                            7 + 16 * 5, 8 + 16 * 5};                                       // split-K only: slice-major
     float best_ms = 1e30f;
     int best = 7;
@@ -2041,6 +2075,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       if ((c & 15) == 11 && !v11_ok(p)) continue;
       if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
+      if ((c & 15) == 14 && !v11_ok(p)) continue;
       if (((c >> 4) & 4) && p.split_k <= 1) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_persistent_variants_match_the_128x128_variant_bitwise():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_v11_check.py")], capture_output=True, text=True,
-                       timeout=900)
+                       timeout=1800)
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "MISMATCH" not in r.stdout and r.stdout.count("same bits") >= 105
+    assert "MISMATCH" not in r.stdout and r.stdout.count("same bits") >= 105 + 4 * 30

@@ -1,4 +1,4 @@
-"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128, 13: 256x192) against the 128x128 variant 7 on every epilogue class and operand layout:
+"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128, 13: 256x192, 14: 256x256 with eight waves) against the 128x128 variant 7 on every epilogue class and operand layout:
 outputs must be bit-identical (same per-element accumulation order), column sums equal after folding their partial
 rows.  Also prints the time of each variant per case.  Re-runs itself once per variant (the variant is a per-process
 environment choice).
@@ -44,6 +44,12 @@ CASES = [
     ("wgrad_split7", 3072, 768, 8192, False, False, dict(split=7)),
     ("wgrad_split14_edges", 700, 760, 4096, False, False, dict(split=14)),
     ("fwd_split3", 2048, 768, 3072, True, True, dict(split=3)),
+    # benchmark-batch shapes of the classes whose epilogue is long (timing of the eight-wave variant 14 against 11 / 13 / 8)
+    ("b1024_fc1_gelu", 32768, 3072, 768, True, True, dict(bias=True, act=1, preact=True)),
+    ("b1024_fc1_dgrad", 32768, 3072, 768, True, False, dict(act=2, aux=True, colsum=True)),
+    ("b1024_qkv_fwd", 32768, 2304, 768, True, True, dict(bias=True, qscale=True)),
+    ("b1024_fc2_fwd", 32768, 768, 3072, True, True, dict(bias=True, residual=True, drop=0.1)),
+    ("b1024_fc2_dgrad", 32768, 768, 3072, True, False, dict(residual=True)),
 ]
 
 
@@ -117,12 +123,16 @@ def run_variant():
     print("JSON" + json.dumps(out))
 
 
-VARIANTS = ("7", "8", "11", "12", "13", "11o1", "12o1", "13o1", "11s", "12o1s", "13s", "11o1p", "13p", "7o5", "8o5")
+VARIANTS = ("7", "8", "11", "12", "13", "14", "11o1", "12o1", "13o1", "14o1", "11s", "12o1s", "13s", "14s", "11o1p", "13p", "14o1p", "7o5",
+            "8o5")
 
 
 def main():
+    global VARIANTS
     if os.environ.get("KMB_V11_CHILD"):
         return run_variant()
+    if os.environ.get("KMB_V11_CHECK_VARIANTS"):   # a subset, e.g. "7,8,11,14,14o1" ("7" and "8" are the references: keep them)
+        VARIANTS = tuple(os.environ["KMB_V11_CHECK_VARIANTS"].split(","))
     res = {}
     # o1: tile_order bit 0 = per-XCD contiguous tile ranges; o5: that plus slice-major split-K enumeration (bit 2); s: shared-device mode (every tile from the atomic counter);
     # p: the activation-panel L2 prefetch on for every shape (the others: off, so both paths of the kernel are compared)
