@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #define KMB_V11_PFD 2
 #endif
   constexpr int KMB_PFD = KMB_V11_PFD;
-  constexpr bool PF_ON = KMB_V11_PREFETCH != 0 && A_KC;
+  constexpr bool PF_ON = KMB_V11_PREFETCH != 0 && A_KC && NW == 4;   // (eight waves: 128 registers beside the accumulators; the prefetch state spills into the K loop)
   const bool pf_rt = (p.tile_order & 2) != 0;   // set per launch (kmb_gemm_launch): only where A is expected to come from HBM
   // The first KMB_PFD steps of a tile have no earlier step of the same tile to be prefetched from: they are touched
   // from the tile `per` places earlier in the range -- the tile whose workgroup is one round ahead of the one that will
@@ -1390,13 +1390,70 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   constexpr int NM = 4 * NJ;                 // MFMAs of one sub-phase (4 A fragments x NJ B fragments)
   bf16x8 fa[2][4], fb[2][NJ];
   f32x4 acc[8][NJ];
+  // Eight waves: 128 registers hold everything beside the accumulators, and hipcc keeps one address register per
+  // distinct fragment address it can hoist out of the K loop (the XOR swizzles are not additive) -- two of them spilled, and
+  // a scratch reload inside the loop is a VMEM load whose wait (vmcnt) also drains the LDS-DMA pieces in flight.  So the
+  // fragment addresses are rebuilt per use from ONE lane constant per operand (same addresses as read_frag3, checked
+  // exhaustively on the host when this was written): with swz the lane's swizzle term,
+  //   K-contiguous image:   row * 128 + (((kk * 4 + g) ^ ((r >> 1) & 7)) << 4)        = (cA ^ (kk << 6)) + rowtile * 2048
+  //   token-major image:    krow * 512 + ((rowtile ^ swz) << 5) + ((r & 3) << 3)        = (cB ^ (j << 5)) + (kk * 32 + hh * 4) * 512
+  // and the constant is laundered through an empty asm in every call so that the XORs are not hoisted again.
+  constexpr bool REMAT = NW == 8;
+  const int rm_ka = r * 128 + ((g ^ ((r >> 1) & 7)) << 4);
+  const int rm_sw = ((r >> 2) & 3) | ((g & 1) << 2);
+  const int rm_l = (g * 8 + (r >> 2)) * (BIMG * 2) + ((r & 3) << 3);
+  const int rm_nb = (rm_l + (((wn * NJ) ^ (rm_sw & 4)) << 5)) ^ ((rm_sw & 3) << 5);
+  const int rm_na = (((g * 8 + (r >> 2)) * (BM4 * 2) + ((r & 3) << 3)) + (((wm * (MH * 4)) ^ (rm_sw & 4)) << 5)) ^ ((rm_sw & 3) << 5);
+  auto tr_read = [&](const char* ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+  };
   auto read_a = [&](const char* stage, int kk, int half, bf16x8 (&dst)[4]) {
+    if constexpr (REMAT && A_KC) {
+      int c = rm_ka;
+      asm volatile("" : "+v"(c));
+      const char* base = stage + (c ^ (kk << 6)) + (wm * (MH * 4) + half * 4) * 2048;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * (MH * 4) + half * 4 + i, kk, r, g);
+      for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(base + i * 2048);
+    } else if constexpr (REMAT) {   // token-major A: row tiles wm * 8 + half * 4 + i (half * 4 + i < 8: low three bits)
+      int c = rm_na;
+      asm volatile("" : "+v"(c));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* pj = stage + kk * (32 * BM4 * 2) + (c ^ ((half * 4 + i) << 5));
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const s16x4 t = tr_read(pj + hh * (4 * BM4 * 2));
+          dst[i][hh * 4 + 0] = t[0]; dst[i][hh * 4 + 1] = t[1]; dst[i][hh * 4 + 2] = t[2]; dst[i][hh * 4 + 3] = t[3];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * (MH * 4) + half * 4 + i, kk, r, g);
+    }
   };
   auto read_b = [&](const char* stage, int kk, bf16x8 (&dst)[NJ]) {
+    if constexpr (REMAT && B_KC) {
+      int c = rm_ka;
+      asm volatile("" : "+v"(c));
+      const char* base = stage + A_BYTES + (c ^ (kk << 6)) + (wn * NJ) * 2048;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) dst[j] = read_frag3<B_KC, BIMG>(stage + A_BYTES, wn * NJ + j, kk, r, g);
+      for (int j = 0; j < NJ; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(base + j * 2048);
+    } else if constexpr (REMAT) {
+      int c = rm_nb;
+      asm volatile("" : "+v"(c));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const char* pj = stage + A_BYTES + kk * (32 * BIMG * 2) + (c ^ (j << 5));
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const s16x4 t = tr_read(pj + hh * (4 * BIMG * 2));
+          dst[j][hh * 4 + 0] = t[0]; dst[j][hh * 4 + 1] = t[1]; dst[j][hh * 4 + 2] = t[2]; dst[j][hh * 4 + 3] = t[3];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) dst[j] = read_frag3<B_KC, BIMG>(stage + A_BYTES, wn * NJ + j, kk, r, g);
+    }
   };
 #ifdef KMB_V11_MFMA32_TIMING
   // TIMING EXPERIMENT ONLY (diagnostic builds): the same fragments fed to 32x32x16 MFMAs -- half as many instructions,
