@@ -1005,7 +1005,7 @@ __device__ __forceinline__ void v11_epilogue(const KmbGemm& p, f32x4 (&acc)[8][N
       case 6: stage(acc[6]); break;
       default: stage(acc[7]); break;
     }
-    gemm_epilogue_body<64, true, 4, LDE, true, 128, ACT, RES, CS, FAST, true, WCOLS>(p, ef, nullptr, lane, row0w + i * 16,
+    gemm_epilogue_body<64, (WCOLS > 64), 4, LDE, true, 128, ACT, RES, CS, FAST, true, WCOLS>(p, ef, nullptr, lane, row0w + i * 16,
                                                                                     col0w, csum);
   }
   if (CS && (ACT >= 0 || p.colsum != nullptr)) {
@@ -1046,7 +1046,9 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
   const int lr = lane / CL;
   // a 96-column wave block (256x192 tile) keeps the 128-column lane map: the last four column-lanes of every row group
   // redo column-lane 11's work on the same addresses (same values: harmless duplicate stores) instead of branching
-  const int c8 = (WCOLS < 128 && WCOLS > 64) ? (((lane & 15) * 8 < WCOLS) ? (lane & 15) * 8 : WCOLS - 8) : (lane % CL) * 8;
+  // a 96- / 48-column wave block keeps the 128- / 64-column lane map: the column-lanes past the block redo the last
+  // column-lane's work on the same addresses (same values: harmless duplicate stores) instead of branching
+  const int c8 = ((lane % CL) * 8 < WCOLS) ? (lane % CL) * 8 : WCOLS - 8;
   const int gcol = col0w + c8;
   kmb_f32x2 bias2[4], csum2[4];
 #pragma unroll
@@ -1217,7 +1219,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 // accumulation order: bit-identical), MFMA-paced either way.
 template <bool A_KC, bool B_KC, int BNT, int NW = 4>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
-  static_assert(NW == 4 || (NW == 8 && BNT == 256), "eight waves: 256 x 256 tiles only");
+  static_assert(NW == 4 || (NW == 8 && (BNT == 256 || BNT == 192)), "eight waves: 256 x 256 and 256 x 192 tiles only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KMB_STAMP(0);
   KMB_STAMP_ID();
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #define KMB_V11_PFD 2
 #endif
   constexpr int KMB_PFD = KMB_V11_PFD;
-  constexpr bool PF_ON = KMB_V11_PREFETCH != 0 && A_KC && NW == 4;   // (eight waves: 128 registers beside the accumulators; the prefetch state spills into the K loop)
+  constexpr bool PF_ON = KMB_V11_PREFETCH != 0 && A_KC;
   const bool pf_rt = (p.tile_order & 2) != 0;   // set per launch (kmb_gemm_launch): only where A is expected to come from HBM
   // The first KMB_PFD steps of a tile have no earlier step of the same tile to be prefetched from: they are touched
   // from the tile `per` places earlier in the range -- the tile whose workgroup is one round ahead of the one that will
@@ -1396,14 +1398,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   // fragment addresses are rebuilt per use from ONE lane constant per operand (same addresses as read_frag3, checked
   // exhaustively on the host when this was written): with swz the lane's swizzle term,
   //   K-contiguous image:   row * 128 + (((kk * 4 + g) ^ ((r >> 1) & 7)) << 4)        = (cA ^ (kk << 6)) + rowtile * 2048
-  //   token-major image:    krow * 512 + ((rowtile ^ swz) << 5) + ((r & 3) << 3)        = (cB ^ (j << 5)) + (kk * 32 + hh * 4) * 512
+  //   token-major image:    krow * 512 + ((rowtile ^ swz) << 5) + ((r & 3) << 3)        = (cB ^ (rowtile << 5)) + (kk * 32 + hh * 4) * 512
   // and the constant is laundered through an empty asm in every call so that the XORs are not hoisted again.
   constexpr bool REMAT = NW == 8;
   const int rm_ka = r * 128 + ((g ^ ((r >> 1) & 7)) << 4);
   const int rm_sw = ((r >> 2) & 3) | ((g & 1) << 2);
   const int rm_l = (g * 8 + (r >> 2)) * (BIMG * 2) + ((r & 3) << 3);
-  const int rm_nb = (rm_l + (((wn * NJ) ^ (rm_sw & 4)) << 5)) ^ ((rm_sw & 3) << 5);
-  const int rm_na = (((g * 8 + (r >> 2)) * (BM4 * 2) + ((r & 3) << 3)) + (((wm * (MH * 4)) ^ (rm_sw & 4)) << 5)) ^ ((rm_sw & 3) << 5);
+  const int rm_nb = rm_l | (rm_sw << 5);                                                   // bits 5-8 of rm_l are zero
+  const int rm_na = ((g * 8 + (r >> 2)) * (BM4 * 2) + ((r & 3) << 3)) | (rm_sw << 5);
   auto tr_read = [&](const char* ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
   };
@@ -1414,12 +1416,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       const char* base = stage + (c ^ (kk << 6)) + (wm * (MH * 4) + half * 4) * 2048;
 #pragma unroll
       for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(base + i * 2048);
-    } else if constexpr (REMAT) {   // token-major A: row tiles wm * 8 + half * 4 + i (half * 4 + i < 8: low three bits)
+    } else if constexpr (REMAT) {   // token-major A: row tiles wm * 8 + half * 4 + i
       int c = rm_na;
       asm volatile("" : "+v"(c));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const char* pj = stage + kk * (32 * BM4 * 2) + (c ^ ((half * 4 + i) << 5));
+        const char* pj = stage + kk * (32 * BM4 * 2) + (c ^ ((wm * (MH * 4) + half * 4 + i) << 5));
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const s16x4 t = tr_read(pj + hh * (4 * BM4 * 2));
@@ -1443,7 +1445,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       asm volatile("" : "+v"(c));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const char* pj = stage + A_BYTES + kk * (32 * BIMG * 2) + (c ^ (j << 5));
+        const char* pj = stage + A_BYTES + kk * (32 * BIMG * 2) + (c ^ ((wn * NJ + j) << 5));
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const s16x4 t = tr_read(pj + hh * (4 * BIMG * 2));
@@ -1565,14 +1567,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(5), 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
-      } else {   // 16 MFMAs (64-column wave blocks)
-      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      } else {   // 16 / 12 MFMAs (64- / 48-column wave blocks of the eight-wave kernels)
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(NM / 4), 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, (NDB + 1) / 2, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(NM / 4), 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, NDB / 2, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(NM / 4), 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NDA, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(4), 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(NM / 4), 1);
       }
 #pragma unroll
       for (int q = 0; q < P1; ++q) {
@@ -1949,7 +1951,7 @@ uint32_t* v11_sched_slot(hipStream_t stream) {
 }
 
 // variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256;
-// 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192 (four waves); 14: persistent 256x256, eight waves
+// 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192 (four waves); 14 / 15: persistent 256x256 / 256x192, eight waves
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
   if (variant == 11) {
@@ -1976,6 +1978,12 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
     if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 256, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 256, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
     else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 256, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
+  } else if (variant == 15) {
+    dim3 grid(v11_grid(p, 192)), block(512);
+    uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot(stream) : nullptr;
+    if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, true, 192, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v11<true, false, 192, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
+    else hipLaunchKernelGGL((gemm_kernel_v11<false, false, 192, 8>), grid, block, LDS11, stream, p, sched, g_shared_device);
   } else if (variant == 8) {
     const int tiles = ((p.M + BM4 - 1) / BM4) * ((p.N + BN4 - 1) / BN4);
     dim3 grid(tiles * nsl), block(512);
@@ -2084,6 +2092,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, true, 192, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<true, false, 192, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v11<false, false, 192, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS11);
   }
   const bool dma_ok = (p.K % BK) == 0;           // LDS-DMA variants have no K-edge zero fill
   const bool big = dma_ok && p.M > 128;
@@ -2110,8 +2121,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (v == 12 && !v11_ok(p, 128)) v = 8;
     if (v == 13 && !v11_ok(p, 192)) v = 8;
     if (v == 14 && !v11_ok(p)) v = 8;
+    if (v == 15 && !v11_ok(p, 192)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
-    if (v != 1 && v != 7 && v != 8 && v != 11 && v != 12 && v != 13 && v != 14) v = 7;
+    if (v != 1 && v != 7 && v != 8 && (v < 11 || v > 15)) v = 7;
     KmbGemm q = p;
     q.tile_order = p.tile_order | (prefetch_a(p) ? 2 : 0);
     return launch_variant(v, q, stream);
@@ -2121,8 +2133,8 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
-    const int cands[14] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
-                           14, 14 + 16,
+    const int cands[16] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
+                           14, 14 + 16, 15, 15 + 16,
                            7 + 16 * 5, 8 + 16 * 5};                                       // split-K only: slice-major
     float best_ms = 1e30f;
     int best = 7;
@@ -2133,6 +2145,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
       if ((c & 15) == 14 && !v11_ok(p)) continue;
+      if ((c & 15) == 15 && !v11_ok(p, 192)) continue;
       if (((c >> 4) & 4) && p.split_k <= 1) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;

@@ -1,4 +1,4 @@
-"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128, 13: 256x192, 14: 256x256 with eight waves) against the 128x128 variant 7 on every epilogue class and operand layout:
+"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128, 13: 256x192, 14 / 15: 256x256 / 256x192 with eight waves) against the 128x128 variant 7 on every epilogue class and operand layout:
 outputs must be bit-identical (same per-element accumulation order), column sums equal after folding their partial
 rows.  Also prints the time of each variant per case.  Re-runs itself once per variant (the variant is a per-process
 environment choice).
@@ -123,8 +123,8 @@ def run_variant():
     print("JSON" + json.dumps(out))
 
 
-VARIANTS = ("7", "8", "11", "12", "13", "14", "11o1", "12o1", "13o1", "14o1", "11s", "12o1s", "13s", "14s", "11o1p", "13p", "14o1p", "7o5",
-            "8o5")
+VARIANTS = ("7", "8", "11", "12", "13", "14", "15", "11o1", "12o1", "13o1", "14o1", "15o1", "11s", "12o1s", "13s", "14s", "15o1s", "11o1p",
+            "13p", "14o1p", "15p", "7o5", "8o5")
 
 
 def main():
