@@ -1240,7 +1240,30 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BNT - 1) / BNT;
-  const int ntiles = ((p.M + BM4 - 1) / BM4) * tiles_n;
+  const int tiles_m = (p.M + BM4 - 1) / BM4;
+  const int ntiles = tiles_m * tiles_n;
+  // Tile enumeration.  Row-major (index = tm * tiles_n + tn) by default.  tile_order bit 3: COLUMN-BLOCK-major for wide
+  // outputs (the tied LM head: 197 column tiles of a 77 MB matrix) -- blocks of CB column tiles, all row panels of a
+  // block before the next block, so that the 32 workgroups of an XCD (contiguous index range) work on 4 row panels x 8
+  // column tiles whose 8 weight panels (3 MB) stay in that XCD's L2 while the row panels stream past once per block;
+  // row-major, every row panel pulled the whole weight matrix through the L2 again (rocprofv3 FETCH_SIZE of the LM
+  // head: 10.5 GB for 128 MB of operands).  The XCDs' contiguous ranges then partition the COLUMNS of the weight.
+  constexpr int CB = 8;
+  const bool col_blocks = (p.tile_order & 8) != 0 && tiles_n > CB;
+  const int cb_full = tiles_n / CB;                          // full blocks; a last block holds the remaining columns
+  auto decode_tile = [&](int t, int& tm, int& tn) {
+    if (!col_blocks) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
+    const int blk = t / (CB * tiles_m);
+    if (blk < cb_full) {
+      const int rem = t - blk * (CB * tiles_m);
+      tm = rem / CB; tn = blk * CB + (rem - tm * CB);
+    } else {
+      const int wl = tiles_n - cb_full * CB;               // > 0 here
+      const int rem = t - cb_full * (CB * tiles_m);
+      tm = rem / wl; tn = cb_full * CB + (rem - tm * wl);
+    }
+  };
+  const int pf_sharers = col_blocks ? CB : tiles_n;         // workgroups that walk a row panel together (L2 prefetch shares)
   // this workgroup's tiles: XCD x owns a contiguous range, its workgroups take every (grid/8)-th tile of it
   // (tile_order bit 0; without it workgroup b simply takes tiles b, b + grid, ...: better when C dominates the traffic)
   const bool xcd_ranges = (p.tile_order & 1) != 0;
@@ -1318,7 +1341,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   const char* pfn_base = reinterpret_cast<const char*>(p.A);
   bool pf_pending = false, pfn_ok = false;
   auto pf_row_offset = [&](int tn, int row0) {
-    int share = (BM4 + tiles_n - 1) / tiles_n;
+    int share = (BM4 + pf_sharers - 1) / pf_sharers;
     share = share > 64 ? 64 : share;
     int prow = tn * share + (lane < share ? lane : 0);
     prow = prow < BM4 ? prow : BM4 - 1;
@@ -1326,15 +1349,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     return (uint32_t)prow * (uint32_t)p.lda * 2u;
   };
   auto set_dma_tile = [&](int tile) {
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    decode_tile(tile, tm, tn);
     const int row0 = tm * BM4, col0 = tn * BNT;
     if (PF_ON) {
-      pf_off = pf_row_offset(tn, row0);
+      pf_off = pf_row_offset(col_blocks ? tn % CB : tn, row0);
       const int tx = tile + per;
       pfn_ok = tx < range1;
       if (pfn_ok) {
-        const int tmx = tx / tiles_n, tnx = tx - tmx * tiles_n;
-        pfn_off = pf_row_offset(tnx, tmx * BM4);
+        int tmx, tnx;
+        decode_tile(tx, tmx, tnx);
+        pfn_off = pf_row_offset(col_blocks ? tnx % CB : tnx, tmx * BM4);
         pfn_base = uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmx * BM4 * p.lda * 2);
       }
     }
@@ -1675,7 +1700,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #endif
     // ---- epilogue of this tile (the next tile's first two stages are in flight / resident meanwhile) ----
     [[maybe_unused]] const uint64_t kmb_t_epi = KMB_NOW();
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    decode_tile(tile, tm, tn);
     const int row0w = tm * BM4 + wm * WROWS, col0w = tn * BNT + wn * WCOLS;
     if (row0w < p.M && col0w < p.N) {
       const bool interior = (row0w + WROWS <= p.M) && (col0w + WCOLS <= p.N);
@@ -2021,18 +2047,19 @@ bool v11_ok(const KmbGemm& p, int bn = BN4) {
 }
 
 // L2 prefetch of the activation operand by the persistent kernels (tile_order bit 1).  The tuning above times
-// back-to-back launches, whose operands sit in the Infinity Cache, so it cannot see what the prefetch is for; the rule
-// comes from per-shape timing inside a step (tools/gemm_shape_table.py, profiles/r02_gemm_prefetch_ab.txt): it pays
-// where A is wide (K >= 2048: the FFN's hidden activations and their gradients, the region features) and too large to
-// still be cached from its producer (forward: it was written together with the GeLU' copy; backward: >= 160 MB), and
-// costs 1-10 % where A is narrow or small (K = 768, or the operand the previous kernel just wrote).
+// back-to-back launches, whose operands sit in the Infinity Cache, so it cannot see what the prefetch is for.
+// Round 2 enabled it by a per-shape rule (K >= 2048 forward launches, >= 160 MB backward operands) taken from in-step
+// timing at a time when the tuner often chose the round-robin tile order, under which the sharers of a row panel sit on
+// eight different XCDs and the touch helps nobody.  With per-XCD tile ranges on every persistent launch (round 3) the
+// sharers of a panel are on one XCD, and the prefetch pays on every shape: in-step GEMM time of a b = 1024 step, same box,
+// alternating processes (tools/gemm_ab_seq.sh): always 39.5 / 39.6 / 41.2 ms, rule 43.3 / 42.7 / 43.7, never 43.5 / 43.4.
 bool prefetch_a(const KmbGemm& p) {
-  static int mode = -1;   // KMB_GEMM_PREFETCH = 0 (never) | 1 (always) | unset (the rule)
+  static int mode = -1;   // KMB_GEMM_PREFETCH = 0 (never) | 1 (always) | 2 (round 2's rule) | unset (always)
   if (mode < 0) {
     const char* e = getenv("KMB_GEMM_PREFETCH");
-    mode = e ? (e[0] == '0' ? 0 : 1) : 2;
+    mode = e ? atoi(e) : 1;
   }
-  if (mode != 2) return mode == 1;
+  if (mode != 2) return mode == 1 && p.a_kc;
   if (!p.a_kc || p.K < 2048) return false;
   return p.b_kc || (double)p.M * p.K * 2.0 >= 160e6;
 }
@@ -2140,7 +2167,19 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     int best = 7;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_variant(7, p, stream);
+    static unsigned exclude = ~0u;   // KMB_GEMM_EXCLUDE=14,15: variants the tuner may not pick (same-box A/B measurements)
+    if (exclude == ~0u) {
+      exclude = 0u;
+      if (const char* ex = getenv("KMB_GEMM_EXCLUDE"))
+        for (const char* q = ex; *q;) {
+          const int v = atoi(q);
+          if (v > 0 && v < 32) exclude |= 1u << v;
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+    }
     for (int c : cands) {
+      if (exclude & (1u << (c & 15))) continue;
       if ((c & 15) == 11 && !v11_ok(p)) continue;
       if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
@@ -2177,6 +2216,19 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   }
   KmbGemm q = p;
   q.tile_order = (it->second >> 4) | (prefetch_a(p) ? 2 : 0);
+  if ((it->second & 15) >= 11) {
+    // Persistent variants: per-XCD contiguous tile ranges ALWAYS (bit 0), column blocks for wide outputs (bit 3).  The
+    // tuner's back-to-back timing cannot see the difference (operands sit in the Infinity Cache there); inside a step
+    // the round-robin order pulls every activation row panel into all eight L2s -- rocprofv3 FETCH_SIZE per launch,
+    // tools/r3_traffic.sh: fc1 forward 822 MB for 105 MB of operands, the N = 768 data gradients 1458 for 407 -- and
+    // measures 0.5-2 % slower (tools/gemm_ab_env.sh).  KMB_GEMM_FORCE_ORDER = 0 | 1 overrides bit 0, KMB_GEMM_COLBLOCKS=0
+    // switches the column blocks off (A/B measurements).
+    static int fo = -2, cbk = -1;
+    if (fo == -2) { const char* e = getenv("KMB_GEMM_FORCE_ORDER"); fo = e ? atoi(e) : -1; }
+    if (cbk < 0) { const char* e = getenv("KMB_GEMM_COLBLOCKS"); cbk = e ? atoi(e) : 1; }
+    q.tile_order = (q.tile_order & ~1) | (fo >= 0 ? (fo & 1) : 1);
+    if (cbk && p.a_kc && p.b_kc && p.N >= 32 * 256) q.tile_order |= 8;
+  }
   if (p.split_k > 1) {
     static int so = -2;   // KMB_GEMM_SPLIT_ORDER = 0 | 1: force the slice-minor / slice-major enumeration (A/B measurements)
     if (so == -2) { const char* e = getenv("KMB_GEMM_SPLIT_ORDER"); so = e ? atoi(e) : -1; }
