@@ -1,7 +1,9 @@
-"""The persistent GEMM variants (11: 256x256 tiles, 12: 256x128; one workgroup per CU walking its tiles as one linear
-K-step sequence) must reproduce the 128x128 variant bit for bit on every epilogue class, operand layout and edge shape.
-The variant is a per-process choice (KMB_GEMM_VARIANT), so the comparison runs tools/gemm_v11_check.py, which re-runs
-itself once per variant and diffs checksums of the outputs (column sums: after folding their partial rows)."""
+"""The column-block tile enumeration of the persistent GEMM variants (tile_order bit 3: blocks of eight column tiles, all
+row panels of a block before the next one -- what the LM head runs with) on every persistent variant, four- and
+eight-wave: results must not depend on the enumeration, so every case must reproduce the 128x128 variant bit for bit
+(tools/gemm_v11_check.py re-runs itself once per variant and diffs checksums; cases with 9 .. 197 column tiles exercise
+full blocks, the partial last block and the fall-back for narrow outputs).  The plain orders of every variant are covered by
+tests/test_gemm_variants_gpu.py."""
 import os
 import subprocess
 import sys
@@ -12,9 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_persistent_variants_match_the_128x128_variant_bitwise():
+def test_column_block_order_is_bitwise_neutral():
+    env = dict(os.environ, KMB_V11_CHECK_VARIANTS="7,8,11o9,12o9,13o9,14o9,15o9")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_v11_check.py")], capture_output=True, text=True,
-                       timeout=1800)
+                       timeout=1800, env=env)
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "MISMATCH" not in r.stdout and r.stdout.count("same bits") >= 105 + 4 * 30
+    assert "MISMATCH" not in r.stdout and r.stdout.count("same bits") >= 6 * 30
