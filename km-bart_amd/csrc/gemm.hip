@@ -1324,7 +1324,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   // Each of them therefore touches ITS share of the panel's rows (256 / tiles_n rows = one 128-byte line each per K
   // step, ONE load instruction of wave 0) KMB_PFD steps ahead of the DMA cursor: the lines are in the XCD's L2 when the
   // DMAs of all sharers ask for them.  The load's result is never used; it stays outstanding across the stage wait
-  // (vmcnt(1) instead of 0 for wave 0) and must only be complete one step later.
+  // (vmcnt(1) instead of 0 for wave 0) and must only be complete one step later (see the K loop for why its destination
+  // is one register web for the whole kernel).
 #ifndef KMB_V11_PREFETCH
 #define KMB_V11_PREFETCH 1
 #endif
@@ -1514,7 +1515,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     for (int i = 2; i < 2 + KMB_PFD; ++i) {
       if (i < nt) {
         const char* pbase = uniform_ptr(gA_d + (size_t)i * stepA);
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_sink) : "v"(pf_off), "s"(pbase) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_off), "s"(pbase) : "memory");
       }
     }
   }
@@ -1609,13 +1610,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       __builtin_amdgcn_sched_barrier(0);
       advance_cursor();
       if (PF_ON) {
+        // The L2 touch is the YOUNGEST memory operation at this step's stage wait (all pieces of the stage are out), so
+        // that wait is vmcnt(1) for wave 0 and the touch -- an HBM miss by design -- has until the NEXT step's wait to
+        // land.  (Issued as the oldest operation of the window behind a plain vmcnt(0) it sat in front of the stage's
+        // pieces in the in-order return queue and the whole gain was gone: 42.2 vs 39.5 ms of in-step GEMM time.)
+        // Its destination is ONE register web for the whole kernel ("+v": every touch reads and writes pf_sink, the last
+        // use is at the end of the kernel), so the allocator cannot hand the register to another value while a load is
+        // still going to write it.  Round 2's form ("=v": a fresh value per touch, dead at once) allowed exactly that:
+        // invisible with 256 free registers, wrong bits in the eight-wave kernel (tools/gemm_v11_check.py, 14o1p).
+        // No touch in a tile's last K step: that step's wait is vmcnt(0), nothing is in flight across the epilogue,
+        // where the register may be spilled and reused.
         const int ps = td + KMB_PFD;   // td: the step the next fetch of this workgroup asks for
         const bool in_tile = ps < nt;
-        pf_pending = pf_rt && wave == 0 && (in_tile || (pfn_ok && ps - nt < nt));
+        pf_pending = pf_rt && wave == 0 && t + 1 < nt && (in_tile || (pfn_ok && ps - nt < nt));
         if (pf_pending) {
           const char* pbase = uniform_ptr(in_tile ? gA_d + (size_t)KMB_PFD * stepA : pfn_base + (size_t)(ps - nt) * stepA);
           const uint32_t poff = in_tile ? pf_off : pfn_off;
-          asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_sink) : "v"(poff), "s"(pbase) : "memory");
+          asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(poff), "s"(pbase) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1628,7 +1639,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       __builtin_amdgcn_sched_barrier(0);
       {
         KMB_WAIT_BEGIN();
-        if (PF_ON && pf_pending) __builtin_amdgcn_s_waitcnt(0x0071);  // vmcnt(1): this step's L2 prefetch stays in flight
+        if (PF_ON && pf_pending) __builtin_amdgcn_s_waitcnt(0x0071);  // vmcnt(1): this step's L2 touch stays in flight
         else __builtin_amdgcn_s_waitcnt(0x0070);                       // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         KMB_WAIT_END(kmb_wait_ticks);
