@@ -164,6 +164,55 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
     }
 
 
+def bench_batch_check(model, dev, bsz, chunk=64):
+    """Correctness gate at the measured size (the GEMM variants, split-K rules and tile orders a batch of `bsz` switches
+    on are not the ones a small batch runs): loss and EVERY gradient of one ragged batch of `bsz` samples (eval mode: no
+    dropout) against the token-weighted sum over its 64-sample chunks -- mean-token CE, reference src/model/model.py:400-402:
+    whole-batch gradient = sum_c (n_c / n) x chunk gradient -- each chunk going through the small-batch kernels.  The
+    same comparison with an oracle check of the chunks is tests/test_bench_batch_gpu.py; here it guards the numbers of
+    THIS run (a broken kernel is often a fast kernel)."""
+    from src.data.synthetic import make_batch
+    g = torch.Generator().manual_seed(bsz)
+    lab = torch.randint(1, T_DEC + 1, (bsz,), generator=g).tolist()
+    b = make_batch(bsz, enc_len=S_ENC, dec_len=T_DEC, num_regions=REGIONS, seed=555 + bsz, label_lens=lab)
+    eng = model._engine
+
+    def run(lo, hi, scale):
+        feats = [f.to(dev) for f in b["image_features"][lo:hi]]
+        loss, _, _ = eng.forward(b["input_ids"][lo:hi].to(dev), feats, b["attention_mask"][lo:hi].to(dev),
+                                 b["decoder_input_ids"][lo:hi].to(dev), b["decoder_attention_mask"][lo:hi].to(dev),
+                                 b["labels"][lo:hi].to(dev), train=False, need_grad=True, want_encoder=False)
+        eng.backward(scale)
+        torch.cuda.synchronize()
+        return float(loss)
+
+    loss_big = run(0, bsz, 1.0)
+    g_big = eng.grads.clone()
+    ntot = int((b["labels"] != -100).sum())
+    acc = torch.zeros_like(g_big)
+    loss_acc = 0.0
+    for c in range(0, bsz, chunk):
+        w = int((b["labels"][c: c + chunk] != -100).sum()) / ntot
+        loss_acc += w * run(c, min(c + chunk, bsz), w)
+        acc += eng.grads
+    worst, worst_name = 0.0, ""
+    for name, (off, rows, cols) in eng.index.items():
+        if "k_proj.bias" in name:   # zero true gradient (softmax is shift-invariant): rounding noise only
+            continue
+        a, r = g_big[off: off + rows * cols], acc[off: off + rows * cols]
+        e = float((a - r).norm() / (r.norm() + 1e-30))
+        if e > worst or e != e:
+            worst, worst_name = e, name
+    loss_rel = abs(loss_big - loss_acc) / abs(loss_acc)
+    ok = bool(loss_rel < 2e-4 and worst < 1e-2)
+    out = {"per_gpu_batch": bsz, "chunks": (bsz + chunk - 1) // chunk, "loss_rel_err": float("%.3e" % loss_rel),
+           "worst_gradient_rel_err": float("%.3e" % worst), "worst_gradient": worst_name, "ok": ok,
+           "bounds": {"loss": 2e-4, "gradient_norm_wise": 1e-2}}
+    if not ok:
+        raise RuntimeError("bench-batch check failed: %s" % json.dumps(out))
+    return out
+
+
 def timed_steps(step, n_warm, n_steps):
     for _ in range(n_warm):
         step()
@@ -473,7 +522,10 @@ def main():
         sweep[str(args.batch)] = {"tokens_per_sec": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 3)}
         out["batch_sweep"] = sweep
         out["legs"] = sweep   # the same objects: b = 64 / 256 / 512 / 1024 get their GEMM roofline below
-        # (3) BASELINE config 5: generation
+        # (3) the measured batch computes what its 64-sample chunks compute (raises otherwise)
+        out["bench_batch_check"] = bench_batch_check(model, dev, args.batch)
+        model.train()
+        # (4) BASELINE config 5: generation
         out["generation"] = generation_leg(dev)
 
     if rank == 0 and not args.no_roofline:

@@ -123,7 +123,10 @@ struct kmb_handle {
   // gradient buffers read by the weight-gradient GEMMs of the side stream: one per LayerNorm site
   // (0 = FFN, 1 = self-attention, 2 = cross-attention) and per layer parity, so that the main stream can run
   // up to one layer ahead of the side stream without overwriting what it still reads
-  struct BwdBufs { bf16_t *dz[3], *dsub[3], *du, *dqkv, *dcq, *dckv; } bb[2];
+  // parts[site]: partial sums of the parameter gradients a site reduces (0 FFN LayerNorm, 1 fc1 bias column sums, 2 self-attn
+  // LayerNorm, 3 self-attn q|k|v bias, 4 cross-attn LayerNorm, 5 cross-attn q|k|v bias): their reducers run on the side
+  // stream too, so the partials need the same lifetime as the gradient buffers above
+  struct BwdBufs { bf16_t *dz[3], *dsub[3], *du, *dqkv, *dcq, *dckv; float* parts[6]; } bb[2];
   hipStream_t side = nullptr; bool side_on = true;
   std::vector<hipEvent_t> ring; size_t ring_pos = 0;
   std::vector<hipEvent_t> layer_done;   // recorded on the side stream
@@ -334,7 +337,18 @@ int ensure_side(kmb_handle* h) {
   if (!h->side_on || h->side != nullptr) return 0;
   const char* env = getenv("KMB_NO_SIDE_STREAM");
   if (env && env[0] == '1') { h->side_on = false; return 0; }
-  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  {
+    // The side stream carries the weight gradients, which nothing in backward waits for; the caller's stream carries the
+    // critical path (data gradients, LayerNorm / attention backward, reducers).  KMB_SIDE_PRIORITY = low | high | default
+    // picks the side stream's queue priority (experiment knob; default: the device's default priority).
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* pr = getenv("KMB_SIDE_PRIORITY");
+    if (pr && (pr[0] == 'l' || pr[0] == 'h'))
+      HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest));
+    else
+      HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  }
   h->ring.resize(1024);   // more than one backward pass records (~90): an event is never re-recorded while an earlier wait on it may be pending
   for (auto& e : h->ring) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   h->layer_done.resize(h->cfg.encoder_layers + h->cfg.decoder_layers + 2);
@@ -381,6 +395,24 @@ int trace(const char* name, const void* p, size_t bytes, hipStream_t s) {
   return 0;
 }
 
+// The reducers that fold partial sums into parameter gradients (LayerNorm gamma / beta, biases) produce nothing backward
+// waits for: like the weight-gradient GEMMs they go to the side stream, behind an event that marks the producer of the
+// partials on the caller's stream.  They are tiny (4-10 us alone) but sat on the critical path between two data-gradient
+// GEMMs, where -- sharing the GPU with a weight-gradient GEMM of the side stream -- each took ~57 us (62 per step:
+// rocprofv3 kernel stats of the overlapped step, profiles/r02_kernel_stats_b1024.md).  `parts` must not be rewritten
+// before the side stream has read it: the per-site, per-layer-parity buffers of BwdBufs.
+// Measured (whole step, same box, alternating processes, tools/step_ab_seq.sh): b = 1024 52.9 / 53.1 ms against 53.5 / 53.9
+// with the reducers on the caller's stream; b = 256 16.50 / 16.55 against 16.21 / 16.39 -- the other way round (short
+// backward: the extra events cost more than the reducers) -- so only long batches take this path.
+hipStream_t reducer_stream(kmb_handle* h, hipStream_t sA) {
+  static const char* env = getenv("KMB_REDUCERS_ON_MAIN");   // "1": never on the side stream, "0": always (A/B knob)
+  const bool want = env ? env[0] == '0' : (h->Me > h->Md ? h->Me : h->Md) >= 16384;
+  if (!want || !h->side_on || h->side == nullptr) return sA;
+  hipEvent_t e = h->next_event();
+  if (hipEventRecord(e, sA) != hipSuccess || hipStreamWaitEvent(h->side, e, 0) != hipSuccess) return sA;
+  return h->side;
+}
+
 int bias_grad(kmb_handle* h, const bf16_t* dy, int ld, int M, int N, float* out, hipStream_t s) {
   HIPCHK(kmb_colsum_launch(dy, ld, M, N, h->parts, s));
   HIPCHK(kmb_reduce_parts_launch(h->parts, kmb_colsum_parts(M), N, out, N, s));
@@ -389,16 +421,20 @@ int bias_grad(kmb_handle* h, const bf16_t* dy, int ld, int M, int N, float* out,
 
 constexpr size_t NO_BIAS = (size_t)-1;
 // bias_off: gradient slot of the bias of the linear that produced the (dropped) sub-layer output, or NO_BIAS
+// site_parts: this site's own partials buffer (the reducer then runs on the side stream), or nullptr: the shared scratch,
+// reducer on the caller's stream
 int ln_backward(kmb_handle* h, const bf16_t* dy, const bf16_t* z, const float* mean, const float* rstd, size_t g_off,
                 size_t b_off, bf16_t* dz, bf16_t* out2, KmbDrop dy_drop, KmbDrop out2_drop, int M, hipStream_t s,
-                size_t bias_off = NO_BIAS) {
+                size_t bias_off = NO_BIAS, float* site_parts = nullptr) {
   const int d = h->d;
   if (b_off != g_off + (size_t)d) return fail("LayerNorm weight/bias are not adjacent in the arena");
-  HIPCHK(kmb_ln_bwd_launch(dy, z, mean, rstd, h->pf(g_off), dz, out2, dy_drop, out2_drop, h->parts, M, d, s));
+  float* parts = site_parts ? site_parts : h->parts;
+  HIPCHK(kmb_ln_bwd_launch(dy, z, mean, rstd, h->pf(g_off), dz, out2, dy_drop, out2_drop, parts, M, d, s));
   const int np = kmb_ln_bwd_parts(M);
+  hipStream_t rs = site_parts ? reducer_stream(h, s) : s;
   // partials are [np][3][d]: dgamma | dbeta (adjacent in the arena too: one reduce) | column sums of the sub-layer gradient
-  if (bias_off != NO_BIAS) HIPCHK(kmb_reduce_parts2_launch(h->parts, np, 3 * d, h->gf(g_off), 2 * d, h->gf(bias_off), d, s));
-  else HIPCHK(kmb_reduce_parts_launch(h->parts, np, 3 * d, h->gf(g_off), 2 * d, s));
+  if (bias_off != NO_BIAS) HIPCHK(kmb_reduce_parts2_launch(parts, np, 3 * d, h->gf(g_off), 2 * d, h->gf(bias_off), d, rs));
+  else HIPCHK(kmb_reduce_parts_launch(parts, np, 3 * d, h->gf(g_off), 2 * d, rs));
   return 0;
 }
 
@@ -491,6 +527,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     bb[k].dqkv = bp.act(Mmax * 3 * d);
     bb[k].dcq = bp.act(Md * d);
     bb[k].dckv = bp.act(Me * 2 * d);
+    for (int site = 0; site < 6; ++site) bb[k].parts[site] = bp.take<float>(parts_floats(h, (int)Mmax, B));
   }
   bf16_t* dob = bp.act(Mmax * d); bf16_t* denc = bp.act(Me * d);
   float* parts = bp.take<float>(parts_floats(h, (int)Mmax, B));
@@ -604,14 +641,14 @@ int ffn_backward(kmb_handle* h, const LayerP& L, int F, const bf16_t* x, const b
   bf16_t* dz = bb.dz[0];
   bf16_t* dsub = dr.thr16 ? bb.dsub[0] : dz;
   KCHK(ln_backward(h, dy, z, mean, rstd, L.ln_g, L.ln_b, dz, dr.thr16 ? dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
-                   L.fc2_b));
+                   L.fc2_b, bb.parts[0]));
   KCHK(trace("ffn.dz", dz, (size_t)M * d * 2, s));
   KCHK(wgrad_side(h, lin_wgrad(dsub, d, hh, F, h->gf(L.fc2_w), M, d, F, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(L.fc2_w), M, d, F);
   g.act = 2; g.aux = u; g.ld_aux = F; g.out_bf16 = bb.du; g.ld_out_bf16 = F;
-  g.colsum = h->parts;  // per-64-row-block column sums of du = partials of the fc1 bias gradient
+  g.colsum = bb.parts[1];  // per-64-row-block column sums of du = partials of the fc1 bias gradient
   KCHK(run_gemm(g, s));
-  HIPCHK(kmb_reduce_parts_launch(h->parts, (M + 63) / 64, F, h->gf(L.fc1_b), F, s));
+  HIPCHK(kmb_reduce_parts_launch(bb.parts[1], (M + 63) / 64, F, h->gf(L.fc1_b), F, reducer_stream(h, s)));
   KCHK(wgrad_side(h, lin_wgrad(bb.du, F, x, d, h->gf(L.fc1_w), M, F, d, 0.f), s));
   KCHK(trace("ffn.du", bb.du, (size_t)M * F * 2, s));
   g = lin_dgrad(bb.du, F, h->wb(L.fc1_w), M, F, d);
@@ -646,7 +683,7 @@ int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf
   bf16_t* dz = bb.dz[1];
   bf16_t* dsub = dr.thr16 ? bb.dsub[1] : dz;
   KCHK(ln_backward(h, dy, z, mean, rstd, A.ln_g, A.ln_b, dz, dr.thr16 ? dsub : nullptr, KmbDrop{0u, 0u, 1.f}, dr, M, s,
-                   A.o_b));
+                   A.o_b, bb.parts[2]));
   KCHK(trace("sa.dz", dz, (size_t)M * d * 2, s));
   KCHK(wgrad_side(h, lin_wgrad(dsub, d, o, d, h->gf(A.o_w), M, d, d, 0.f), s));
   KmbGemm g = lin_dgrad(dsub, d, h->wb(A.o_w), M, d, d);
@@ -656,9 +693,9 @@ int self_attn_backward(kmb_handle* h, const AttnP& A, int H, const bf16_t* x, bf
   KCHK(trace("sa.o(saved)", o, (size_t)M * d * 2, s));
   KCHK(trace("sa.qkv(saved)", qkv, (size_t)M * 3 * d * 2, s));
   AttnIO io{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, T, T, mask, causal};
-  KCHK(attn_backward(h, io, B, H, o, lse, h->dob, bb.dqkv, 3 * d, bb.dqkv + d, bb.dqkv + 2 * d, 3 * d, h->parts,
-                     h->parts + d, h->parts + 2 * d, 3 * d, s));
-  HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(A.qkv_b), 3 * d, s));
+  KCHK(attn_backward(h, io, B, H, o, lse, h->dob, bb.dqkv, 3 * d, bb.dqkv + d, bb.dqkv + 2 * d, 3 * d, bb.parts[3],
+                     bb.parts[3] + d, bb.parts[3] + 2 * d, 3 * d, s));
+  HIPCHK(kmb_reduce_parts_launch(bb.parts[3], B, 3 * d, h->gf(A.qkv_b), 3 * d, reducer_stream(h, s)));
   KCHK(trace("sa.dqkv", bb.dqkv, (size_t)M * 3 * d * 2, s));
   KCHK(wgrad_side(h, lin_wgrad(bb.dqkv, 3 * d, x, d, h->gf(A.qkv_w), M, 3 * d, d, 0.f), s));
   g = lin_dgrad(bb.dqkv, 3 * d, h->wb(A.qkv_w), M, 3 * d, d);
@@ -1242,17 +1279,17 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
       bf16_t* dz = bb.dz[2];
       bf16_t* dsub = dr.thr16 ? bb.dsub[2] : dz;
       KCHK(ln_backward(h, t0, a.z2, a.m2, a.r2, L.ca.ln_g, L.ca.ln_b, dz, dr.thr16 ? dsub : nullptr,
-                       KmbDrop{0u, 0u, 1.f}, dr, Md, s, L.ca.o_b));
+                       KmbDrop{0u, 0u, 1.f}, dr, Md, s, L.ca.o_b, bb.parts[4]));
       KCHK(trace("ca.dz", dz, (size_t)Md * d * 2, s));
       KCHK(wgrad_side(h, lin_wgrad(dsub, d, a.o2, d, h->gf(L.ca.o_w), Md, d, d, 0.f), s));
       KmbGemm g = lin_dgrad(dsub, d, h->wb(L.ca.o_w), Md, d, d);
       g.out_bf16 = h->dob; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
       AttnIO io{a.cq, d, a.ckv, a.ckv + d, 2 * d, T, S, bt.attention_mask, 0};
-      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, bb.dcq, d, bb.dckv, bb.dckv + d, 2 * d, h->parts,
-                         h->parts + d, h->parts + 2 * d, 3 * d, s));
+      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, bb.dcq, d, bb.dckv, bb.dckv + d, 2 * d, bb.parts[5],
+                         bb.parts[5] + d, bb.parts[5] + 2 * d, 3 * d, s));
       // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn: q|k|v biases are adjacent
-      HIPCHK(kmb_reduce_parts_launch(h->parts, B, 3 * d, h->gf(L.ca.qkv_b), 3 * d, s));
+      HIPCHK(kmb_reduce_parts_launch(bb.parts[5], B, 3 * d, h->gf(L.ca.qkv_b), 3 * d, reducer_stream(h, s)));
       KCHK(trace("ca.dob", h->dob, (size_t)Md * d * 2, s));
       KCHK(trace("ca.dcq", bb.dcq, (size_t)Md * d * 2, s));
       KCHK(trace("ca.dckv", bb.dckv, (size_t)Me * 2 * d * 2, s));
