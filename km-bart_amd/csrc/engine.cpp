@@ -1052,7 +1052,11 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
     // bf16 head (product path, no logits requested): ONE GEMM writes bf16 logits into dlogits_c and the CE kernel turns
     // them into the gradient in place.  fp32 head: logits requested by the caller / fp32 validation mode / very wide
     // vocabularies, in row chunks that bound the fp32 buffer.
-    const bool bf16_head = !g_f32 && !logits_out && h->Vpad <= 65536;
+    // KMB_FP32_HEAD=1 forces the fp32 head (chunked fp32 logits + ce_kernel_reg) in the product mode as well: the bf16 head
+    // rounds logits of magnitude 10-20 to 8 significant bits before the softmax (the reference's AMP path holds fp16
+    // logits, its CPU path fp32); measured effect on the vcg_base loss 5e-5 relative either way.
+    static const bool force_fp32_head = getenv("KMB_FP32_HEAD") != nullptr && getenv("KMB_FP32_HEAD")[0] == '1';
+    const bool bf16_head = !g_f32 && !logits_out && h->Vpad <= 65536 && !force_fp32_head;
     const int CH = bf16_head ? Md : (Md < h->lm_chunk ? Md : h->lm_chunk);
     const bf16_t* Eb = h->wb(h->shared);
     const float lmf = extra ? extra->lm_factor : 1.f;
