@@ -657,6 +657,8 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
         if labels is None and mrm_labels is None and attribute_labels is None and relation_labels is None:
             return super().forward(input_ids, image_features, attention_mask=attention_mask,
                                    decoder_input_ids=decoder_input_ids, decoder_attention_mask=decoder_attention_mask)
+        if mrm_labels is not None and mrm_mask is None:
+            raise ValueError('"mrm_mask" cannot be None while "mrm_labels" is set')   # model.py:228-229
         B, T = decoder_input_ids.shape
         dev = eng.device
         mrm = attr = rel = None
@@ -685,8 +687,6 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
         if labels is not None:
             lm_labels = labels.clone()
             lm_labels[lm_labels == cfg.cls_token_id] = -100   # model.py:297-298
-        if mrm_labels is not None and mrm_mask is None:
-            raise ValueError('"mrm_mask" cannot be None while "mrm_labels" is set')   # model.py:228-229
         need_grad = torch.is_grad_enabled()
         factors = (float(cfg.lm_loss_factor), float(cfg.mrm_loss_factor), float(cfg.attribute_loss_factor),
                    float(cfg.relation_loss_factor))

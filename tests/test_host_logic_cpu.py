@@ -190,3 +190,13 @@ def test_reference_parameter_order_matches_bart_registration_order():
     assert order[i + 2] == "model.encoder.embed_positions.weight"
     assert order[-12:] == [h + s for h in ("mrm_head", "attribute_head", "relation_head")
                            for s in (".dense.weight", ".dense.bias", ".out_proj.weight", ".out_proj.bias")]
+
+
+def test_validate_generation_score_is_importable_and_says_what_it_needs():
+    """reference vcg_train.py:28 imports `validate_generation_score` from src.validation; the metric package behind it
+    (src/evaluation.py + Java tools) is out of scope, so without it the call must fail loudly BEFORE generating."""
+    import pytest
+    from src.validation import validate_fine_tune_loss, validate_generation_score, validate_pretraining_loss  # noqa: F401
+    with pytest.raises(NotImplementedError) as e:
+        validate_generation_score(0, object(), [], [], None, "cpu", types.SimpleNamespace(cpu=True))
+    assert "evaluation" in str(e.value)

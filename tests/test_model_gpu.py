@@ -303,3 +303,54 @@ def test_pretraining_heads_against_oracle():
         if e > worst[1]:
             worst = (n, e)
     assert worst[1] < GRAD_TOL, worst
+
+
+def test_pretraining_forward_without_lm_labels_against_oracle():
+    """reference src/model/model.py:293-307: with head labels but `labels=None` the LM term is 0, the dict has no 'lm_loss'
+    key and 'loss' is the sum of the head terms; every gradient -- the tied matrix's now comes from the two embedding
+    scatter-adds alone -- against the oracle's autograd."""
+    from src.data.synthetic import make_pretrain_batch
+    from src.model import MultiModalBartForPreTraining
+    kw = dict(num_labels=37, num_attributes=11, num_relations=9, lm_loss_factor=5.0, mrm_loss_factor=1.0,
+              attribute_loss_factor=2.0, relation_loss_factor=0.5)
+    ocfg = G.tiny_config(**kw)
+    sd = G.golden_state_dict(ocfg, seed=34)
+    b = make_pretrain_batch(3, enc_len=24, dec_len=16, num_regions=6, seed=78, num_labels=37, num_attributes=11,
+                            num_relations=9, vocab_hi=G.TINY_SPECIAL_BASE, img_feat_id=ocfg.img_feat_id,
+                            special_base=G.TINY_SPECIAL_BASE, cls_id=ocfg.cls_token_id, mrm_probability=0.3)
+    b["image_features"] = G.golden_features([6, 6, 6])
+    osd = {k: v.clone().requires_grad_(k != "final_logits_bias") for k, v in sd.items()}
+    ref, _ = O.pretrain_forward(osd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"],
+                                b["decoder_input_ids"], b["decoder_attention_mask"], None, b["mrm_labels"],
+                                b["mrm_mask"], b["attribute_labels"], b["attribute_mask"], b["relation_labels"])
+    assert "lm_loss" not in ref
+    ref["loss"].backward()
+    model = MultiModalBartForPreTraining(cfg_from_oracle(ocfg, **kw))
+    model.load_state_dict(sd, strict=False)
+    model.to(DEV).eval()
+    losses = model(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
+                   attention_mask=b["attention_mask"].to(DEV), decoder_input_ids=b["decoder_input_ids"].to(DEV),
+                   decoder_attention_mask=b["decoder_attention_mask"].to(DEV), labels=None,
+                   mrm_labels=b["mrm_labels"], mrm_mask=b["mrm_mask"], attribute_labels=b["attribute_labels"],
+                   attribute_mask=b["attribute_mask"], relation_labels=b["relation_labels"])[0]
+    assert "lm_loss" not in losses and set(losses) == {"loss", "mrm_loss", "attribute_loss", "relation_loss"}
+    for k in ("loss", "mrm_loss", "attribute_loss", "relation_loss"):
+        assert abs(float(losses[k]) - float(ref[k])) <= 2e-3 * abs(float(ref[k])) + 1e-4, (k, float(losses[k]), float(ref[k]))
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    worst = ("", 0.0)
+    for n, p in model.named_parameters():
+        r = osd[n].grad
+        if r is None or float(r.norm()) < 1e-6:
+            if r is None or "k_proj.bias" in n:
+                continue
+            assert float(p.grad.norm()) < 1e-2, n
+            continue
+        e = rel(p.grad, r)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < GRAD_TOL, worst
+    with pytest.raises(ValueError):   # model.py:228-229
+        model(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
+              attention_mask=b["attention_mask"].to(DEV), decoder_input_ids=b["decoder_input_ids"].to(DEV),
+              decoder_attention_mask=b["decoder_attention_mask"].to(DEV), mrm_labels=b["mrm_labels"], mrm_mask=None)
