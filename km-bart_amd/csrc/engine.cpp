@@ -295,7 +295,16 @@ KmbGemm lin_wgrad(const bf16_t* dy, int lddy, const bf16_t* x, int ldx, float* d
 int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_floats) {
   const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
   const int nt = (g.K + 63) / 64;
-  int S = 512 / tiles;   // two 128x128 workgroups per CU; floor: a partial last round costs more than it fills
+  // Slices fill `fill` workgroup slots: 512 (two 128x128 workgroups per CU) when the reduction is long.  With a short
+  // reduction (small batches: <= 8192 encoder tokens; the rule goes by the batch, not by the GEMM: a per-GEMM rule measured
+  // worse at b = 128) the slab traffic of many slices -- S x the gradient written, then read --
+  // costs more than the fuller grid buys, and the caller's stream keeps the other CUs busy anyway: whole step, same box
+  // (tools/step_ab_seq.sh): b = 64 7.52 ms with 256 against 7.78 with 512 (384: 7.67, 192: 7.60), b = 128 10.51 with 384
+  // against 10.80 (256: 10.95), b = 32 5.99 with 256 against 6.17, b = 256 16.7 with 512 against 18.3 with 256.
+  static const int fill_env = getenv("KMB_WGRAD_FILL") ? atoi(getenv("KMB_WGRAD_FILL")) : 0;   // A/B knob
+  const int mmax = h->Me > h->Md ? h->Me : h->Md;   // tokens of the longer side: how busy the caller's stream keeps the chip
+  const int fill = fill_env > 0 ? fill_env : mmax <= 4096 ? 256 : mmax <= 8192 ? 384 : 512;
+  int S = fill / tiles;   // floor: a partial last round costs more than it fills
                          // (tools/wgrad_split_sweep.py: 36 tiles S14 59 us vs S11 70 us, 72 tiles S7 97 vs S6 104)
   if (S > 16) S = 16;
   // 128-160 tiles and a very long reduction (3072x768 over 32768 tokens): 256x256 tiles with a slice count that fills
