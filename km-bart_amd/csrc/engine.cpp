@@ -235,7 +235,8 @@ int run_gemm(const KmbGemm& g, hipStream_t s) {
       !g.out_f32 && g.out_bf16 && g.beta == 0.f && (g.N & 7) == 0 && (g.K % 64) == 0 && g.M > 512) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     const int nt = g.K / 64;
-    int S = tiles > 0 ? 512 / tiles : 1;
+    static const int small_fill = getenv("KMB_SMALL_FILL") ? atoi(getenv("KMB_SMALL_FILL")) : 512;   // A/B knob
+    int S = tiles > 0 ? small_fill / tiles : 1;
     if (S > 8) S = 8;
     if (S > nt / 4) S = nt / 4;
     while (S > 1 && (size_t)S * g.M * g.N > g_small_floats) --S;

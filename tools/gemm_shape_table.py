@@ -21,7 +21,7 @@ opt.allow_overlap(True)
 b = make_batch(B, seed=1)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 batch["image_features"] = [f.to(dev) for f in b["image_features"]]
-for _ in range(3):
+for _ in range(int(os.environ.get("KMB_TABLE_WARM_STEPS", "12"))):   # enough steps for the in-step refinement of every shape (12 launches of the once-per-step shapes)
     model.train_step_fwd_bwd(batch)
     opt.step()
 torch.cuda.synchronize()
