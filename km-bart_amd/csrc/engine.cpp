@@ -61,7 +61,9 @@ template <typename T> inline T* EP(T* p, size_t n) { return (T*)((char*)p + n * 
 
 struct ParamInfo { std::string name; size_t off; int rows, cols; };
 struct AttnP { size_t qkv_w, qkv_b, o_w, o_b, ln_g, ln_b; };
-struct LayerP { AttnP sa, ca; size_t fc1_w, fc1_b, fc2_w, fc2_b, ln_g, ln_b; };
+// ca: the cross-attention block; its qkv_w / qkv_b are the QUERY projection only -- the key | value projections of all
+// decoder layers live together in the arena (kmb_handle::xkv_w / xkv_b), ca_kv_w / ca_kv_b are this layer's slices
+struct LayerP { AttnP sa, ca; size_t ca_kv_w, ca_kv_b, fc1_w, fc1_b, fc2_w, fc2_b, ln_g, ln_b; };
 struct Bucket { size_t off, count; };
 struct HeadP { size_t dw = 0, db = 0, ow = 0, ob = 0; int d_in = 0, C = 0; bool on = false; };
 
@@ -96,6 +98,12 @@ struct kmb_handle {
   std::vector<ParamInfo> params;
   size_t arena = 0;
   size_t img_w, img_b, enc_pos, enc_lne_g, enc_lne_b, dec_pos, dec_lne_g, dec_lne_b, shared;
+  // Cross-attention keys and values are projections of the ENCODER output: the same input for every decoder layer, known
+  // before the decoder starts.  Their weights [Ld][k | v][d, d] and biases [Ld][k | v][d] are contiguous in the arena so
+  // that ONE GEMM computes all layers' keys | values ([Me, Ld * 2d]), ONE data-gradient GEMM (K = Ld * 2d) produces the
+  // encoder-output gradient (instead of six launches that each re-read and re-write it) and ONE weight-gradient GEMM
+  // their gradients.  Parameter names are the reference's (model.decoder.layers.N.encoder_attn.k_proj.weight ...).
+  size_t xkv_w = 0, xkv_b = 0;
   std::vector<LayerP> enc, dec;
   HeadP head[3];                    // mrm, attribute, relation (src/model/model.py:133-158)
   size_t heads_begin = 0, heads_end = 0; int head_rows_cap = 0;
@@ -120,6 +128,7 @@ struct kmb_handle {
   float* logits_c = nullptr; size_t logits_c_floats = 0; bf16_t* dlogits_c = nullptr; float* loss_rows = nullptr; int32_t* count = nullptr;
   int32_t* status = nullptr; float* loss_dev = nullptr;
   bf16_t *dhdec, *dyA, *dyB, *dz, *dob, *denc;
+  bf16_t *ckv_all = nullptr, *dckv_all = nullptr;   // [Me, Ld * 2d]: every decoder layer's cross-attention k | v and their gradients
   // gradient buffers read by the weight-gradient GEMMs of the side stream: one per LayerNorm site
   // (0 = FFN, 1 = self-attention, 2 = cross-attention) and per layer parity, so that the main stream can run
   // up to one layer ahead of the side stream without overwriting what it still reads
@@ -189,6 +198,17 @@ void add_attn(kmb_handle* h, const std::string& p, const std::string& ln, AttnP&
   a.qkv_b = add_param(h, p + "q_proj.bias", 1, d);
   add_param(h, p + "k_proj.bias", 1, d);
   add_param(h, p + "v_proj.bias", 1, d);
+  a.o_w = add_param(h, p + "out_proj.weight", d, d);
+  a.o_b = add_param(h, p + "out_proj.bias", 1, d);
+  a.ln_g = add_param(h, ln + ".weight", 1, d);
+  a.ln_b = add_param(h, ln + ".bias", 1, d);
+}
+
+// cross-attention block of a decoder layer: query projection, output projection, LayerNorm (k | v: see kmb_handle::xkv_w)
+void add_cross_attn(kmb_handle* h, const std::string& p, const std::string& ln, AttnP& a) {
+  const int d = h->d;
+  a.qkv_w = add_param(h, p + "q_proj.weight", d, d);
+  a.qkv_b = add_param(h, p + "q_proj.bias", 1, d);
   a.o_w = add_param(h, p + "out_proj.weight", d, d);
   a.o_b = add_param(h, p + "out_proj.bias", 1, d);
   a.ln_g = add_param(h, ln + ".weight", 1, d);
@@ -331,6 +351,12 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_
         if (eff(k) > eff(best) + 0.02) best = k;
       if (eff(best) >= eff(1) + 0.10) S = best;
     }
+  }
+  // 64 .. 128 tiles of 256x256 and no slice from the rules above (the batched cross-attention k | v weights: 9216 x 768 =
+  // 108 tiles): two or more slices so that the 256x256 kernel covers the chip once
+  if (S <= 1 && nt >= 128) {
+    const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (tiles256 >= 64 && tiles256 <= 128) S = 256 / tiles256;
   }
   if (S > nt / 2) S = nt / 2;
   while (S > 1 && (size_t)S * g.M * g.N > slab_floats) --S;
@@ -498,10 +524,12 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     a.m1 = bp.take<float>(Me); a.r1 = bp.take<float>(Me); a.m2 = bp.take<float>(Me); a.r2 = bp.take<float>(Me);
   }
   std::vector<DecAct> da(Ld);
+  bf16_t* ckv_all = bp.act(Me * (size_t)Ld * 2 * d);    // [Me, Ld * 2d]: layer l's k | v are columns [l * 2d, (l + 1) * 2d)
+  bf16_t* dckv_all = bp.act(Me * (size_t)Ld * 2 * d);
   for (int l = 0; l < Ld; ++l) {
     DecAct& a = da[l];
     a.qkv = bp.act(Md * 3 * d); a.o1 = bp.act(Md * d); a.z1 = bp.act(Md * d);
-    a.y1 = bp.act(Md * d); a.cq = bp.act(Md * d); a.ckv = bp.act(Me * 2 * d);
+    a.y1 = bp.act(Md * d); a.cq = bp.act(Md * d); a.ckv = EP(ckv_all, (size_t)l * 2 * d);
     a.o2 = bp.act(Md * d); a.z2 = bp.act(Md * d); a.y2 = bp.act(Md * d);
     a.u = bp.act(Md * Fd); a.hh = bp.act(Md * Fd); a.z3 = bp.act(Md * d);
     a.lse1 = bp.take<float>((size_t)B * h->Hd * T); a.lse2 = bp.take<float>((size_t)B * h->Hd * T);
@@ -536,7 +564,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     bb[k].du = bp.act(Mmax * Fmax);
     bb[k].dqkv = bp.act(Mmax * 3 * d);
     bb[k].dcq = bp.act(Md * d);
-    bb[k].dckv = bp.act(Me * 2 * d);
+    bb[k].dckv = nullptr;   // (the k | v gradients of every layer go to dckv_all)
     for (int site = 0; site < 6; ++site) bb[k].parts[site] = bp.take<float>(parts_floats(h, (int)Mmax, B));
   }
   bf16_t* dob = bp.act(Mmax * d); bf16_t* denc = bp.act(Me * d);
@@ -567,6 +595,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     H->slab = slab; H->slab_floats = slab_floats; H->small_slab = small_slab; H->small_floats = small_floats;
     H->hx = hx; H->hy = hy; H->hdy = hdy; H->hdx = hdx; H->hdlg = hdlg; H->hlg = hlg; H->hloss = hloss; H->dhead = dhead;
     H->losses5 = losses5; H->head_slab = head_slab; H->head_slab_floats = head_slab_floats;
+    H->ckv_all = ckv_all; H->dckv_all = dckv_all;
   }
   return bp.used();
 }
@@ -842,11 +871,25 @@ int kmb_create(const kmb_config* cfg, kmb_handle** out) {
   h->dec_lne_g = add_param(h, "model.decoder.layernorm_embedding.weight", 1, d);
   h->dec_lne_b = add_param(h, "model.decoder.layernorm_embedding.bias", 1, d);
   h->dec.resize(cfg->decoder_layers);
+  // every layer's cross-attention k | v weights, then their biases: part of the decoder-embedding segment of the arena
+  // (its gradients are complete when the batched weight gradient behind the last decoder layer's backward has run)
+  h->xkv_w = align_up(h->arena, 64);
+  for (int l = 0; l < cfg->decoder_layers; ++l) {
+    const std::string p = "model.decoder.layers." + std::to_string(l) + ".encoder_attn.";
+    h->dec[l].ca_kv_w = add_param(h, p + "k_proj.weight", d, d);
+    add_param(h, p + "v_proj.weight", d, d);
+  }
+  h->xkv_b = align_up(h->arena, 64);
+  for (int l = 0; l < cfg->decoder_layers; ++l) {
+    const std::string p = "model.decoder.layers." + std::to_string(l) + ".encoder_attn.";
+    h->dec[l].ca_kv_b = add_param(h, p + "k_proj.bias", 1, d);
+    add_param(h, p + "v_proj.bias", 1, d);
+  }
   for (int l = 0; l < cfg->decoder_layers; ++l) {
     marks.push_back(align_up(h->arena, 64));
     const std::string p = "model.decoder.layers." + std::to_string(l) + ".";
     add_attn(h, p + "self_attn.", p + "self_attn_layer_norm", h->dec[l].sa);
-    add_attn(h, p + "encoder_attn.", p + "encoder_attn_layer_norm", h->dec[l].ca);
+    add_cross_attn(h, p + "encoder_attn.", p + "encoder_attn_layer_norm", h->dec[l].ca);
     add_ffn(h, p, h->Fd, h->dec[l]);
   }
   marks.push_back(align_up(h->arena, 64));
@@ -1026,6 +1069,13 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   KCHK(embed_ln_forward(bt.decoder_input_ids, nullptr, h->pf(h->shared), nullptr, h->pf(h->dec_pos),
                         h->cfg.extra_pos_embeddings, T, scale, h->pf(h->dec_lne_g), h->pf(h->dec_lne_b),
                         h->zd0, h->xd[0], h->md0, h->rd0, Md, d, eps, h->drop_site(2, tr), s));
+  const int Ldec = h->cfg.decoder_layers;
+  const int ldkv = Ldec * 2 * d;   // row stride of the batched cross-attention k | v buffers
+  if (Ldec > 0) {   // every decoder layer's cross-attention keys | values in ONE GEMM (same input: the encoder output)
+    KmbGemm g = lin_fwd(enc, d, h->wb(h->xkv_w), h->pf(h->xkv_b), Me, ldkv, d);
+    g.out_bf16 = h->ckv_all; g.ld_out_bf16 = ldkv;
+    KCHK(run_gemm(g, s));
+  }
   for (int l = 0; l < h->cfg.decoder_layers; ++l) {
     const LayerP& L = h->dec[l];
     DecAct& a = h->da[l];
@@ -1035,10 +1085,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
     KmbGemm g = lin_fwd(a.y1, d, h->wb(L.ca.qkv_w), h->pf(L.ca.qkv_b), Md, d, d);
     g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = a.cq; g.ld_out_bf16 = d;
     KCHK(run_gemm(g, s));
-    g = lin_fwd(enc, d, EP(h->wb(L.ca.qkv_w), (size_t)d * d), h->pf(L.ca.qkv_b) + d, Me, 2 * d, d);
-    g.out_bf16 = a.ckv; g.ld_out_bf16 = 2 * d;
-    KCHK(run_gemm(g, s));
-    AttnIO io{a.cq, d, a.ckv, EP(a.ckv, d), 2 * d, T, S, bt.attention_mask, 0};
+    AttnIO io{a.cq, d, a.ckv, EP(a.ckv, d), ldkv, T, S, bt.attention_mask, 0};
     KCHK(attn_forward(h, io, B, h->Hd, a.o2, a.lse2, s));
     const KmbDrop dr = h->drop_site(101 + 3 * l, tr);
     g = lin_fwd(a.o2, d, h->wb(L.ca.o_w), h->pf(L.ca.o_b), Md, d, d);
@@ -1228,7 +1275,7 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
     for (int k = 0; k < 2; ++k) {
       for (int st = 0; st < 3; ++st) { pr("bb.dz", h->bb[k].dz[st], Mm * d * 2); pr("bb.dsub", h->bb[k].dsub[st], Mm * d * 2); }
       pr("bb.du", h->bb[k].du, Mm * (size_t)(h->Fe > h->Fd ? h->Fe : h->Fd) * 2); pr("bb.dqkv", h->bb[k].dqkv, Mm * 3 * d * 2);
-      pr("bb.dcq", h->bb[k].dcq, (size_t)Md * d * 2); pr("bb.dckv", h->bb[k].dckv, (size_t)Me * 2 * d * 2);
+      pr("bb.dcq", h->bb[k].dcq, (size_t)Md * d * 2);
     }
     pr("ws_begin", h->ws, h->ws_bytes);
   }
@@ -1299,32 +1346,39 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
       KmbGemm g = lin_dgrad(dsub, d, h->wb(L.ca.o_w), Md, d, d);
       g.out_bf16 = h->dob; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
-      AttnIO io{a.cq, d, a.ckv, a.ckv + d, 2 * d, T, S, bt.attention_mask, 0};
-      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, bb.dcq, d, bb.dckv, bb.dckv + d, 2 * d, bb.parts[5],
+      const int ldkv = Ld * 2 * d;
+      bf16_t* dkv = h->dckv_all + (size_t)l * 2 * d;   // this layer's columns of the batched k | v gradient
+      AttnIO io{a.cq, d, a.ckv, a.ckv + d, ldkv, T, S, bt.attention_mask, 0};
+      KCHK(attn_backward(h, io, B, h->Hd, a.o2, a.lse2, h->dob, bb.dcq, d, dkv, dkv + d, ldkv, bb.parts[5],
                          bb.parts[5] + d, bb.parts[5] + 2 * d, 3 * d, s));
-      // q projection (weights rows [0,d)), k|v projection (rows [d,3d)) of encoder_attn: q|k|v biases are adjacent
-      HIPCHK(kmb_reduce_parts_launch(bb.parts[5], B, 3 * d, h->gf(L.ca.qkv_b), 3 * d, reducer_stream(h, s)));
+      // bias gradients from the attention kernel's per-batch-item column sums [B][q | k | v]: q's bias lives in the layer,
+      // the k | v biases of all layers together (kmb_handle::xkv_b)
+      HIPCHK(kmb_reduce_parts2_launch(bb.parts[5], B, 3 * d, h->gf(L.ca.qkv_b), d, h->gf(L.ca_kv_b), 2 * d, reducer_stream(h, s)));
       KCHK(trace("ca.dob", h->dob, (size_t)Md * d * 2, s));
       KCHK(trace("ca.dcq", bb.dcq, (size_t)Md * d * 2, s));
-      KCHK(trace("ca.dckv", bb.dckv, (size_t)Me * 2 * d * 2, s));
       KCHK(wgrad_side(h, lin_wgrad(bb.dcq, d, a.y1, d, h->gf(L.ca.qkv_w), Md, d, d, 0.f), s));
       g = lin_dgrad(bb.dcq, d, h->wb(L.ca.qkv_w), Md, d, d);
       g.residual = dz; g.ld_res = d; g.out_bf16 = t1; g.ld_out_bf16 = d;
       KCHK(run_gemm(g, s));
-      KCHK(wgrad_side(h, lin_wgrad(bb.dckv, 2 * d, enc, d, h->gf(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d, 0.f), s));
-      g = lin_dgrad(bb.dckv, 2 * d, h->wb(L.ca.qkv_w) + (size_t)d * d, Me, 2 * d, d);
-      if (denc_init) { g.residual = h->denc; g.ld_res = d; }
-      g.out_bf16 = h->denc; g.ld_out_bf16 = d;
-      KCHK(run_gemm(g, s));
       KCHK(trace("ca.t1", t1, (size_t)Md * d * 2, s));
-      KCHK(trace("ca.denc", h->denc, (size_t)Me * d * 2, s));
-      denc_init = true;
     }
     KCHK(self_attn_backward(h, L.sa, h->Hd, h->xd[l], a.qkv, a.o1, a.lse1, a.z1, a.m1, a.r1, t1, t0, B, T,
                             bt.decoder_attention_mask, 1, h->drop_site(100 + 3 * l, tr), bb, s));
     dy = t0;  // t0 now holds d(loss)/d(xd[l]); keep it as the input of the next iteration
     cur ^= 1;  // next iteration writes its first result into the other buffer
     KCHK(layer_end(c, ev++));
+  }
+  // ---- cross-attention keys | values of ALL decoder layers: one data gradient (the encoder output's gradient, reduction
+  // over Ld * 2d) and one weight gradient
+  if (Ld > 0) {
+    const int ldkv = Ld * 2 * d;
+    KCHK(trace("ca.dckv_all", h->dckv_all, (size_t)Me * ldkv * 2, s));
+    KCHK(wgrad_side(h, lin_wgrad(h->dckv_all, ldkv, enc, d, h->gf(h->xkv_w), Me, ldkv, d, 0.f), s));
+    KmbGemm g = lin_dgrad(h->dckv_all, ldkv, h->wb(h->xkv_w), Me, ldkv, d);
+    g.out_bf16 = h->denc; g.ld_out_bf16 = d;
+    KCHK(run_gemm(g, s));
+    KCHK(trace("ca.denc", h->denc, (size_t)Me * d * 2, s));
+    denc_init = true;
   }
   // ---- decoder embedding: xd[0] = drop(LN(zd0))  (main stream only)
   KCHK(ln_backward(h, dy, h->zd0, h->md0, h->rd0, h->dec_lne_g, h->dec_lne_b, h->dz, nullptr, h->drop_site(2, tr),
@@ -1336,7 +1390,16 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
   HIPCHK(kmb_embed_bwd_launch(h->dz, bt.decoder_input_ids, nullptr, scale, h->gf(h->shared), nullptr,
                               h->cfg.pad_token_id, Md, d, s));
   HIPCHK(kmb_pos_bwd_launch(h->dz, B, T, d, h->gf(h->dec_pos), h->cfg.extra_pos_embeddings, h->Prows, s));
-  HIPCHK(hipEventRecord(h->events[ev++], s));
+  // this bucket also holds the cross-attention k | v weights and biases of every decoder layer, whose gradients come from
+  // the side stream (the batched weight gradient above, the per-layer bias reducers): complete when BOTH streams are here
+  if (side) {
+    hipEvent_t e = h->next_event();
+    HIPCHK(hipEventRecord(e, s));
+    HIPCHK(hipStreamWaitEvent(h->side, e, 0));
+    HIPCHK(hipEventRecord(h->events[ev++], h->side));
+  } else {
+    HIPCHK(hipEventRecord(h->events[ev++], s));
+  }
   // ---- encoder layers
   if (!denc_init) HIPCHK(hipMemsetAsync(h->denc, 0, (size_t)Me * d * sizeof(bf16_t), s));
   dy = h->denc;
@@ -1485,8 +1548,9 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
   a.m1 = bp.take<float>(Me); a.r1 = bp.take<float>(Me); a.m2 = bp.take<float>(Me); a.r2 = bp.take<float>(Me);
   g.ckv.resize(Ld);
   for (int i = 0; i < 2; ++i) { g.kc[i].resize(Ld); g.vc[i].resize(Ld); }
+  bf16_t* ckv_all = bp.act(Me * (size_t)Ld * 2 * d);   // [Me, Ld * 2d]: layer l's cross-attention k | v are columns [l * 2d, (l + 1) * 2d)
   for (int l = 0; l < Ld; ++l) {
-    g.ckv[l] = bp.act(Me * 2 * d);
+    g.ckv[l] = ckv_all + (size_t)l * 2 * d;
     for (int i = 0; i < 2; ++i) { g.kc[i][l] = bp.act(R * Tmax * d); g.vc[i][l] = bp.act(R * Tmax * d); }
   }
   g.kv_row = bp.take<int32_t>(R);
@@ -1543,11 +1607,10 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.ckv = g.ckv; G.kc[0] = g.kc[0]; G.kc[1] = g.kc[1]; G.vc[0] = g.vc[0]; G.vc[1] = g.vc[1];
   G.kv_row = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
   G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab; G.wp = g.wp;
-  // cross-attention K|V of every decoder layer, computed once per batch item (not per beam)
-  for (int l = 0; l < Ld; ++l) {
-    const LayerP& L = h->dec[l];
-    KmbGemm gm = lin_fwd(enc, d, h->wb(L.ca.qkv_w) + (size_t)d * d, h->pf(L.ca.qkv_b) + d, Me, 2 * d, d);
-    gm.out_bf16 = G.ckv[l]; gm.ld_out_bf16 = 2 * d;
+  // cross-attention K|V of every decoder layer, computed once per batch item (not per beam), all layers in ONE GEMM
+  if (Ld > 0) {
+    KmbGemm gm = lin_fwd(enc, d, h->wb(h->xkv_w), h->pf(h->xkv_b), Me, Ld * 2 * d, d);
+    gm.out_bf16 = G.ckv[0]; gm.ld_out_bf16 = Ld * 2 * d;
     KCHK(run_gemm(gm, s));
   }
   if (!G.wp.empty()) {   // fragment-order copies of the decoder weights for the fused decode blocks, one launch per 48
@@ -1643,7 +1706,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       memset(&b, 0, sizeof(b));
       b.kind = 2; b.in = G.z; b.ld_in = d; b.gamma = h->pf(L.sa.ln_g); b.beta = h->pf(L.sa.ln_b); b.eps = eps; b.ln_out = G.y;
       b.W = G.wp[(size_t)l * 6 + 2]; b.bias = h->pf(L.ca.qkv_b); b.R = R; b.K = d; b.N = d; b.out = G.o; b.ld_out = d;
-      b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.ckv[l]; b.Vc = G.ckv[l] + d; b.Tmax = G.S; b.ldc = 2 * d; b.Tk = G.S;
+      b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.ckv[l]; b.Vc = G.ckv[l] + d; b.Tmax = G.S; b.ldc = h->cfg.decoder_layers * 2 * d; b.Tk = G.S;
       b.kv_row = G.kv_row; b.key_mask = G.bt.attention_mask; b.mask_ld = G.S; b.kv_group = G.nb;   // kv_row[i] = i / nb
       KCHK(block(b));
       memset(&b, 0, sizeof(b));
@@ -1682,7 +1745,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     g.col_scale = 0.125f; g.col_scale_n = d; g.out_bf16 = G.cq; g.ld_out_bf16 = d;
     KCHK(run_gemm(g, s));
     memset(&a, 0, sizeof(a));
-    a.Q = G.cq; a.ldq = d; a.Kc = G.ckv[l]; a.Vc = G.ckv[l] + d; a.Tmax = G.S; a.ldc = 2 * d; a.kv_row = G.kv_row;
+    a.Q = G.cq; a.ldq = d; a.Kc = G.ckv[l]; a.Vc = G.ckv[l] + d; a.Tmax = G.S; a.ldc = h->cfg.decoder_layers * 2 * d; a.kv_row = G.kv_row;
     a.key_mask = G.bt.attention_mask; a.mask_ld = G.S; a.mask_row = G.kv_row;
     a.R = R; a.H = h->Hd; a.Tk = G.S; a.O = G.o; a.ldo = d;
     HIPCHK(kmb_attn_decode_launch(a, s));
