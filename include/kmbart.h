@@ -62,7 +62,8 @@ typedef struct KmbGemm {
   int32_t M, N, K;
   const float* bias;
   float col_scale; int32_t col_scale_n;
-  int32_t act;                    /* 0 none, 1 GeLU (erf form), 2 multiply by aux (the stored GeLU'), 3 tanh, 4 multiply by 1 - aux^2 */
+  int32_t act;                    /* 0 none, 1 GeLU (erf form), 2 multiply by aux (the stored GeLU'), 3 tanh, 4 multiply by 1 - aux^2,
+                                   * 5 exp(v - row_shift[row]) with per-row sums (the tied head's cross-entropy: fields at the end) */
   kmb_bf16* preact; int32_t ld_preact;   /* act 1, optional: receives GeLU'(pre-activation) -- what the backward pass needs */
   const kmb_bf16* aux; int32_t ld_aux;   /* act 2: the tensor act 1 stored; act 4: tanh output */
   uint32_t drop_thr16; uint32_t drop_seed; float drop_scale;
@@ -74,6 +75,12 @@ typedef struct KmbGemm {
   int32_t tile_order;             /* set by the launcher (results never depend on it): bit 0 = contiguous tile range per
                                    * XCD; bit 1 = L2 prefetch of the activation panel (persistent kernels); bit 2 = split-K
                                    * (tile, slice) pairs enumerated slice-major: an XCD works on one or two K slices */
+  /* act 5 (reference src/model/model.py:397-402 without a pass over the logits): the output is exp(v - row_shift[row]);
+   * row_sums[row * row_sums_ld + col / 64] receives, for every 64-column block, the fp32 sum of the row's values in it (a
+   * wider wave block puts its whole sum into its first slot and zeros into the others: every slot is written exactly
+   * once), pick_out[row] the value v - row_shift[row] at column pick_col[row] (rows whose pick_col is outside [0, N)
+   * are not written).  Persistent 256- / 128-column variants only, M and N multiples of 256, bias required. */
+  const float* row_shift; float* row_sums; int32_t row_sums_ld; const int64_t* pick_col; float* pick_out;
 } KmbGemm;
 
 /* ---- fused attention (csrc/attention.hip) -------------------------------------------------- */

@@ -129,6 +129,10 @@ struct kmb_handle {
   int32_t* status = nullptr; float* loss_dev = nullptr;
   bf16_t *dhdec, *dyA, *dyB, *dz, *dob, *denc;
   bf16_t *ckv_all = nullptr, *dckv_all = nullptr;   // [Me, Ld * 2d]: every decoder layer's cross-attention k | v and their gradients
+  // tied-head cross-entropy without a pass over the logits (loss.hip): per-row shift / picked label value / row sum / scale,
+  // the row-scaled decoder states a . H and the bias padded to Vpad
+  float *ce_shift = nullptr, *ce_pick = nullptr, *ce_srow = nullptr, *ce_alpha = nullptr, *ce_bias = nullptr;
+  bf16_t* ce_ah = nullptr;
   // gradient buffers read by the weight-gradient GEMMs of the side stream: one per LayerNorm site
   // (0 = FFN, 1 = self-attention, 2 = cross-attention) and per layer parity, so that the main stream can run
   // up to one layer ahead of the side stream without overwriting what it still reads
@@ -551,6 +555,10 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   const size_t small_floats = Mmax <= 8192 ? (size_t)8 * Mmax * d : 1024;
   float* small_slab = bp.take<float>(small_floats);
   float* loss_rows = bp.take<float>(Md);
+  float* ce_shift = bp.take<float>(Md); float* ce_pick = bp.take<float>(Md);
+  float* ce_srow = bp.take<float>(Md); float* ce_alpha = bp.take<float>(Md);
+  float* ce_bias = bp.take<float>(h->Vpad);
+  bf16_t* ce_ah = bp.act(Md * d);
   bf16_t* dhdec = bp.act(Md * d);
   bf16_t* dyA = bp.act(Mmax * d); bf16_t* dyB = bp.act(Mmax * d);
   bf16_t* dz = bp.act(Mmax * d);
@@ -596,6 +604,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
     H->hx = hx; H->hy = hy; H->hdy = hdy; H->hdx = hdx; H->hdlg = hdlg; H->hlg = hlg; H->hloss = hloss; H->dhead = dhead;
     H->losses5 = losses5; H->head_slab = head_slab; H->head_slab_floats = head_slab_floats;
     H->ckv_all = ckv_all; H->dckv_all = dckv_all;
+    H->ce_shift = ce_shift; H->ce_pick = ce_pick; H->ce_srow = ce_srow; H->ce_alpha = ce_alpha; H->ce_bias = ce_bias; H->ce_ah = ce_ah;
   }
   return bp.used();
 }
@@ -1117,7 +1126,53 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
     const int CH = bf16_head ? Md : (Md < h->lm_chunk ? Md : h->lm_chunk);
     const bf16_t* Eb = h->wb(h->shared);
     const float lmf = extra ? extra->lm_factor : 1.f;
-    for (int r0 = 0, c = 0; r0 < Md; r0 += CH, ++c) {
+    // Cross-entropy without a pass over the logits (loss.hip "Tied-head cross-entropy WITHOUT a pass over the logits"):
+    // the head GEMM stores exp(logit - label's logit) and per-row sums, the data- and weight-gradient GEMMs run on that
+    // matrix with per-row factors applied outside.  Needs whole 256-row / 256-column tiles (Md % 256 == 0; the vocabulary is
+    // padded to Vpad with a -1e30 bias); other shapes, fp32 logits and KMB_FUSED_CE=0 take the two-kernel path below.
+    const char* fce = getenv("KMB_FUSED_CE");     // read per call: tests flip it inside one process
+    const bool fused_ce_env = !(fce && fce[0] == '0');
+    const int nparts = h->Vpad / 64;
+    const bool fused_ce = bf16_head && bt.labels && fused_ce_env && (Md % 256) == 0 && (h->Vpad % 256) == 0 && (d % 64) == 0 &&
+                          d >= 128 && (long)(Md / 256) * (h->Vpad / 256) >= 128 && (size_t)Md * nparts <= h->logits_c_floats;
+    if (fused_ce) {
+      HIPCHK(kmb_ce_label_logit_launch(hdec, d, Eb, d, h->flb, bt.labels, Md, d, h->V, h->ce_shift, s));
+      HIPCHK(kmb_ce_pad_bias_launch(h->flb, h->V, h->Vpad, h->ce_bias, s));
+      KmbGemm g = lin_fwd(hdec, d, Eb, h->ce_bias, Md, h->Vpad, d);
+      g.act = 5; g.out_bf16 = h->dlogits_c; g.ld_out_bf16 = h->Vpad;
+      g.row_shift = h->ce_shift; g.row_sums = h->logits_c; g.row_sums_ld = nparts; g.pick_col = bt.labels; g.pick_out = h->ce_pick;
+      KCHK(run_gemm(g, s));
+      HIPCHK(kmb_ce_rows_finish_launch(h->logits_c, nparts, nparts, h->ce_pick, bt.labels, h->count, lmf, Md, d, h->V, hdec, d,
+                                       h->loss_rows, h->ce_srow, h->ce_alpha, need_grad ? h->ce_ah : nullptr, s));
+      if (need_grad) {
+        // dH_r = a_r (sum_j P_rj E_j - S_r E[label_r]): the GEMM on P into fp32 slabs (the row sums in that buffer were consumed
+        // by the launch above), then the finish
+        KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, Md, h->Vpad, d);
+        const int tiles256 = ((Md + 255) / 256) * ((d + 255) / 256);
+        static const int rounds = getenv("KMB_HEAD_DGRAD_ROUNDS") ? atoi(getenv("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
+        int S = tiles256 > 0 ? (256 * rounds) / tiles256 : 1;
+        if (S > 8) S = 8;
+        while (S > 1 && (size_t)S * Md * d > h->logits_c_floats) --S;
+        if (S > 1 && h->Vpad / 64 >= 2 * S) {
+          gd.split_k = S; gd.slab = h->logits_c;
+        } else {
+          S = 1; gd.out_f32 = h->logits_c; gd.ld_out_f32 = d;
+        }
+        KCHK(run_gemm(gd, s));
+        HIPCHK(kmb_ce_dgrad_finish_launch(h->logits_c, S, (size_t)Md * d, h->ce_alpha, h->ce_srow, bt.labels, Eb, d, h->V, h->dhdec,
+                                          Md, d, s));
+        // dE = P^T (a . H) - scatter_r(S_r (a . H)_r -> row label_r), on the side stream like the two-kernel path's
+        KCHK(ensure_side(h));
+        KCHK(wgrad_side(h, lin_wgrad(h->dlogits_c, h->Vpad, h->ce_ah, d, h->gf(h->shared), Md, h->V, d, 0.f), s));
+        const bool on_side = h->side_on && h->side;
+        HIPCHK(kmb_ce_wgrad_fix_launch(h->ce_ah, h->ce_srow, bt.labels, h->V, h->gf(h->shared), Md, d, on_side ? h->side : s));
+        if (on_side) {
+          HIPCHK(hipEventRecord(h->head_wgrad_done, h->side));
+          h->head_wgrad_pending = true;
+        }
+      }
+    }
+    for (int r0 = 0, c = 0; !fused_ce && r0 < Md; r0 += CH, ++c) {
       const int rows = (Md - r0) < CH ? (Md - r0) : CH;
       KmbGemm g = lin_fwd(EP(hdec, (size_t)r0 * d), d, Eb, h->flb, rows, h->V, d);
       if (bf16_head) {
@@ -1136,7 +1191,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       HIPCHK(kmb_ce_launch(lg, h->Vpad, h->V, bt.labels + r0, rows, h->count, lmf, h->loss_rows + r0,
                            need_grad ? h->dlogits_c + (size_t)r0 * h->Vpad : nullptr, s));
     }
-    if (bt.labels && need_grad) {
+    if (bt.labels && need_grad && !fused_ce) {
       // dH = dlogits E  (reduction over the padded vocabulary; pad columns / rows are zero)
       KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, Md, h->Vpad, d);
       // [Md, d] has few 256x256 tiles (192 at Md = 16384: three quarters of the CUs) and the reduction runs over the

@@ -1150,7 +1150,34 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
         if (SCALE) v[e] = v[e] * scale2;
       }
       const size_t roff = (size_t)(16 * i + RPI * it);
-      if (ACT == 1) {
+      if constexpr (ACT == 5) {
+        // tied-head cross-entropy: exp(v - shift[row]) is what is stored; the row's fp32 sum over this wave block and the
+        // shifted value at the label's column go to the side buffers (see KmbGemm)
+        static_assert(ACT != 5 || WCOLS == 64 || WCOLS == 128, "act 5: 64- or 128-column wave blocks");
+        const int grow = row0w + lr + 16 * i + RPI * it;
+        const float c = p.row_shift[grow];
+        const long long label = p.pick_col != nullptr ? (long long)p.pick_col[grow] : -1ll;
+        const kmb_f32x2 c2 = {c, c};
+        float picked = 0.f;
+        bool has = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = v[e] - c2;
+          if ((long long)(gcol + 2 * e) == label) { picked = v[e][0]; has = true; }
+          if ((long long)(gcol + 2 * e + 1) == label) { picked = v[e][1]; has = true; }
+          const kmb_f32x2 t = v[e] * 1.4426950408889634f;
+          v[e] = kmb_f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        }
+        if (has) p.pick_out[grow] = picked;
+        float sum = (v[0][0] + v[0][1]) + (v[1][0] + v[1][1]) + ((v[2][0] + v[2][1]) + (v[3][0] + v[3][1]));
+#pragma unroll
+        for (int o = 1; o < CL; o <<= 1) sum += __shfl_xor(sum, o);   // the CL column-lanes of a row are consecutive lanes
+        if ((lane % CL) == 0) {
+          float* slot = p.row_sums + (size_t)grow * p.row_sums_ld + (col0w >> 6);
+          slot[0] = sum;
+          if (WCOLS == 128) slot[1] = 0.f;
+        }
+      } else if (ACT == 1) {
         if (pre != nullptr) {   // GeLU and GeLU' from one evaluation; the derivative is stored for backward (ACT 2)
           kmb_f32x2 dv[4];
 #pragma unroll
@@ -1757,6 +1784,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
         KMB_LEAN(true, false, 1, false, false, false);
       } else if (lean_ok && p.act == 2 && !hb && !hr && !hd && hc && !hs) {
         KMB_LEAN(false, false, 2, false, false, true);
+      } else if (lean_ok && p.act == 5 && hb && !hr && !hd && !hc && !hs && (WCOLS == 64 || WCOLS == 128)) {
+        if constexpr (WCOLS == 64 || WCOLS == 128) KMB_LEAN(true, false, 5, false, false, false);
       } else {
         v11_epilogue<-1, true, true, false, WROWS, NJ>(p, acc, ef, lane, r, g, row0w, col0w);   // edges and rare classes
       }
@@ -1969,6 +1998,10 @@ const char* kmb_gemm_check(const KmbGemm& p) {
   if (p.preact && ((p.ld_preact & 7) || ((uintptr_t)p.preact & 15))) return "gemm: preact alignment";
   if (p.out_f32 && ((uintptr_t)p.out_f32 & 15)) return "gemm: f32 output alignment";
   if ((p.act == 2 || p.act == 4) && !p.aux) return "gemm: derivative epilogue needs aux";
+  if (p.act == 5 && (!p.row_shift || !p.row_sums || !p.bias || !p.out_bf16 || p.out_f32 || p.split_k > 1 || (p.M & 255) || (p.N & 255) ||
+                     !p.a_kc || !p.b_kc || (p.K % BK) || p.K < 2 * BK || p.residual || p.colsum || p.drop_thr16 || p.col_scale_n > 0 ||
+                     p.row_sums_ld < p.N / 64 || (long)(p.M / 256) * (p.N / 256) < 128 || (p.pick_col && !p.pick_out)))
+    return "gemm: act 5 (exp with row sums) needs the persistent forward layout: M, N multiples of 256 with >= 128 tiles, bias, bf16 output, row_shift, row_sums";
   if (!p.a_kc && p.b_kc) return "gemm: (M-contiguous A, K-contiguous B) is not instantiated";
   if (p.colsum && p.split_k > 1) return "gemm: column sums are not available with split-K";
   if (p.split_k > 1) {
@@ -2261,6 +2294,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (v == 15 && !v11_ok(p, 192)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
     if (v != 1 && v != 7 && v != 8 && (v < 11 || v > 15)) v = 7;
+    if (p.act == 5 && (v < 11 || v == 13 || v == 15)) v = 11;
     KmbGemm q = p;
     q.tile_order = p.tile_order | (prefetch_a(p) ? 2 : 0);
     return launch_variant(v, q, stream);
@@ -2269,12 +2303,12 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   const TuneKey key{p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act};
   auto it = g_best.find(key);
   if (it == g_best.end()) {
-    if (!autotune || writes_an_input(p)) return launch_variant(7, p, stream);
+    if (!autotune || writes_an_input(p)) return p.act == 5 ? launch_config(p, 11, stream) : launch_variant(7, p, stream);
     const int cands[16] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
                            14, 14 + 16, 15, 15 + 16,
                            7 + 16 * 5, 8 + 16 * 5};                                       // split-K only: slice-major
     float best_ms = 1e30f;
-    int best = 7;
+    int best = p.act == 5 ? 11 : 7;
     std::vector<std::pair<float, int>> timed;   // (ms, candidate) of every eligible candidate
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_variant(7, p, stream);
@@ -2296,6 +2330,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
       if ((c & 15) == 14 && !v11_ok(p)) continue;
       if ((c & 15) == 15 && !v11_ok(p, 192)) continue;
+      if (p.act == 5 && ((c & 15) < 11 || (c & 15) == 13 || (c & 15) == 15)) continue;   // lean epilogue of the 256- / 128-column persistent variants only
       if (((c >> 4) & 4) && p.split_k <= 1) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;

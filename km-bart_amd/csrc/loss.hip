@@ -709,7 +709,168 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tied-head cross-entropy WITHOUT a pass over the logits (round 3).  Reference src/model/model.py:397-402:
+//   loss = mean over valid rows of  lse(v_r) - v_r[label_r],   v_r = h_r E^T + b.
+// The head GEMM (KmbGemm act 5) stores  P[r][j] = exp(v_rj - c_r)  in bf16 with c_r = the label's logit, so that
+// P[r][label] = 1 exactly and the row cannot overflow unless some logit exceeds the label's by 88 (a loss of 88), and
+// leaves the fp32 row sums S_r = sum_j P[r][j] (per 64-column block) and d_r = v_r[label] - c_r.  Then
+//   loss_r = log S_r - d_r,      softmax_rj = P[r][j] / S_r,
+//   dlogits_rj = g (P[r][j] / S_r - [j == label_r]),          g = lm_factor / (number of valid rows)
+// is never materialised: with a_r = g / S_r
+//   dH_r  = a_r * (sum_j P[r][j] E_j  -  S_r E[label_r])            (the data-gradient GEMM runs on P, this is its finish)
+//   dE    = P^T (a . H)  -  scatter_r ( S_r * (a . H)_r  -> row label_r )   (the weight-gradient GEMM runs on P and a . H)
+// so the 2 x 3.3 GB read-modify-write of ce_kernel_reg_bf16 (1.76 ms of a b = 1024 step) disappears; P is stored at
+// 8 significant bits relative to the probability itself (the two-kernel path rounds the LOGIT to 8 bits: 3-6 % on p).
+// Both corrections use the same rounded a . H that the GEMM reads, so the label row's net term (1 - S_r) keeps its
+// relative precision.
+
+// c_r = h_r . E[label_r] + bias[label_r]   (ignored rows: column 0, only to keep their exps finite); one wave per row
+__global__ __launch_bounds__(256) void ce_label_logit_kernel(const bf16_t* __restrict__ H, int ldh, const bf16_t* __restrict__ E,
+                                                             int lde, const float* __restrict__ bias,
+                                                             const int64_t* __restrict__ labels, int rows, int d, int V,
+                                                             float* __restrict__ shift) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  long long lab = labels[r];
+  if (lab < 0 || lab >= V) lab = 0;
+  const bf16_t* h = H + (size_t)r * ldh;
+  const bf16_t* e = E + (size_t)lab * lde;
+  float acc = 0.f;
+  for (int i = lane * 8; i < d; i += 512) {
+    float a[8], b[8];
+    unpack8(*reinterpret_cast<const u32x4*>(h + i), a);
+    unpack8(*reinterpret_cast<const u32x4*>(e + i), b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fmaf(a[k], b[k], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) shift[r] = acc + bias[lab];
+}
+
+// bias_pad[0, V) = bias, bias_pad[V, Vpad) = -1e30 (exp -> 0: the padded vocabulary columns contribute nothing)
+__global__ __launch_bounds__(256) void ce_pad_bias_kernel(const float* __restrict__ bias, int V, int Vpad, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < Vpad) out[i] = i < V ? bias[i] : -1e30f;
+}
+
+// per row: S_r, loss_r, a_r and the row-scaled copy a . H (bf16); one wave per row
+__global__ __launch_bounds__(256) void ce_rows_finish_kernel(const float* __restrict__ row_sums, int ld_sums, int nparts,
+                                                             const float* __restrict__ pick, const int64_t* __restrict__ labels,
+                                                             const int32_t* __restrict__ count, float lm_factor, int rows, int d, int V,
+                                                             const bf16_t* __restrict__ H, int ldh, float* __restrict__ loss_rows,
+                                                             float* __restrict__ srow, float* __restrict__ alpha,
+                                                             bf16_t* __restrict__ ah) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const long long lab = labels[r];
+  const bool valid = lab != -100 && lab >= 0 && lab < V;
+  float s = 0.f;
+  for (int i = lane; i < nparts; i += 64) s += row_sums[(size_t)r * ld_sums + i];
+  s = wave_sum(s);
+  const int n = count[0];
+  const float a = (valid && n > 0 && s > 0.f) ? lm_factor / ((float)n * s) : 0.f;
+  if (lane == 0) {
+    loss_rows[r] = valid ? __logf(s) - pick[r] : 0.f;
+    srow[r] = valid ? s : 0.f;
+    alpha[r] = a;
+  }
+  if (ah != nullptr) {
+    for (int i = lane * 8; i < d; i += 512) {
+      float x[8];
+      unpack8(*reinterpret_cast<const u32x4*>(H + (size_t)r * ldh + i), x);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] *= a;
+      *reinterpret_cast<u32x4*>(ah + (size_t)r * d + i) = pack8(x);
+    }
+  }
+}
+
+// dH_r = a_r * (sum_s slab[s][r] - S_r E[label_r]);  8 columns per thread
+__global__ __launch_bounds__(256) void ce_dgrad_finish_kernel(const float* __restrict__ slab, int nslabs, size_t stride,
+                                                              const float* __restrict__ alpha, const float* __restrict__ srow,
+                                                              const int64_t* __restrict__ labels, const bf16_t* __restrict__ E, int lde,
+                                                              int V, bf16_t* __restrict__ out, int rows, int d) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // chunk of 8 columns
+  const int per_row = d >> 3;
+  const int r = (int)(idx / per_row);
+  if (r >= rows) return;
+  const int c = (int)(idx - (size_t)r * per_row) * 8;
+  const float a = alpha[r];
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (a != 0.f) {
+    for (int s = 0; s < nslabs; ++s) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + s * stride + (size_t)r * d + c);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + s * stride + (size_t)r * d + c + 4);
+      v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3]; v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
+    }
+    const long long lab = labels[r];
+    if (lab >= 0 && lab < V) {
+      float e[8];
+      unpack8(*reinterpret_cast<const u32x4*>(E + (size_t)lab * lde + c), e);
+      const float sr = srow[r];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] -= sr * e[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= a;
+  }
+  *reinterpret_cast<u32x4*>(out + (size_t)r * d + c) = pack8(v);
+}
+
+// dE[label_r] -= S_r * (a . H)_r   (fp32 atomics: several rows may name the same token; like the embedding scatter-adds)
+__global__ __launch_bounds__(256) void ce_wgrad_fix_kernel(const bf16_t* __restrict__ ah, const float* __restrict__ srow,
+                                                           const int64_t* __restrict__ labels, int V, float* __restrict__ dE, int rows,
+                                                           int d) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const long long lab = labels[r];
+  const float sr = srow[r];
+  if (lab < 0 || lab >= V || sr == 0.f) return;
+  for (int i = lane; i < d; i += 64)   // one wave instruction = 256 contiguous bytes of the row (the atomics' full-rate shape)
+    atomicAdd(dE + (size_t)lab * d + i, -sr * bf2f(ah[(size_t)r * d + i]));
+}
+
 }  // namespace
+
+hipError_t kmb_ce_label_logit_launch(const bf16_t* H, int ldh, const bf16_t* E, int lde, const float* bias, const int64_t* labels,
+                                     int rows, int d, int V, float* shift, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if ((d & 7) || (ldh & 7) || (lde & 7)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ce_label_logit_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, H, ldh, E, lde, bias, labels, rows, d, V, shift);
+  return hipGetLastError();
+}
+hipError_t kmb_ce_pad_bias_launch(const float* bias, int V, int Vpad, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(ce_pad_bias_kernel, dim3((Vpad + 255) / 256), dim3(256), 0, stream, bias, V, Vpad, out);
+  return hipGetLastError();
+}
+hipError_t kmb_ce_rows_finish_launch(const float* row_sums, int ld_sums, int nparts, const float* pick, const int64_t* labels,
+                                     const int32_t* count, float lm_factor, int rows, int d, int V, const bf16_t* H, int ldh,
+                                     float* loss_rows, float* srow, float* alpha, bf16_t* ah, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if ((d & 7) || (ldh & 7)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ce_rows_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, row_sums, ld_sums, nparts, pick, labels, count,
+                     lm_factor, rows, d, V, H, ldh, loss_rows, srow, alpha, ah);
+  return hipGetLastError();
+}
+hipError_t kmb_ce_dgrad_finish_launch(const float* slab, int nslabs, size_t stride, const float* alpha, const float* srow,
+                                      const int64_t* labels, const bf16_t* E, int lde, int V, bf16_t* out, int rows, int d,
+                                      hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if ((d & 7) || (lde & 7) || (stride & 3)) return hipErrorInvalidValue;
+  const size_t chunks = (size_t)rows * (d >> 3);
+  hipLaunchKernelGGL(ce_dgrad_finish_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, slab, nslabs, stride, alpha,
+                     srow, labels, E, lde, V, out, rows, d);
+  return hipGetLastError();
+}
+hipError_t kmb_ce_wgrad_fix_launch(const bf16_t* ah, const float* srow, const int64_t* labels, int V, float* dE, int rows, int d,
+                                   hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if (d & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ce_wgrad_fix_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ah, srow, labels, V, dE, rows, d);
+  return hipGetLastError();
+}
 
 hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, hipStream_t stream) {
   hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, stream, labels, n, count);

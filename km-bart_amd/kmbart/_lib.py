@@ -47,7 +47,8 @@ class KmbGemm(C.Structure):
                 ("act", i32), ("preact", c_p), ("ld_preact", i32), ("aux", c_p), ("ld_aux", i32),
                 ("drop_thr16", u32), ("drop_seed", u32), ("drop_scale", f32), ("residual", c_p), ("ld_res", i32),
                 ("out_bf16", c_p), ("ld_out_bf16", i32), ("out_f32", c_p), ("ld_out_f32", i32), ("beta", f32),
-                ("split_k", i32), ("slab", c_p), ("colsum", c_p), ("tile_order", i32)]
+                ("split_k", i32), ("slab", c_p), ("colsum", c_p), ("tile_order", i32),
+                ("row_shift", c_p), ("row_sums", c_p), ("row_sums_ld", i32), ("pick_col", c_p), ("pick_out", c_p)]
 
 
 class KmbAttn(C.Structure):

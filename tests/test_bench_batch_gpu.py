@@ -140,3 +140,34 @@ def test_chunk_zero_against_the_oracle(setup):
     loss.backward()
     torch.cuda.synchronize()
     check_grads(model, {k: v.grad for k, v in osd.items() if v.grad is not None}, "vcg_base ragged b=64")
+
+
+@pytest.mark.parametrize("bsz", [64, 512])
+def test_cross_entropy_fused_into_the_head_gemm_vs_the_two_kernel_path(setup, bsz):
+    """The tied head's loss two ways (engine.cpp forward_impl): the head GEMM's epilogue storing exp(logit - label logit)
+    plus row sums (no pass over the logits), against bf16 logits + the softmax kernel (KMB_FUSED_CE=0).  Same mathematics
+    (reference src/model/model.py:398-402), other roundings: the probabilities are bf16 of exp(v - c) instead of bf16 of
+    the scaled difference, the per-row factor multiplies H (bf16) for the weight gradient and the fp32 sum for dH."""
+    model, _, _ = setup
+    eng = model._engine
+    b = _ragged_batch(bsz, seed=77 + bsz)
+    d = _dev(b)
+    os.environ["KMB_FUSED_CE"] = "0"
+    try:
+        loss_two, g_two = _fwd_bwd(model, d)
+    finally:
+        os.environ.pop("KMB_FUSED_CE", None)
+    loss_fused, g_fused = _fwd_bwd(model, d)
+    loss_fused2, g_fused2 = _fwd_bwd(model, d)
+    print(f"[b={bsz}] loss fused {loss_fused:.6f} vs two-kernel {loss_two:.6f}")
+    assert abs(loss_fused - loss_two) <= 2e-4 * abs(loss_two)
+    errs = _per_param_err(eng, g_fused, g_two.double())
+    print("worst gradient differences:", errs[:6])
+    worst = max(e for e, nr, name in errs if "k_proj.bias" not in name)
+    assert worst < 1.5e-2, errs[:6]
+    # deterministic apart from the tied matrix's fp32 atomics
+    off, rows, cols = eng.index["model.shared.weight"]
+    same = g_fused == g_fused2
+    same[off: off + rows * cols] = True
+    assert bool(same.all()) and loss_fused == loss_fused2
+    assert torch.allclose(g_fused[off: off + rows * cols], g_fused2[off: off + rows * cols], rtol=0, atol=1e-5)
