@@ -2174,8 +2174,14 @@ hipError_t launch_config(const KmbGemm& p, int cfg, hipStream_t stream) {
     }
   }
   if (p.split_k > 1) {
-    static int so = -2;   // KMB_GEMM_SPLIT_ORDER = 0 | 1: force the slice-minor / slice-major enumeration (A/B measurements)
-    if (so == -2) { const char* e = getenv("KMB_GEMM_SPLIT_ORDER"); so = e ? atoi(e) : -1; }
+    // Split-K launches: per-XCD contiguous ranges + slice-major enumeration ALWAYS (bits 0 and 2), like the persistent rule
+    // above and for the same reason -- the tuner's back-to-back timing cannot tell the orders apart, the L2s can: with
+    // the round-robin order the 12 column tiles that share a 768-row operand slice sit on eight XCDs (fc2's weight
+    // gradient 768 x 3072 x 65536: 1544 MB fetched for 503 MB of operands, its transpose 3072 x 768 with the other order
+    // 628; profiles/r03_gemm_traffic_by_shape_b1024.txt).  In-step: b = 1024 neutral, b = 256 -0.4...-1.3 %
+    // (profiles/r03_ab_split_order_instep.txt).  KMB_GEMM_SPLIT_ORDER = 0 | 2: force slice-minor / leave the tuner's pick.
+    static int so = -2;
+    if (so == -2) { const char* e = getenv("KMB_GEMM_SPLIT_ORDER"); so = e ? atoi(e) : 1; }
     if (so == 0) q.tile_order &= ~4;
     else if (so == 1) q.tile_order |= 5;
   }
