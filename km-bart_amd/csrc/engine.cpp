@@ -1143,10 +1143,11 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       g.row_shift = h->ce_shift; g.row_sums = h->logits_c; g.row_sums_ld = nparts; g.pick_col = bt.labels; g.pick_out = h->ce_pick;
       KCHK(run_gemm(g, s));
       HIPCHK(kmb_ce_rows_finish_launch(h->logits_c, nparts, nparts, h->ce_pick, bt.labels, h->count, lmf, Md, d, h->V, hdec, d,
-                                       h->loss_rows, h->ce_srow, h->ce_alpha, need_grad ? h->ce_ah : nullptr, s));
+                                       h->loss_rows, h->ce_srow, h->ce_alpha, need_grad ? h->ce_ah : nullptr,
+                                       need_grad ? h->dlogits_c : nullptr, h->Vpad, s));
       if (need_grad) {
-        // dH_r = a_r (sum_j P_rj E_j - S_r E[label_r]): the GEMM on P into fp32 slabs (the row sums in that buffer were consumed
-        // by the launch above), then the finish
+        // dH_r = a_r sum_j P'_rj E_j: the GEMM on P' into fp32 slabs (the row sums in that buffer were consumed by the launch
+        // above), then the finish
         KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, Md, h->Vpad, d);
         const int tiles256 = ((Md + 255) / 256) * ((d + 255) / 256);
         static const int rounds = getenv("KMB_HEAD_DGRAD_ROUNDS") ? atoi(getenv("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
@@ -1159,14 +1160,11 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
           S = 1; gd.out_f32 = h->logits_c; gd.ld_out_f32 = d;
         }
         KCHK(run_gemm(gd, s));
-        HIPCHK(kmb_ce_dgrad_finish_launch(h->logits_c, S, (size_t)Md * d, h->ce_alpha, h->ce_srow, bt.labels, Eb, d, h->V, h->dhdec,
-                                          Md, d, s));
-        // dE = P^T (a . H) - scatter_r(S_r (a . H)_r -> row label_r), on the side stream like the two-kernel path's
+        HIPCHK(kmb_ce_dgrad_finish_launch(h->logits_c, S, (size_t)Md * d, h->ce_alpha, h->dhdec, Md, d, s));
+        // dE = P'^T (a . H), on the side stream like the two-kernel path's
         KCHK(ensure_side(h));
         KCHK(wgrad_side(h, lin_wgrad(h->dlogits_c, h->Vpad, h->ce_ah, d, h->gf(h->shared), Md, h->V, d, 0.f), s));
-        const bool on_side = h->side_on && h->side;
-        HIPCHK(kmb_ce_wgrad_fix_launch(h->ce_ah, h->ce_srow, bt.labels, h->V, h->gf(h->shared), Md, d, on_side ? h->side : s));
-        if (on_side) {
+        if (h->side_on && h->side) {
           HIPCHK(hipEventRecord(h->head_wgrad_done, h->side));
           h->head_wgrad_pending = true;
         }

@@ -88,14 +88,13 @@ hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, 
 hipError_t kmb_ce_label_logit_launch(const bf16_t* H, int ldh, const bf16_t* E, int lde, const float* bias, const int64_t* labels,
                                      int rows, int d, int V, float* shift, hipStream_t stream);
 hipError_t kmb_ce_pad_bias_launch(const float* bias, int V, int Vpad, float* out, hipStream_t stream);
+// S_r, loss_r, a_r = lm_factor / (count S_r), ah = a . H (bf16, may be null), and P[r][label_r] := exp(pick_r) - S_r (P may be null)
 hipError_t kmb_ce_rows_finish_launch(const float* row_sums, int ld_sums, int nparts, const float* pick, const int64_t* labels,
                                      const int32_t* count, float lm_factor, int rows, int d, int V, const bf16_t* H, int ldh,
-                                     float* loss_rows, float* srow, float* alpha, bf16_t* ah, hipStream_t stream);
-hipError_t kmb_ce_dgrad_finish_launch(const float* slab, int nslabs, size_t stride, const float* alpha, const float* srow,
-                                      const int64_t* labels, const bf16_t* E, int lde, int V, bf16_t* out, int rows, int d,
+                                     float* loss_rows, float* srow, float* alpha, bf16_t* ah, bf16_t* P, int ldp, hipStream_t stream);
+// out[r] = bf16(alpha[r] * sum_s slab[s][r])
+hipError_t kmb_ce_dgrad_finish_launch(const float* slab, int nslabs, size_t stride, const float* alpha, bf16_t* out, int rows, int d,
                                       hipStream_t stream);
-hipError_t kmb_ce_wgrad_fix_launch(const bf16_t* ah, const float* srow, const int64_t* labels, int V, float* dE, int rows, int d,
-                                   hipStream_t stream);
 // per row: loss_rows[r] = lse - logit[label] (0 if ignored); dlogits (bf16, ld = ldv, pad columns zeroed)
 //          = (softmax - onehot) * grad_scale / count   (0 rows if ignored).  dlogits may be null.
 hipError_t kmb_ce_launch(const float* logits, int ldv, int V, const int64_t* labels, int rows,

@@ -45,16 +45,31 @@ __device__ __forceinline__ void row_lse(const float* __restrict__ row, int V, fl
   m_out = m; s_out = s;
 }
 
-__global__ __launch_bounds__(256) void count_valid_kernel(const int64_t* __restrict__ labels, int n,
-                                                          int32_t* __restrict__ count) {
-  __shared__ int sh[4];
+// one workgroup of 1024 threads, eight independent loads in flight per thread (a 256-thread loop of dependent loads took
+// 54 us for the 32768 labels of the benchmark batch)
+__global__ __launch_bounds__(1024) void count_valid_kernel(const int64_t* __restrict__ labels, int n,
+                                                           int32_t* __restrict__ count) {
+  __shared__ int sh[16];
   int c = 0;
-  for (int i = threadIdx.x; i < n; i += 256) c += (labels[i] != -100) ? 1 : 0;
+  int i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {
+    int64_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = labels[i + k * 1024];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c += (v[k] != -100) ? 1 : 0;
+  }
+  for (; i < n; i += 1024) c += (labels[i] != -100) ? 1 : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
   __syncthreads();
-  if (threadIdx.x == 0) count[0] = sh[0] + sh[1] + sh[2] + sh[3];
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k];
+    count[0] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, int ldv, int V,
@@ -178,18 +193,28 @@ __global__ __launch_bounds__(1024) void ce_kernel_reg(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ loss_rows, int rows,
-                                                          const int32_t* __restrict__ count, float* __restrict__ loss) {
-  __shared__ float sh[4];
+__global__ __launch_bounds__(1024) void loss_finish_kernel(const float* __restrict__ loss_rows, int rows,
+                                                           const int32_t* __restrict__ count, float* __restrict__ loss) {
+  __shared__ float sh[16];
   float a = 0.f;
-  for (int i = threadIdx.x; i < rows; i += 256) a += loss_rows[i];
+  int i = threadIdx.x;
+  for (; i + 7 * 1024 < rows; i += 8 * 1024) {   // eight independent loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = loss_rows[i + k * 1024];
+    a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; i < rows; i += 1024) a += loss_rows[i];
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
   __syncthreads();
   if (threadIdx.x == 0) {
     const int n = count[0];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k];
     // torch CrossEntropyLoss(mean) over zero valid targets is NaN
-    loss[0] = n > 0 ? (sh[0] + sh[1] + sh[2] + sh[3]) / (float)n : __uint_as_float(0x7fc00000u);
+    loss[0] = n > 0 ? t / (float)n : __uint_as_float(0x7fc00000u);
   }
 }
 
@@ -718,13 +743,15 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
 // leaves the fp32 row sums S_r = sum_j P[r][j] (per 64-column block) and d_r = v_r[label] - c_r.  Then
 //   loss_r = log S_r - d_r,      softmax_rj = P[r][j] / S_r,
 //   dlogits_rj = g (P[r][j] / S_r - [j == label_r]),          g = lm_factor / (number of valid rows)
-// is never materialised: with a_r = g / S_r
-//   dH_r  = a_r * (sum_j P[r][j] E_j  -  S_r E[label_r])            (the data-gradient GEMM runs on P, this is its finish)
-//   dE    = P^T (a . H)  -  scatter_r ( S_r * (a . H)_r  -> row label_r )   (the weight-gradient GEMM runs on P and a . H)
+// is never materialised: the row finish replaces the label's entry by P'[r][label_r] = P[r][label_r] - S_r (one bf16
+// element per row: the difference rounded once, the relative error the two-kernel path's bf16 gradient row has there), and
+// with a_r = g / S_r
+//   dH_r  = a_r * sum_j P'[r][j] E_j            (the data-gradient GEMM runs on P', its slab finish applies a_r)
+//   dE    = P'^T (a . H)                        (the weight-gradient GEMM runs on P' and the row-scaled copy a . H)
 // so the 2 x 3.3 GB read-modify-write of ce_kernel_reg_bf16 (1.76 ms of a b = 1024 step) disappears; P is stored at
 // 8 significant bits relative to the probability itself (the two-kernel path rounds the LOGIT to 8 bits: 3-6 % on p).
-// Both corrections use the same rounded a . H that the GEMM reads, so the label row's net term (1 - S_r) keeps its
-// relative precision.
+// (A first version kept P intact and corrected both products afterwards -- S_r E[label_r] in the finish and an atomic
+// scatter of S_r (a . H)_r into dE: 115 us of fp32 atomics per b = 1024 step for the same precision.)
 
 // c_r = h_r . E[label_r] + bias[label_r]   (ignored rows: column 0, only to keep their exps finite); one wave per row
 __global__ __launch_bounds__(256) void ce_label_logit_kernel(const bf16_t* __restrict__ H, int ldh, const bf16_t* __restrict__ E,
@@ -755,13 +782,16 @@ __global__ __launch_bounds__(256) void ce_pad_bias_kernel(const float* __restric
   if (i < Vpad) out[i] = i < V ? bias[i] : -1e30f;
 }
 
-// per row: S_r, loss_r, a_r and the row-scaled copy a . H (bf16); one wave per row
+// per row: S_r, loss_r, a_r, the row-scaled copy a . H (bf16), and the label's entry of the stored matrix turned into
+// P[r, label_r] - S_r (so that a_r P'[r, :] IS the softmax gradient row and both gradient GEMMs need no correction term;
+// the entry is exp(pick_r) ~ 1 against S_r >= 1: one bf16 rounding of the difference, the same relative error the bf16
+// gradient row of the two-kernel path carries at the label); one wave per row
 __global__ __launch_bounds__(256) void ce_rows_finish_kernel(const float* __restrict__ row_sums, int ld_sums, int nparts,
                                                              const float* __restrict__ pick, const int64_t* __restrict__ labels,
                                                              const int32_t* __restrict__ count, float lm_factor, int rows, int d, int V,
                                                              const bf16_t* __restrict__ H, int ldh, float* __restrict__ loss_rows,
                                                              float* __restrict__ srow, float* __restrict__ alpha,
-                                                             bf16_t* __restrict__ ah) {
+                                                             bf16_t* __restrict__ ah, bf16_t* __restrict__ P, int ldp) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= rows) return;
   const long long lab = labels[r];
@@ -775,6 +805,7 @@ __global__ __launch_bounds__(256) void ce_rows_finish_kernel(const float* __rest
     loss_rows[r] = valid ? __logf(s) - pick[r] : 0.f;
     srow[r] = valid ? s : 0.f;
     alpha[r] = a;
+    if (valid && P != nullptr) P[(size_t)r * ldp + lab] = f2bf(__expf(pick[r]) - s);
   }
   if (ah != nullptr) {
     for (int i = lane * 8; i < d; i += 512) {
@@ -787,11 +818,9 @@ __global__ __launch_bounds__(256) void ce_rows_finish_kernel(const float* __rest
   }
 }
 
-// dH_r = a_r * (sum_s slab[s][r] - S_r E[label_r]);  8 columns per thread
+// dH_r = a_r * sum_s slab[s][r]  (the label's correction is inside the matrix the GEMM multiplied);  8 columns per thread
 __global__ __launch_bounds__(256) void ce_dgrad_finish_kernel(const float* __restrict__ slab, int nslabs, size_t stride,
-                                                              const float* __restrict__ alpha, const float* __restrict__ srow,
-                                                              const int64_t* __restrict__ labels, const bf16_t* __restrict__ E, int lde,
-                                                              int V, bf16_t* __restrict__ out, int rows, int d) {
+                                                              const float* __restrict__ alpha, bf16_t* __restrict__ out, int rows, int d) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // chunk of 8 columns
   const int per_row = d >> 3;
   const int r = (int)(idx / per_row);
@@ -805,31 +834,10 @@ __global__ __launch_bounds__(256) void ce_dgrad_finish_kernel(const float* __res
       const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + s * stride + (size_t)r * d + c + 4);
       v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3]; v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
     }
-    const long long lab = labels[r];
-    if (lab >= 0 && lab < V) {
-      float e[8];
-      unpack8(*reinterpret_cast<const u32x4*>(E + (size_t)lab * lde + c), e);
-      const float sr = srow[r];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] -= sr * e[k];
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= a;
   }
   *reinterpret_cast<u32x4*>(out + (size_t)r * d + c) = pack8(v);
-}
-
-// dE[label_r] -= S_r * (a . H)_r   (fp32 atomics: several rows may name the same token; like the embedding scatter-adds)
-__global__ __launch_bounds__(256) void ce_wgrad_fix_kernel(const bf16_t* __restrict__ ah, const float* __restrict__ srow,
-                                                           const int64_t* __restrict__ labels, int V, float* __restrict__ dE, int rows,
-                                                           int d) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (r >= rows) return;
-  const long long lab = labels[r];
-  const float sr = srow[r];
-  if (lab < 0 || lab >= V || sr == 0.f) return;
-  for (int i = lane; i < d; i += 64)   // one wave instruction = 256 contiguous bytes of the row (the atomics' full-rate shape)
-    atomicAdd(dE + (size_t)lab * d + i, -sr * bf2f(ah[(size_t)r * d + i]));
 }
 
 }  // namespace
@@ -847,33 +855,25 @@ hipError_t kmb_ce_pad_bias_launch(const float* bias, int V, int Vpad, float* out
 }
 hipError_t kmb_ce_rows_finish_launch(const float* row_sums, int ld_sums, int nparts, const float* pick, const int64_t* labels,
                                      const int32_t* count, float lm_factor, int rows, int d, int V, const bf16_t* H, int ldh,
-                                     float* loss_rows, float* srow, float* alpha, bf16_t* ah, hipStream_t stream) {
+                                     float* loss_rows, float* srow, float* alpha, bf16_t* ah, bf16_t* P, int ldp, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
   if ((d & 7) || (ldh & 7)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ce_rows_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, row_sums, ld_sums, nparts, pick, labels, count,
-                     lm_factor, rows, d, V, H, ldh, loss_rows, srow, alpha, ah);
+                     lm_factor, rows, d, V, H, ldh, loss_rows, srow, alpha, ah, P, ldp);
   return hipGetLastError();
 }
-hipError_t kmb_ce_dgrad_finish_launch(const float* slab, int nslabs, size_t stride, const float* alpha, const float* srow,
-                                      const int64_t* labels, const bf16_t* E, int lde, int V, bf16_t* out, int rows, int d,
+hipError_t kmb_ce_dgrad_finish_launch(const float* slab, int nslabs, size_t stride, const float* alpha, bf16_t* out, int rows, int d,
                                       hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
-  if ((d & 7) || (lde & 7) || (stride & 3)) return hipErrorInvalidValue;
+  if ((d & 7) || (stride & 3)) return hipErrorInvalidValue;
   const size_t chunks = (size_t)rows * (d >> 3);
   hipLaunchKernelGGL(ce_dgrad_finish_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, slab, nslabs, stride, alpha,
-                     srow, labels, E, lde, V, out, rows, d);
-  return hipGetLastError();
-}
-hipError_t kmb_ce_wgrad_fix_launch(const bf16_t* ah, const float* srow, const int64_t* labels, int V, float* dE, int rows, int d,
-                                   hipStream_t stream) {
-  if (rows <= 0) return hipSuccess;
-  if (d & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ce_wgrad_fix_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ah, srow, labels, V, dE, rows, d);
+                     out, rows, d);
   return hipGetLastError();
 }
 
 hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, hipStream_t stream) {
-  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, stream, labels, n, count);
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, stream, labels, n, count);
   return hipGetLastError();
 }
 
@@ -901,7 +901,7 @@ hipError_t kmb_ce_bf16_launch(const bf16_t* logits, int ldv, int V, const int64_
 
 hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
                                   hipStream_t stream) {
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, stream, loss_rows, rows, count, loss);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, stream, loss_rows, rows, count, loss);
   return hipGetLastError();
 }
 
