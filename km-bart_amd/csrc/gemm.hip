@@ -1165,8 +1165,10 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
           v[e] = v[e] - c2;
           if ((long long)(gcol + 2 * e) == label) { picked = v[e][0]; has = true; }
           if ((long long)(gcol + 2 * e + 1) == label) { picked = v[e][1]; has = true; }
+          // 2^115 bounds a stored value and a 50k-column row sum inside fp32 / bf16: a logit more than 80 above the label's (a
+          // row whose loss exceeds 80 nats) saturates instead of turning the row's sum, loss and gradients into inf / NaN
           const kmb_f32x2 t = v[e] * 1.4426950408889634f;
-          v[e] = kmb_f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+          v[e] = kmb_f32x2{__builtin_amdgcn_exp2f(fminf(t[0], 115.f)), __builtin_amdgcn_exp2f(fminf(t[1], 115.f))};
         }
         if (has) p.pick_out[grow] = picked;
         float sum = (v[0][0] + v[0][1]) + (v[1][0] + v[1][1]) + ((v[2][0] + v[2][1]) + (v[3][0] + v[3][1]));

@@ -70,6 +70,27 @@ def test_exp_epilogue_against_torch(M, N, K):
         assert ("sha " + mine) in r.stdout, (variant, mine, r.stdout[-300:])
 
 
+def test_exp_epilogue_saturates_instead_of_overflowing():
+    """A row whose logits exceed the shift by more than 80 (a label the model gives probability e^-80) stores 2^115 and a
+    finite row sum; every other row is untouched."""
+    from gpu_util import gemm
+    M, N, K = 1024, 8192, 768
+    A, B, bias, labels, shift, v = _case(M, N, K, seed=11)
+    shift2 = shift.clone()
+    shift2[5] -= 300.0
+    P = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    sums = torch.empty((M, N // 64), device=DEV)
+    pick = torch.zeros((M,), device=DEV)
+    gemm(A, B, bias=bias, act=5, out_bf16=P, row_shift=shift2, row_sums=sums, pick_col=labels, pick_out=pick)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(P.float()).all()) and bool(torch.isfinite(sums).all())
+    assert float(P[5, : N - 37].float().min()) == 2.0 ** 115
+    ref = torch.exp(v - shift[:, None])
+    keep = torch.ones(M, dtype=torch.bool, device=DEV)
+    keep[5] = False
+    assert ((P.float() - ref).abs() / (ref.abs() + 1e-6))[keep].max().item() < 6e-3
+
+
 def test_exp_epilogue_rejects_shapes_it_cannot_run():
     from gpu_util import gemm
     A, B, bias, labels, shift, _ = _case(1024, 8192, 768, seed=3)
