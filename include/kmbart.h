@@ -216,6 +216,10 @@ int kmb_backward_dev(kmb_handle* h, const float* loss_scale_dev, void* stream);
 int kmb_adamw_step(kmb_handle* h, const KmbAdamW* hp, int64_t offset, int64_t count, void* stream);
 /* status word written by device-side input validation (bit 0: #<img_feat> ids != #region rows) */
 int kmb_read_status(kmb_handle* h, int32_t* status_host, void* stream);
+/* The same without the synchronisation: the status word is copied to `status_host` (page-locked memory) in stream order; the
+ * caller reads it after a later synchronisation of that stream (generation: at the end of generate(), so that the decode
+ * steps are enqueued while the encoder still runs). */
+int kmb_read_status_async(kmb_handle* h, int32_t* status_host, void* stream);
 
 /* ---- multi-task pre-training (MultiModalBartForPreTraining.forward, src/model/model.py:162-309) ----
  * rows index the flattened decoder positions [B*T]; every pointer is a device pointer; n_* may be 0 */

@@ -1023,6 +1023,12 @@ int kmb_read_status(kmb_handle* h, int32_t* status_host, void* stream) {
   return 0;
 }
 
+int kmb_read_status_async(kmb_handle* h, int32_t* status_host, void* stream) {
+  if (!h->status) return fail("kmb_read_status_async: no forward has run");
+  HIPCHK(hipMemcpyAsync(status_host, h->status, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+
 // --------------------------------------------------------------------------------- forward
 // the tied LM head on rows [0, Md) of hdec: fp32 logits [Md, Vpad] (src/model/model.py:397)
 static int head_logits(kmb_handle* h, const bf16_t* hdec, int Md, float* logits_out, hipStream_t s) {

@@ -270,6 +270,26 @@ class Engine:
             raise RuntimeError("number of <img_feat>/<cls> ids differs from the number of region features "
                                "(reference src/model/modules.py:98-100 would raise a shape mismatch)")
 
+    def check_inputs_begin(self):
+        """check_inputs without the wait: the status word is copied to page-locked memory in stream order; the caller
+        calls check_inputs_end() after its next synchronisation of the stream."""
+        st = self.pinned((1,), torch.int32)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_read_status_async(self.h, ptr(st), _stream()))
+            ev = torch.cuda.Event()
+            ev.record()
+        self._status_pending = (st, ev)
+
+    def check_inputs_end(self):
+        pend = self.__dict__.pop("_status_pending", None)
+        if pend is None:
+            return
+        st, ev = pend
+        ev.synchronize()
+        if int(st[0]) & 1:
+            raise RuntimeError("number of <img_feat>/<cls> ids differs from the number of region features "
+                               "(reference src/model/modules.py:98-100 would raise a shape mismatch)")
+
     def backward(self, loss_scale=1.0):
         """loss_scale: a Python float, or a 1-element fp32 device tensor (autograd's upstream gradient: no host sync)."""
         with torch.cuda.device(self.device):

@@ -402,7 +402,12 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         V = cfg.vocab_size
         R = B * num_beams
         eng.gen_begin(input_ids, image_features, attention_mask, num_beams, max_length)
-        eng.check_inputs()
+        # the device-side input validation is read back without waiting (the decode steps are enqueued while the encoder
+        # still runs); a flagged batch raises at the first point where the host waits for the device anyway
+        if os.environ.get("KMB_GEN_SYNC_CHECK") == "1":   # A/B knob: wait for the encoder before the first decode step
+            eng.check_inputs()
+        else:
+            eng.check_inputs_begin()
         cur_len = 1
 
         if num_beams == 1:
@@ -437,7 +442,9 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                             keep = pending[0]
                             break
                     pending = (cur_len, ev)
-            return torch.stack(cols[:keep] if keep is not None else cols, dim=1)
+            out = torch.stack(cols[:keep] if keep is not None else cols, dim=1)
+            eng.check_inputs_end()
+            return out
 
         # Host bookkeeping on plain Python lists: indexing small CPU tensors element by element (as the reference does)
         # costs ~10 us per access and made a beam step 6x longer than its GPU work.
@@ -489,13 +496,16 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             # one decode step that is thrown away.  A `done` batch item keeps decoding on the device (the reference feeds
             # it pad tokens); its rows feed nothing that is read.
             staging = eng.pinned((max_length, B, k, 2), torch.int32)
-            beam_scores_dev = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
+            beam_scores_dev = torch.full((B, num_beams), -1e9, dtype=torch.float32, device=dev)   # = beam_scores, built on the device
+            beam_scores_dev[:, 0] = 0.0
+            beam_scores_dev = beam_scores_dev.view(-1)
             pending = None
 
             def replay(item):
                 nonlocal beam_scores, seqs
                 slot, ev, step_len = item
                 ev.synchronize()
+                eng.check_inputs_end()
                 c = staging[slot]
                 ns = c[:, :, 0].contiguous().view(torch.float32).tolist()
                 nt = c[:, :, 1].tolist()
@@ -582,13 +592,14 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 lens.append(len(hyp))
         if min(lens) != max(lens):
             L = min(max(lens) + 1, max_length)
-            out = torch.full((len(best), L), pad_token_id, dtype=torch.long)
-            for i, hyp in enumerate(best):
-                out[i, : lens[i]] = torch.tensor(hyp, dtype=torch.long)
-                if lens[i] < max_length:
-                    out[i, lens[i]] = eos_token_id
+            rows = []
+            for hyp, n in zip(best, lens):   # hypothesis, EOS behind it if it stopped early, pads (one tensor build, not one per row)
+                row = list(hyp) + ([eos_token_id] if n < max_length else [])
+                rows.append(row + [pad_token_id] * (L - len(row)))
+            out = torch.tensor(rows, dtype=torch.long)
         else:
             out = torch.tensor(best, dtype=torch.long)
+        eng.check_inputs_end()
         out = out.to(dev)
         return (out, torch.tensor(best_scores)) if return_scores else out
 
