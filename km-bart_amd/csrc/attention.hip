@@ -171,6 +171,138 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const KmbAttn p) {
   }
 }
 
+// ------------------------------------------ forward, single-tile shapes (Tq <= 64 and Tk <= 64: every training shape)
+// attn_fwd_kernel runs one (batch, head) item per workgroup: load -> barrier -> QK^T -> softmax -> PV -> store, four workgroups
+// per CU and nothing in flight while an item is computed (3.5 / 2.5 / 3.2 TB/s of algorithmic bytes on the encoder self /
+// decoder self / cross shapes at b = 1024).  Here a workgroup is persistent over items like attn_bwd_small_kernel: the global
+// loads of item i+1 (Q, K, V: six 16-byte chunks per thread, in registers) are issued before item i is computed and written
+// to LDS after it.  Same arithmetic, operation for operation, as one key tile of attn_fwd_kernel (whose online-softmax
+// rescale is exp(-inf - m) = 0 on the first tile): identical bits.  Waves without query rows (Tq = 32: waves 2, 3) only
+// stage.
+struct FwdRegs { u32x4 q[2], k[2], v[2]; };
+
+__device__ __forceinline__ void fwd_load_item(const KmbAttn& p, int item, int tid, FwdRegs& x) {
+  const int b = item / p.H, h = item % p.H;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id >> 3, c = id & 7;
+    const int tq = row < p.Tq ? row : p.Tq - 1, tk = row < p.Tk ? row : p.Tk - 1;
+    // rows 32 .. 63 (i = 1) of a tile that holds at most 32 rows are never fetched: their LDS rows stay zero
+    if (i == 0 || p.Tq > 32) x.q[i] = *reinterpret_cast<const u32x4*>(p.Q + ((size_t)b * p.Tq + tq) * p.ldq + h * HD + c * 8);
+    if (i == 0 || p.Tk > 32) {
+      x.k[i] = *reinterpret_cast<const u32x4*>(p.K + ((size_t)b * p.Tk + tk) * p.ldk + h * HD + c * 8);
+      x.v[i] = *reinterpret_cast<const u32x4*>(p.V + ((size_t)b * p.Tk + tk) * p.ldv + h * HD + c * 8);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES + 4 * 2048];
+  char* Qs = smem;
+  char* Ks = smem + TILE_BYTES;
+  char* Vs = smem + 2 * TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  char* Ps = smem + 3 * TILE_BYTES + wave * 2048;
+  const int nitems = p.B * p.H;
+  const int q0 = wave * 16;
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  FwdRegs x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {   // (masked keys multiply a probability of exactly 0: their rows must be finite, not just ignored)
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    x.q[i] = z; x.k[i] = z; x.v[i] = z;
+  }
+  fwd_load_item(p, item, tid, x);
+  for (; item < nitems; item += gridDim.x) {
+    const int b = item / p.H, h = item % p.H;
+    __syncthreads();   // everyone is done with the previous item's LDS images
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // (the never-fetched halves are rewritten with their zeros: LDS stores are not the limit)
+      const int id = tid + 256 * i;
+      const int row = id >> 3, c = id & 7;
+      *reinterpret_cast<u32x4*>(Qs + tile_off(row, c)) = x.q[i];
+      *reinterpret_cast<u32x4*>(Ks + tile_off(row, c)) = x.k[i];
+      *reinterpret_cast<u32x4*>(Vs + tile_off(row, c)) = x.v[i];
+    }
+    __syncthreads();
+    const int nxt = item + (int)gridDim.x;   // the next item's loads go out now and land while this one is computed
+    if (nxt < nitems) fwd_load_item(p, nxt, tid, x);
+    if (q0 >= p.Tq) continue;   // wave-uniform: this wave has no query rows (both barriers are at the loop head)
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 qf = frag_rows(Qs, wave, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, frag_rows(Ks, j, kk, r, g), s[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = j * 16 + r;
+      bool kv = key < p.Tk;
+      if (kv && p.key_mask != nullptr) kv = p.key_mask[(size_t)b * p.Tk + key] != 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int qi = q0 + g * 4 + q;
+        const bool ok = kv && (!p.causal || key <= qi);
+        s[j][q] = ok ? s[j][q] : -INFINITY;
+      }
+    }
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float mx = fmaxf(fmaxf(s[0][q], s[1][q]), fmaxf(s[2][q], s[3][q]));
+      mx = group16_max(mx);
+      float lsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = (mx == -INFINITY) ? 0.f : __expf(s[j][q] - mx);
+        s[j][q] = pv;
+        lsum += pv;
+      }
+      l_run[q] = lsum;
+      m_run[q] = mx;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<bf16_t*>(Ps + elem_off(g * 4 + q, j * 16 + r)) = f2bf(s[j][q]);
+    // Ps is this wave's own: its LDS operations execute in order, a wave-level fence keeps the compiler from moving the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 pf = frag_rows(Ps, 0, kk, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_cols(Vs, j, kk, r, g), o[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float l = group16_sum(l_run[q]);
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      const int qi = q0 + g * 4 + q;
+      if (qi < p.Tq) {
+        bf16_t* orow = p.O + ((size_t)b * p.Tq + qi) * p.ldo + h * HD;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow[j * 16 + r] = f2bf(o[j][q] * inv);
+        if (r == 0 && p.lse != nullptr)
+          p.lse[((size_t)b * p.H + h) * p.Tq + qi] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------- backward
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -610,6 +742,12 @@ const char* kmb_attn_check(const KmbAttn& p, int backward) {
 }
 
 hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
+  static const bool small_ok = !(getenv("KMB_ATTN_FWD_SMALL") && getenv("KMB_ATTN_FWD_SMALL")[0] == '0');
+  if (small_ok && p.Tq <= 64 && p.Tk <= 64 && p.B * p.H >= 1024) {   // one query tile, one key tile, enough items to pipeline
+    const int items = p.B * p.H;
+    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(items < 1024 ? items : 1024), dim3(256), 0, stream, p);   // four workgroups per CU
+    return hipGetLastError();
+  }
   dim3 grid(p.B * p.H, (p.Tq + 63) / 64), block(256);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, p);
   return hipGetLastError();

@@ -222,6 +222,45 @@ def test_attention_fwd_bwd(case):
     assert rel_err(dKV[:, d:], rows(vf.grad, Tk)) < 2e-2
 
 
+@pytest.mark.parametrize("Tq,Tk,causal,fused", [(64, 64, False, True), (32, 32, True, True), (32, 64, False, False), (20, 50, False, False)])
+def test_attention_fwd_persistent_single_tile(Tq, Tk, causal, fused):
+    """>= 1024 (batch, head) items of one query tile x one key tile run attn_fwd_small_kernel (persistent workgroups, the next
+    item's loads in flight); the same items in batches of < 1024 run attn_fwd_kernel: same arithmetic, operation for operation,
+    so the outputs and log-sum-exps must be IDENTICAL, and both match fp32 torch."""
+    B, H = 160, 12          # 1920 items; ragged key masks
+    d = H * 64
+    lib = _lib.load()
+    if fused:
+        qkv = bf(rnd(B * Tq, 3 * d, seed=30, scale=0.7))
+        Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    else:
+        Q = bf(rnd(B * Tq, d, seed=31, scale=0.7))
+        kv = bf(rnd(B * Tk, 2 * d, seed=32, scale=0.7))
+        K, V = kv[:, :d], kv[:, d:]
+    key_mask = torch.ones((B, Tk), dtype=torch.int64, device=DEV)
+    for b in range(B):
+        key_mask[b, Tk - (b % (Tk - 1)):] = 0 if b % 3 else 1
+    O = torch.full((B * Tq, d), 7.0, dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((B, H, Tq), 7.0, dtype=torch.float32, device=DEV)
+    a = attn_struct(Q, K, V, B, H, Tq, Tk, key_mask, causal, O, lse)
+    check(lib.kmb_op_attn_fwd(C.byref(a), stream()))
+    O2 = torch.full_like(O, 3.0)
+    lse2 = torch.full_like(lse, 3.0)
+    step = 40               # 480 items per call: the one-item-per-workgroup kernel
+    for b0 in range(0, B, step):
+        sl_q, sl_k = slice(b0 * Tq, (b0 + step) * Tq), slice(b0 * Tk, (b0 + step) * Tk)
+        a2 = attn_struct(Q[sl_q], K[sl_k], V[sl_k], step, H, Tq, Tk, key_mask[b0: b0 + step], causal, O2[sl_q], lse2[b0: b0 + step])
+        check(lib.kmb_op_attn_fwd(C.byref(a2), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(O, O2) and torch.equal(lse, lse2)
+
+    def heads(x, T):
+        return x.float().reshape(B, T, H, 64).transpose(1, 2)
+
+    ref = ref_attention(heads(Q, Tq), heads(K, Tk), heads(V, Tk), key_mask, causal)
+    assert rel_err(O, ref.transpose(1, 2).reshape(B * Tq, d)) < 1e-2
+
+
 def test_attention_decode():
     lib = _lib.load()
     R, H, Tk, Tmax = 6, 2, 37, 48
