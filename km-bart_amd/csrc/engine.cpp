@@ -1146,9 +1146,9 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       HIPCHK(kmb_ce_pad_bias_launch(h->flb, h->V, h->Vpad, h->ce_bias, s));
       KmbGemm g = lin_fwd(hdec, d, Eb, h->ce_bias, Md, h->Vpad, d);
       g.act = 5; g.out_bf16 = h->dlogits_c; g.ld_out_bf16 = h->Vpad;
-      g.row_shift = h->ce_shift; g.row_sums = h->logits_c; g.row_sums_ld = nparts; g.pick_col = bt.labels; g.pick_out = h->ce_pick;
+      g.row_shift = h->ce_shift; g.row_sums = h->logits_c; g.row_sums_ld = nparts; g.pick_col = nullptr; g.pick_out = nullptr;   // the shift is the label's logit itself: v[label] - shift = 0 up to summation order
       KCHK(run_gemm(g, s));
-      HIPCHK(kmb_ce_rows_finish_launch(h->logits_c, nparts, nparts, h->ce_pick, bt.labels, h->count, lmf, Md, d, h->V, hdec, d,
+      HIPCHK(kmb_ce_rows_finish_launch(h->logits_c, nparts, nparts, nullptr, bt.labels, h->count, lmf, Md, d, h->V, hdec, d,
                                        h->loss_rows, h->ce_srow, h->ce_alpha, need_grad ? h->ce_ah : nullptr,
                                        need_grad ? h->dlogits_c : nullptr, h->Vpad, s));
       if (need_grad) {

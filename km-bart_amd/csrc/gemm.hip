@@ -1109,6 +1109,17 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
       s1[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 + RPI * it) * ld_side);
     }
   }
+  // act 5: the rows' shifts, loaded like the side operand two chunks ahead of their use (a load at the point of use exposed
+  // its latency in every row-iteration: the head's forward GEMM 2.24 -> 3.19 ms)
+  float h0[NIT], h1[NIT], h2[NIT];
+  const float* shift_base = ACT == 5 ? p.row_shift + row0w + lr : nullptr;
+  if constexpr (ACT == 5) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      h0[it] = shift_base[RPI * it];
+      h1[it] = shift_base[16 + RPI * it];
+    }
+  }
   auto stage_chunk = [&](int i) {
     switch (i) {   // static accumulator indices in every arm (a run-time index would put acc in scratch)
       case 0: stage(acc[0]); break;
@@ -1139,6 +1150,11 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 #pragma unroll
       for (int it = 0; it < NIT; ++it) s2[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 * ahead + RPI * it) * ld_side);
     }
+    if constexpr (ACT == 5) {
+      const int ahead = i + 2 < WROWS / 16 ? i + 2 : WROWS / 16 - 1;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) h2[it] = shift_base[16 * ahead + RPI * it];
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const f32x4 lo = lo4[it];
@@ -1155,22 +1171,29 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
         // shifted value at the label's column go to the side buffers (see KmbGemm)
         static_assert(ACT != 5 || WCOLS == 64 || WCOLS == 128, "act 5: 64- or 128-column wave blocks");
         const int grow = row0w + lr + 16 * i + RPI * it;
-        const float c = p.row_shift[grow];
-        const long long label = p.pick_col != nullptr ? (long long)p.pick_col[grow] : -1ll;
+        const float c = h0[it];
         const kmb_f32x2 c2 = {c, c};
-        float picked = 0.f;
-        bool has = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] - c2;
+        if (p.pick_col != nullptr) {   // uniform; optional (the engine does without: the shift IS the label's logit)
+          const int rel = (int)((long long)p.pick_col[grow] - (long long)gcol);   // the label's column relative to this lane's eight
+          if (rel >= 0 && rel < 8) {
+            float picked = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (rel == 2 * e) picked = v[e][0];
+              if (rel == 2 * e + 1) picked = v[e][1];
+            }
+            p.pick_out[grow] = picked;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = v[e] - c2;
-          if ((long long)(gcol + 2 * e) == label) { picked = v[e][0]; has = true; }
-          if ((long long)(gcol + 2 * e + 1) == label) { picked = v[e][1]; has = true; }
           // 2^115 bounds a stored value and a 50k-column row sum inside fp32 / bf16: a logit more than 80 above the label's (a
           // row whose loss exceeds 80 nats) saturates instead of turning the row's sum, loss and gradients into inf / NaN
           const kmb_f32x2 t = v[e] * 1.4426950408889634f;
           v[e] = kmb_f32x2{__builtin_amdgcn_exp2f(fminf(t[0], 115.f)), __builtin_amdgcn_exp2f(fminf(t[1], 115.f))};
         }
-        if (has) p.pick_out[grow] = picked;
         float sum = (v[0][0] + v[0][1]) + (v[1][0] + v[1][1]) + ((v[2][0] + v[2][1]) + (v[3][0] + v[3][1]));
 #pragma unroll
         for (int o = 1; o < CL; o <<= 1) sum += __shfl_xor(sum, o);   // the CL column-lanes of a row are consecutive lanes
@@ -1236,6 +1259,10 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
     if (SIDE) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) { s0[it] = s1[it]; s1[it] = s2[it]; }
+    }
+    if constexpr (ACT == 5) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { h0[it] = h1[it]; h1[it] = h2[it]; }
     }
   }
   if (CS) {

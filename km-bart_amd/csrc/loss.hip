@@ -802,10 +802,11 @@ __global__ __launch_bounds__(256) void ce_rows_finish_kernel(const float* __rest
   const int n = count[0];
   const float a = (valid && n > 0 && s > 0.f) ? lm_factor / ((float)n * s) : 0.f;
   if (lane == 0) {
-    loss_rows[r] = valid ? __logf(s) - pick[r] : 0.f;
+    const float pk = pick != nullptr ? pick[r] : 0.f;   // v_r[label] - c_r: 0 up to summation order when c_r is the label's logit
+    loss_rows[r] = valid ? __logf(s) - pk : 0.f;
     srow[r] = valid ? s : 0.f;
     alpha[r] = a;
-    if (valid && P != nullptr) P[(size_t)r * ldp + lab] = f2bf(__expf(pick[r]) - s);
+    if (valid && P != nullptr) P[(size_t)r * ldp + lab] = f2bf(__expf(pk) - s);
   }
   if (ah != nullptr) {
     for (int i = lane * 8; i < d; i += 512) {
