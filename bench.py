@@ -113,6 +113,7 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
     lib.kmb_set_side_stream(model._engine.h, 0)  # kernels timed one at a time, not overlapped with each other
     step()
     alg_bytes, alg_n = 0.0, 0
+    ce_us, ce_fl, last_us, last_fl = 0.0, 0.0, 0.0, 0.0   # the launch whose epilogue carries the cross-entropy (act 5), last profiled step
     for i in range(n_prof):
         lib.kmb_profile_gemm(1)
         step()
@@ -134,6 +135,11 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
                 extra = M * N * 2 if act in (1, 2) else 0                # GeLU' written / read beside the output
                 alg_bytes += 2.0 * (M * K + N * K) + out_b * M * N + extra
                 alg_n += 1
+                last_us += float(us)
+                last_fl += 2.0 * M * N * K
+                if act == 5:
+                    ce_us += float(us)
+                    ce_fl += 2.0 * M * N * K
             os.remove(dump)
         lib.kmb_profile_gemm(0)
     lib.kmb_set_side_stream(model._engine.h, 1)
@@ -158,6 +164,11 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
         "per_gpu_batch": per_gpu_batch,
         "launches_per_step": launches // n_prof, "avg_launch_us": round(tot_ms / launches * 1e3, 2),
         "gemm_ms_per_step": round(tot_ms / n_prof, 3),
+        # round 3: the tied head's forward GEMM also computes the cross-entropy's exponentials and row sums in its epilogue (the
+        # 1.76 ms softmax kernel of round 2 is gone); its time counts as GEMM time here.  For comparisons across rounds:
+        "ce_head_launch": ({"us": round(ce_us, 1), "tflops": round(ce_fl / ce_us * 1e-6, 1),
+                            "frac_of_other_launches": round((last_fl - ce_fl) / (last_us - ce_us) * 1e-6 / PEAK_BF16_TFLOPS, 4)}
+                           if ce_us > 0 and last_us > ce_us else None),
         "by_variant": {k: {"launches_per_step": a[0] // n_prof, "avg_us": round(a[1] / max(a[0], 1) * 1e3, 2),
                            "tflops": round(a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None}
                        for k, a in agg.items()},
