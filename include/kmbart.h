@@ -285,6 +285,9 @@ int kmb_profile_dump(const char* path);   /* one text line per profiled GEMM lau
 
 /* ================= single operators (unit tests / profiling) ================= */
 int kmb_op_gemm(const KmbGemm* p, void* stream);
+/* the same product on the "all rows" kernel (one workgroup per 256 output columns holds every row: M <= 320, forward layout, bias
+ * only, fp32 output): what a generation decode step's vocabulary projection runs; bit-identical to kmb_op_gemm */
+int kmb_op_gemm_allrows(const KmbGemm* p, void* stream);
 int kmb_op_attn_fwd(const KmbAttn* p, void* stream);
 int kmb_op_attn_bwd(const KmbAttn* p, void* stream);
 int kmb_op_attn_decode(const KmbAttnDecode* p, void* stream);

@@ -25,6 +25,12 @@ int kmb_op_gemm(const KmbGemm* p, void* stream) {
   if (why) return kmb_set_error(why);
   return hipfail(kmb_gemm_launch(*p, (hipStream_t)stream), "gemm");
 }
+int kmb_op_gemm_allrows(const KmbGemm* p, void* stream) {
+  const char* why = kmb_gemm_check(*p);
+  if (!why) why = kmb_gemm_allrows_check(*p);
+  if (why) return kmb_set_error(why);
+  return hipfail(kmb_gemm_allrows_launch(*p, (hipStream_t)stream), "gemm_allrows");
+}
 int kmb_op_attn_fwd(const KmbAttn* p, void* stream) {
   const char* why = kmb_attn_check(*p, 0);
   if (why) return kmb_set_error(why);

@@ -1031,6 +1031,19 @@ int kmb_read_status_async(kmb_handle* h, int32_t* status_host, void* stream) {
 
 // --------------------------------------------------------------------------------- forward
 // the tied LM head on rows [0, Md) of hdec: fp32 logits [Md, Vpad] (src/model/model.py:397)
+// The vocabulary projection with fp32 logits.  A decode step's rows (batch x beams = 257 .. 320: the benchmarked 64 x 5): one
+// workgroup per 256 vocabulary columns holds ALL rows, so every row of the tied matrix crosses a CU's memory pipe once
+// (gemm.hip "All rows" kernel: 58 -> 47 us at 320 rows, tools/allrows_time.py; at <= 192 rows the 128x128 tiles already read
+// the matrix once or twice and are faster: 31 against 39 us).  Bit-identical either way; KMB_GEMM_ALLROWS=0: always the tuner's pick.
+static int run_vocab_gemm(const KmbGemm& g, hipStream_t s) {
+  static const bool allrows_ok = !(getenv("KMB_GEMM_ALLROWS") && getenv("KMB_GEMM_ALLROWS")[0] == '0');
+  if (allrows_ok && !g_f32 && g.M > 256 && g.M <= 320 && kmb_gemm_allrows_check(g) == nullptr) {
+    HIPCHK(kmb_gemm_allrows_launch(g, s));
+    return 0;
+  }
+  return run_gemm(g, s);
+}
+
 static int head_logits(kmb_handle* h, const bf16_t* hdec, int Md, float* logits_out, hipStream_t s) {
   const int d = h->d;
   const int CH = Md < h->lm_chunk ? Md : h->lm_chunk;
@@ -1038,7 +1051,7 @@ static int head_logits(kmb_handle* h, const bf16_t* hdec, int Md, float* logits_
     const int rows = (Md - r0) < CH ? (Md - r0) : CH;
     KmbGemm g = lin_fwd(EP(hdec, (size_t)r0 * d), d, h->wb(h->shared), h->flb, rows, h->V, d);
     g.out_f32 = logits_out + (size_t)r0 * h->Vpad; g.ld_out_f32 = h->Vpad;
-    KCHK(run_gemm(g, s));
+    KCHK(run_vocab_gemm(g, s));
   }
   return 0;
 }
@@ -1819,7 +1832,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
   if (logits_out) {
     KmbGemm g = lin_fwd(x, d, h->wb(h->shared), h->flb, R, h->V, d);
     g.out_f32 = logits_out; g.ld_out_f32 = h->Vpad;
-    KCHK(run_gemm(g, s));
+    KCHK(run_vocab_gemm(g, s));
   }
   return 0;
 }

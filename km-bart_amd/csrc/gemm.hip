@@ -949,6 +949,97 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 
 
 // ------------------------------------------------------------------------------------------
+// "All rows" kernel: the vocabulary projection of a generation decode step (R = batch x beams <= 320 rows, N = 50320, K = 768,
+// forward layout, fp32 logits).  The 128x128 kernel re-reads the R activation rows for each of 394 column tiles and the tied
+// matrix for each of 3 row tiles: 463 MB through the CUs' memory pipes for 141 MB of operands, and that pipe (~50 GB/s per CU),
+// not the MFMAs, is what a decode-sized GEMM waits for (51-71 us inside a step).  Here ONE workgroup holds all rows: tile =
+// 320 rows x 256 columns, eight waves 2 x 4 of 160 x 64 (10 x 4 MFMA tiles, 160 accumulator registers), two 72 KB LDS stages
+// filled by LDS-DMA (same K-contiguous images and swizzle as the other kernels), 197 workgroups = one round, each weight row
+// read exactly once: 174 MB.  The K loop is deliberately plain (wait, barrier, 80 MFMAs, barrier, next fetch): 72 KB per K
+// step arrive in ~1.4 us, the MFMAs take 0.5.  Same MFMA, same k order, fp32 bias add: bit-identical to every other variant.
+// Rows past M are clamped copies of the last row (computed, never stored).
+constexpr int VR = 320, VN = 256;
+constexpr int V_A = VR * BK * 2;                  // 40 KB
+constexpr int V_STG = (VR + VN) * BK * 2;         // 72 KB
+constexpr int LDS_VOC = 2 * V_STG;                // 144 KB
+
+__global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, g = lane >> 4;
+  const int col0 = (int)blockIdx.x * VN;
+  f32x4 acc[10][4];
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nt = p.K / BK;
+  uint32_t offA[5], offB[4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {   // 40 pieces of 8 rows x 128 bytes: five per wave
+    const int row = (wave * 5 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int grow = row < p.M ? row : p.M - 1;
+    offA[i] = (uint32_t)((grow * p.lda + c * 8) * 2);
+  }
+  dma_offsets256<true>(offB, p.ldb, col0, p.N, wave, lane);
+  auto uniform_ptr = [](const char* ptr) {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  const char* const gA = reinterpret_cast<const char*>(p.A);
+  const char* const gB = reinterpret_cast<const char*>(p.B) + (size_t)col0 * p.ldb * 2;
+  auto dma_stage = [&](int ks, int buf) {
+    char* st = smem + buf * V_STG;
+    const char* ga = uniform_ptr(gA + (size_t)ks * BK * 2);
+    const char* gb = uniform_ptr(gB + (size_t)ks * BK * 2);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma_piece(ga, offA[i], st + (wave * 5 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(gb, offB[i], st + V_A + (wave * 4 + i) * 1024);
+  };
+  dma_stage(0, 0);
+  if (nt > 1) dma_stage(1, 1);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) __builtin_amdgcn_s_waitcnt(0x0F79);   // vmcnt(9): all but the newer stage's nine pieces have landed
+    else __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+    __syncthreads();
+    const char* cur = smem + (t & 1) * V_STG;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag3<true, VN>(cur + V_A, wn * 4 + j, kk, r, g);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const bf16x8 fa = read_frag3<true, VR>(cur, wm * 10 + i, kk, r, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);   // C^T tile
+      }
+    }
+    __syncthreads();   // everyone is done reading this buffer
+    if (t + 2 < nt) dma_stage(t + 2, t & 1);
+  }
+  // transposed accumulators: lane (r, g) holds C[16 i + r][16 j + 4 g .. + 3] -> one 16-byte store per tile and lane
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = col0 + wn * 64 + j * 16 + g * 4;
+    if (col >= p.N) continue;   // N % 4 == 0 (launcher): a group of four columns is inside or outside
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int row = wm * 160 + i * 16 + r;
+      if (row < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * p.ld_out_f32 + col) = acc[i][j] + b4;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // v11: persistent 256x256 tile.  One workgroup per CU (grid = 256), four waves (2x2), each wave a 128x128 block of C
 // (8x8 MFMA tiles, 256 accumulator registers -- the whole AGPR file; one wave per SIMD).  Why:
 //   * LDS bandwidth.  v8's 128x64 wave block reads 24 fragments per 64 MFMAs: 192 KB of ds_reads + 64 KB of LDS-DMA
@@ -2253,6 +2344,30 @@ hipEvent_t refine_event() {
 }
 
 }  // namespace
+
+// The all-rows kernel (gemm_kernel_allrows): nullptr if `p` can run on it.  Plain forward GEMM with fp32 output only.
+const char* kmb_gemm_allrows_check(const KmbGemm& p) {
+  if (!p.a_kc || !p.b_kc) return "all-rows GEMM: forward layout only";
+  if (p.M <= 0 || p.M > VR) return "all-rows GEMM: at most 320 rows";
+  if ((p.K % BK) || p.K < BK || (p.N & 3) || p.N <= 0) return "all-rows GEMM: K % 64 == 0, N % 4 == 0";
+  if (p.act != 0 || p.residual || p.drop_thr16 || p.colsum || p.split_k > 1 || p.preact || p.aux || p.col_scale_n > 0 || p.beta != 0.f)
+    return "all-rows GEMM: plain epilogue (bias) only";
+  if (!p.out_f32 || p.out_bf16 || (p.ld_out_f32 & 3) || ((uintptr_t)p.out_f32 & 15) || (p.bias && ((uintptr_t)p.bias & 15)))
+    return "all-rows GEMM: fp32 output, 16-byte aligned";
+  if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return "all-rows GEMM: operand alignment";
+  return nullptr;
+}
+
+hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_allrows, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_VOC);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_kernel_allrows, dim3((p.N + VN - 1) / VN), dim3(512), LDS_VOC, stream, p);
+  return hipGetLastError();
+}
 
 // Every variant computes bit-identical results (same per-element accumulation order), so the choice is pure
 // speed: the first launch of a new shape times the eligible variants on the real operands (measure, don't guess).

@@ -10,6 +10,9 @@ typedef uint16_t bf16_t;
 // ------------------------------------------------------------------ gemm.hip
 const char* kmb_gemm_check(const KmbGemm& p);
 hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream);
+// the "all rows" kernel for decode-sized forward GEMMs (<= 320 rows, fp32 output, bias only): bit-identical to kmb_gemm_launch
+const char* kmb_gemm_allrows_check(const KmbGemm& p);
+hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream);
 void kmb_gemm_set_shared_device(int on);   // persistent variants: hand out every tile dynamically
 
 // ------------------------------------------------------------- attention.hip

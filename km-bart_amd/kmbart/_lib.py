@@ -130,6 +130,7 @@ PROTOTYPES = {
     "kmb_profile_read": (C.c_int, [C.c_int, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
     "kmb_profile_dump": (C.c_int, [C.c_char_p]),
     "kmb_op_gemm": (C.c_int, [C.POINTER(KmbGemm), c_p]),
+    "kmb_op_gemm_allrows": (C.c_int, [C.POINTER(KmbGemm), c_p]),
     "kmb_op_attn_fwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_bwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_decode": (C.c_int, [C.POINTER(KmbAttnDecode), c_p]),

@@ -20,7 +20,8 @@ def bf(x):
 
 def gemm(A, B, a_kc=True, b_kc=True, M=None, N=None, K=None, bias=None, col_scale=1.0, col_scale_n=0, act=0,
          preact=None, aux=None, drop_p=0.0, drop_seed=0, residual=None, out_bf16=None, out_f32=None, beta=0.0,
-         split_k=0, slab=None, colsum=None, tile_order=None, row_shift=None, row_sums=None, pick_col=None, pick_out=None):
+         split_k=0, slab=None, colsum=None, tile_order=None, row_shift=None, row_sums=None, pick_col=None, pick_out=None,
+         allrows=False):
     """A, B are bf16 2-D tensors in their STORAGE layout; M/N/K default from the shapes."""
     lib = _lib.load()
     if M is None:
@@ -58,7 +59,7 @@ def gemm(A, B, a_kc=True, b_kc=True, M=None, N=None, K=None, bias=None, col_scal
         g.row_shift, g.row_sums, g.row_sums_ld = ptr(row_shift), ptr(row_sums), row_sums.stride(0)
         g.pick_col, g.pick_out = ptr(pick_col), ptr(pick_out)
     g.tile_order = int(os.environ.get("KMB_TILE_ORDER", "0"), 0) if tile_order is None else tile_order
-    check(lib.kmb_op_gemm(C.byref(g), stream()))
+    check((lib.kmb_op_gemm_allrows if allrows else lib.kmb_op_gemm)(C.byref(g), stream()))
 
 
 def attn_struct(Q, K, V, B, H, Tq, Tk, key_mask, causal, O, lse):

@@ -592,3 +592,25 @@ def test_beam_merge_select_picks_the_beams_the_host_bookkeeping_sends_on():
             got = list(zip(ns[b * nb:(b + 1) * nb].tolist(), nt[b * nb:(b + 1) * nb].tolist(), ni[b * nb:(b + 1) * nb].tolist()))
             for (ws, wt, wi), (gs, gt, gi) in zip(want, got):
                 assert (wt, wi) == (gt, gi) and (ws == gs or (ws != ws and gs != gs))
+
+
+@pytest.mark.parametrize("M,N,K", [(320, 50320, 768), (160, 50320, 768), (129, 1000, 128), (300, 4100, 64), (1, 512, 192)])
+def test_gemm_all_rows_kernel_is_bit_identical(M, N, K):
+    """The vocabulary projection of a decode step (R = batch x beams <= 320 rows) runs gemm_kernel_allrows: one workgroup per
+    256 columns holds every row.  Same MFMA, same k order, same fp32 bias add as the tiled kernels: identical bits; columns
+    past N and the output's padding stay untouched."""
+    A = bf(rnd(M, K, seed=40, scale=0.5))
+    Bm = bf(rnd(N, K, seed=41, scale=0.5))
+    bias = rnd(N, seed=42)
+    ld = ((N + 127) // 128) * 128
+    out1 = torch.full((M, ld), 7.0, dtype=torch.float32, device=DEV)
+    out2 = torch.full((M, ld), 7.0, dtype=torch.float32, device=DEV)
+    gemm(A, Bm, bias=bias, out_f32=out1)
+    gemm(A, Bm, bias=bias, out_f32=out2, allrows=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2)
+    assert bool((out2[:, N:] == 7.0).all())
+    ref = A.float() @ Bm.float().t() + bias
+    assert rel_err(out2[:, :N], ref) < 1e-5
+    with pytest.raises(RuntimeError):      # more rows than one workgroup holds
+        gemm(bf(rnd(321, K, seed=43)), Bm, bias=bias, out_f32=torch.empty((321, ld), device=DEV), allrows=True)
