@@ -325,7 +325,9 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
     gap = float((sc.float() - ref_sc.float()).abs().max())
     diff_gap = float((sc.float() - ref_sc.float())[~same_row.cpu()].abs().max()) if rows_equal < out.shape[0] else 0.0
     same_gap = float((sc.float() - ref_sc.float())[same_row.cpu()].abs().max()) if rows_equal else 0.0
-    gen_ok = bool(out.shape[0] == ref_ids.shape[0] and rows_equal >= 0.9 * out.shape[0])
+    # every differing row must be a near-tie (its two winners' scores within 2e-2), and at least 90 % of the rows identical
+    gen_ok = bool(out.shape[0] == ref_ids.shape[0] and rows_equal >= 0.9 * out.shape[0] and
+                  (rows_equal == out.shape[0] or diff_gap <= 2e-2))
     if not gen_ok:
         print("[bench] GENERATION CHECK FAILED: fused decode blocks disagree with the launch-per-operation path (%d/%d rows "
               "identical, score gap of differing rows %.3e)" % (rows_equal, out.shape[0], diff_gap), file=sys.stderr, flush=True)
@@ -536,7 +538,7 @@ def main():
         sweep[str(args.batch)] = {"tokens_per_sec": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 3)}
         out["batch_sweep"] = sweep
         out["legs"] = sweep   # the same objects: b = 64 / 256 / 512 / 1024 get their GEMM roofline below
-        # (3) the measured batch computes what its 64-sample chunks compute (raises otherwise)
+        # (3) the measured batch computes what its 64-sample chunks compute (reported in `bench_batch_check.ok`, folded into `self_checks_ok`)
         out["bench_batch_check"] = bench_batch_check(model, dev, args.batch)
         model.train()
         # (4) BASELINE config 5: generation

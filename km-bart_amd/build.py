@@ -88,8 +88,11 @@ def build_variant(name, defines, sources=("gemm.hip",)):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:   # python build.py --variant plain KMB_PLAIN_STORES
+    if "--variant" in sys.argv:   # python build.py --variant plain KMB_PLAIN_STORES | --variant diag KMB_DIAG
         i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        defs = sys.argv[i + 2:]
+        # KMB_DIAG (csrc/diag.h) switches the A/B environment knobs and ablation bits on in every file that has them
+        srcs = ("gemm.hip", "engine.cpp", "attention.hip") if "KMB_DIAG" in defs else ("gemm.hip",)
+        print(build_variant(sys.argv[i + 1], defs, srcs))
     else:
         build(force="--force" in sys.argv)

@@ -13,6 +13,7 @@
 // transposed reads (ds_read_b64_tr_b16); the XOR swizzle below makes both conflict-free.
 #include <cstdlib>
 #include "common.h"
+#include "diag.h"
 #include "kernels.h"
 
 namespace {
@@ -742,7 +743,7 @@ const char* kmb_attn_check(const KmbAttn& p, int backward) {
 }
 
 hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
-  static const bool small_ok = !(getenv("KMB_ATTN_FWD_SMALL") && getenv("KMB_ATTN_FWD_SMALL")[0] == '0');
+  static const bool small_ok = !(KMB_DIAG_ENV("KMB_ATTN_FWD_SMALL") && KMB_DIAG_ENV("KMB_ATTN_FWD_SMALL")[0] == '0');
   if (small_ok && p.Tq <= 64 && p.Tk <= 64 && p.B * p.H >= 1024) {   // one query tile, one key tile, enough items to pipeline
     const int items = p.B * p.H;
     hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(items < 1024 ? items : 1024), dim3(256), 0, stream, p);   // four workgroups per CU
@@ -755,7 +756,7 @@ hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
 
 hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream) {
   const int nqt = (p.Tq + 63) / 64;
-  static const bool small_ok = !(getenv("KMB_ATTN_BWD_SMALL") && getenv("KMB_ATTN_BWD_SMALL")[0] == '0');
+  static const bool small_ok = !(KMB_DIAG_ENV("KMB_ATTN_BWD_SMALL") && KMB_DIAG_ENV("KMB_ATTN_BWD_SMALL")[0] == '0');
   if (small_ok && p.Tq <= 64 && p.Tk <= 64) {   // one query tile, one key tile: the persistent, software-pipelined form
     const size_t lds_s = 6 * TILE_BYTES + (128 + 768) * sizeof(float);
     static bool attr_set = false;

@@ -102,7 +102,7 @@ int kmb_op_pos_bwd(const kmb_bf16* dz, int B, int S, int D, float* dP, int pos_b
 int kmb_op_ce(const float* logits, int ldv, int V, const int64_t* labels, int rows, float grad_scale,
               float* loss_rows, kmb_bf16* dlogits, int32_t* count, float* loss, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  int rc = hipfail(kmb_count_valid_launch(labels, rows, count, s), "count_valid");
+  int rc = hipfail(kmb_count_valid_launch(labels, rows, V, count, nullptr, s), "count_valid");
   if (rc) return rc;
   rc = hipfail(kmb_ce_launch(logits, ldv, V, labels, rows, count, grad_scale, loss_rows, dlogits, s), "ce");
   if (rc) return rc;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "diag.h"
 
 namespace {
 
@@ -57,6 +58,12 @@ thread_local bool g_f32 = false;
 thread_local float* g_small_slab = nullptr;
 thread_local size_t g_small_floats = 0;
 inline size_t esz() { return g_f32 ? 4 : 2; }
+// KMB_FP32_HEAD=1: fp32 logits + the register-resident fp32 cross-entropy in the bf16 product mode as well.  Read ONCE and
+// used by the workspace layout and by the forward pass alike (the logits buffer is sized for whichever head runs).
+inline bool force_fp32_head() {
+  static const bool on = getenv("KMB_FP32_HEAD") != nullptr && getenv("KMB_FP32_HEAD")[0] == '1';
+  return on;
+}
 template <typename T> inline T* EP(T* p, size_t n) { return (T*)((char*)p + n * esz()); }
 
 struct ParamInfo { std::string name; size_t off; int rows, cols; };
@@ -259,7 +266,7 @@ int run_gemm(const KmbGemm& g, hipStream_t s) {
       !g.out_f32 && g.out_bf16 && g.beta == 0.f && (g.N & 7) == 0 && (g.K % 64) == 0 && g.M > 512) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     const int nt = g.K / 64;
-    static const int small_fill = getenv("KMB_SMALL_FILL") ? atoi(getenv("KMB_SMALL_FILL")) : 512;   // A/B knob
+    static const int small_fill = KMB_DIAG_ENV("KMB_SMALL_FILL") ? atoi(KMB_DIAG_ENV("KMB_SMALL_FILL")) : 512;   // A/B knob
     int S = tiles > 0 ? small_fill / tiles : 1;
     if (S > 8) S = 8;
     if (S > nt / 4) S = nt / 4;
@@ -326,7 +333,7 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_
   // costs more than the fuller grid buys, and the caller's stream keeps the other CUs busy anyway: whole step, same box
   // (tools/step_ab_seq.sh): b = 64 7.52 ms with 256 against 7.78 with 512 (384: 7.67, 192: 7.60), b = 128 10.51 with 384
   // against 10.80 (256: 10.95), b = 32 5.99 with 256 against 6.17, b = 256 16.7 with 512 against 18.3 with 256.
-  static const int fill_env = getenv("KMB_WGRAD_FILL") ? atoi(getenv("KMB_WGRAD_FILL")) : 0;   // A/B knob
+  static const int fill_env = KMB_DIAG_ENV("KMB_WGRAD_FILL") ? atoi(KMB_DIAG_ENV("KMB_WGRAD_FILL")) : 0;   // A/B knob
   const int mmax = h->Me > h->Md ? h->Me : h->Md;   // tokens of the longer side: how busy the caller's stream keeps the chip
   const int fill = fill_env > 0 ? fill_env : mmax <= 4096 ? 256 : mmax <= 8192 ? 384 : 512;
   int S = fill / tiles;   // floor: a partial last round costs more than it fills
@@ -383,7 +390,7 @@ int ensure_side(kmb_handle* h) {
     // picks the side stream's queue priority (experiment knob; default: the device's default priority).
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const char* pr = getenv("KMB_SIDE_PRIORITY");
+    const char* pr = KMB_DIAG_ENV("KMB_SIDE_PRIORITY");
     if (pr && (pr[0] == 'l' || pr[0] == 'h'))
       HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest));
     else
@@ -408,7 +415,7 @@ int wgrad_side(kmb_handle* h, const KmbGemm& g, hipStream_t sA) {
   KCHK(run_wgrad(h, g, h->side, h->slab, h->slab_floats));
   // KMB_SIDE_SERIALIZE=1 (diagnostic): the caller's stream waits for every weight gradient -- the side stream's
   // launches stay where they are, nothing overlaps (run-to-run reproducibility)
-  static const bool serialize = getenv("KMB_SIDE_SERIALIZE") != nullptr;
+  static const bool serialize = KMB_DIAG_ENV("KMB_SIDE_SERIALIZE") != nullptr;
   if (serialize) {
     hipEvent_t e2 = h->next_event();
     HIPCHK(hipEventRecord(e2, h->side));
@@ -426,7 +433,7 @@ bool g_trace_on = false;
 int g_trace_layer = -1;
 int trace(const char* name, const void* p, size_t bytes, hipStream_t s) {
   if (!g_trace_on) return 0;
-  static const char* only = getenv("KMB_BWD_TRACE_ONLY");   // substring filter: fewer probes disturb the timing less
+  static const char* only = KMB_DIAG_ENV("KMB_BWD_TRACE_ONLY");   // substring filter: fewer probes disturb the timing less
   if (only && !strstr(name, only)) return 0;
   if (!g_trace_dev) HIPCHK(hipMalloc(&g_trace_dev, 4096 * sizeof(unsigned long long)));
   if (g_trace.size() >= 4096) return 0;
@@ -445,7 +452,7 @@ int trace(const char* name, const void* p, size_t bytes, hipStream_t s) {
 // with the reducers on the caller's stream; b = 256 16.50 / 16.55 against 16.21 / 16.39 -- the other way round (short
 // backward: the extra events cost more than the reducers) -- so only long batches take this path.
 hipStream_t reducer_stream(kmb_handle* h, hipStream_t sA) {
-  static const char* env = getenv("KMB_REDUCERS_ON_MAIN");   // "1": never on the side stream, "0": always (A/B knob)
+  static const char* env = KMB_DIAG_ENV("KMB_REDUCERS_ON_MAIN");   // "1": never on the side stream, "0": always (A/B knob)
   const bool want = env ? env[0] == '0' : (h->Me > h->Md ? h->Me : h->Md) >= 16384;
   if (!want || !h->side_on || h->side == nullptr) return sA;
   hipEvent_t e = h->next_event();
@@ -544,7 +551,7 @@ size_t layout_train(kmb_handle* h, char* base, size_t cap, int B, int S, int T, 
   // kernel); logits_c only holds the split-K slabs of the head's data gradient (<= 8 x Md x d floats).  The fp32
   // validation mode keeps fp32 logits here, in row chunks of lm_chunk.
   const size_t CH = Md < (size_t)h->lm_chunk ? Md : (size_t)h->lm_chunk;
-  const size_t lc_floats = (g_f32 || h->Vpad > 65536) ? CH * h->Vpad : (size_t)8 * Md * d;
+  const size_t lc_floats = (g_f32 || h->Vpad > 65536 || force_fp32_head()) ? std::max(CH * h->Vpad, (size_t)8 * Md * d) : (size_t)8 * Md * d;
   float* logits_c = bp.take<float>(lc_floats);
   bf16_t* dlogits_c = bp.act(Md * h->Vpad);   // all rows: the head's dgrad / wgrad run once, un-chunked
   // split-K partial slabs of the weight-gradient GEMMs: 14 slices of a 768x768 matrix ... 3 of the tied V x d matrix
@@ -782,7 +789,7 @@ int head_run(kmb_handle* h, int k, const bf16_t* hdec, int n, const int32_t* row
     HIPCHK(kmb_kl_div_launch(h->hlg, Cpad, C, soft_targets, C, n, factor, h->hloss, need_grad ? h->hdlg : nullptr, Cpad, s));
     HIPCHK(kmb_mean_rows_launch(h->hloss, n, factor, (float)n, loss_out, s));
   } else {             // CrossEntropyLoss()(pred, labels) * factor
-    HIPCHK(kmb_count_valid_launch(labels, n, h->count + 1, s));
+    HIPCHK(kmb_count_valid_launch(labels, n, C, h->count + 1, h->status, s));
     HIPCHK(kmb_ce_launch(h->hlg, Cpad, C, labels, n, h->count + 1, factor, h->hloss, need_grad ? h->hdlg : nullptr, s));
     HIPCHK(kmb_mean_rows_launch(h->hloss, n, factor, (float)n, loss_out, s));
   }
@@ -939,7 +946,7 @@ int kmb_create(const kmb_config* cfg, kmb_handle** out) {
       (void)hipGetLastError();
     }
   }
-  const char* ch = getenv("KMB_LM_CHUNK");
+  const char* ch = KMB_DIAG_ENV("KMB_LM_CHUNK");
   if (ch && atoi(ch) > 0) h->lm_chunk = atoi(ch);
   *out = h;
   return 0;
@@ -1036,7 +1043,7 @@ int kmb_read_status_async(kmb_handle* h, int32_t* status_host, void* stream) {
 // (gemm.hip "All rows" kernel: 58 -> 47 us at 320 rows, tools/allrows_time.py; at <= 192 rows the 128x128 tiles already read
 // the matrix once or twice and are faster: 31 against 39 us).  Bit-identical either way; KMB_GEMM_ALLROWS=0: always the tuner's pick.
 static int run_vocab_gemm(const KmbGemm& g, hipStream_t s) {
-  static const bool allrows_ok = !(getenv("KMB_GEMM_ALLROWS") && getenv("KMB_GEMM_ALLROWS")[0] == '0');
+  static const bool allrows_ok = !(KMB_DIAG_ENV("KMB_GEMM_ALLROWS") && KMB_DIAG_ENV("KMB_GEMM_ALLROWS")[0] == '0');
   if (allrows_ok && !g_f32 && g.M > 256 && g.M <= 320 && kmb_gemm_allrows_check(g) == nullptr) {
     HIPCHK(kmb_gemm_allrows_launch(g, s));
     return 0;
@@ -1132,7 +1139,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   // ---- tied LM head + CE (src/model/model.py:397-403), in row chunks of lm_chunk (8192) rows: one launch at the
   // benchmark batch.  Smaller chunks (KMB_LM_CHUNK) keep the fp32 logits on-die but quantise the tile count worse:
   // 512-row chunks measured 0.8 % slower end to end.
-  if (bt.labels) HIPCHK(kmb_count_valid_launch(bt.labels, Md, h->count, s));
+  if (bt.labels) HIPCHK(kmb_count_valid_launch(bt.labels, Md, h->V, h->count, h->status, s));
   if (bt.labels || logits_out) {
     // bf16 head (product path, no logits requested): ONE GEMM writes bf16 logits into dlogits_c and the CE kernel turns
     // them into the gradient in place.  fp32 head: logits requested by the caller / fp32 validation mode / very wide
@@ -1140,8 +1147,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
     // KMB_FP32_HEAD=1 forces the fp32 head (chunked fp32 logits + ce_kernel_reg) in the product mode as well: the bf16 head
     // rounds logits of magnitude 10-20 to 8 significant bits before the softmax (the reference's AMP path holds fp16
     // logits, its CPU path fp32); measured effect on the vcg_base loss 5e-5 relative either way.
-    static const bool force_fp32_head = getenv("KMB_FP32_HEAD") != nullptr && getenv("KMB_FP32_HEAD")[0] == '1';
-    const bool bf16_head = !g_f32 && !logits_out && h->Vpad <= 65536 && !force_fp32_head;
+    const bool bf16_head = !g_f32 && !logits_out && h->Vpad <= 65536 && !force_fp32_head();
     const int CH = bf16_head ? Md : (Md < h->lm_chunk ? Md : h->lm_chunk);
     const bf16_t* Eb = h->wb(h->shared);
     const float lmf = extra ? extra->lm_factor : 1.f;
@@ -1169,7 +1175,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
         // above), then the finish
         KmbGemm gd = lin_dgrad(h->dlogits_c, h->Vpad, Eb, Md, h->Vpad, d);
         const int tiles256 = ((Md + 255) / 256) * ((d + 255) / 256);
-        static const int rounds = getenv("KMB_HEAD_DGRAD_ROUNDS") ? atoi(getenv("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
+        static const int rounds = KMB_DIAG_ENV("KMB_HEAD_DGRAD_ROUNDS") ? atoi(KMB_DIAG_ENV("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
         int S = tiles256 > 0 ? (256 * rounds) / tiles256 : 1;
         if (S > 8) S = 8;
         while (S > 1 && (size_t)S * Md * d > h->logits_c_floats) --S;
@@ -1202,6 +1208,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
         continue;
       }
       float* lg = logits_out ? logits_out + (size_t)r0 * h->Vpad : h->logits_c;
+      if (!logits_out && (size_t)rows * h->Vpad > h->logits_c_floats) return fail("forward: the fp32 logits chunk does not fit the workspace's logits buffer");
       g.out_f32 = lg; g.ld_out_f32 = h->Vpad;
       KCHK(run_gemm(g, s));
       if (!bt.labels) continue;
@@ -1216,7 +1223,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
       // slabs into the bf16 gradient.  The slabs live in the fp32 logits buffer, which is free once the CE ran.
       const int tiles256 = ((Md + 255) / 256) * ((d + 255) / 256);
       const size_t CHl = h->logits_c_floats;   // floats in the slab / logits buffer
-      static const int rounds = getenv("KMB_HEAD_DGRAD_ROUNDS") ? atoi(getenv("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
+      static const int rounds = KMB_DIAG_ENV("KMB_HEAD_DGRAD_ROUNDS") ? atoi(KMB_DIAG_ENV("KMB_HEAD_DGRAD_ROUNDS")) : 3;   // tuning knob
       int S = tiles256 > 0 ? (256 * rounds) / tiles256 : 1;
       if (S > 8) S = 8;
       while (S > 1 && (size_t)S * Md * d > CHl) --S;
@@ -1338,7 +1345,7 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
     if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   KCHK(ensure_side(h));
   const bool side = h->side_on && h->side != nullptr;
-  if (getenv("KMB_PRINT_LAYOUT")) {   // diagnostic: workspace addresses (overlap check)
+  if (KMB_DIAG_ENV("KMB_PRINT_LAYOUT")) {   // diagnostic: workspace addresses (overlap check)
     auto pr = [&](const char* n, const void* p, size_t bytes) { fprintf(stderr, "LAYOUT %s %p %zu\n", n, p, bytes); };
     const size_t Mm = (size_t)(Me > Md ? Me : Md);
     pr("slab", h->slab, h->slab_floats * 4); pr("dhdec", h->dhdec, (size_t)Md * d * 2); pr("dyA", h->dyA, Mm * d * 2);
@@ -1727,8 +1734,8 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
   auto proj_ln = [&](const bf16_t* in, int K, size_t w_off, size_t b_off, const bf16_t* res, size_t g_off, size_t be_off,
                      bf16_t* out) -> int {
     const int nt = K / 64;
-    static const int s_small = getenv("KMB_GEN_SPLIT_SMALL") ? atoi(getenv("KMB_GEN_SPLIT_SMALL")) : 3;   // tuning knobs
-    static const int s_large = getenv("KMB_GEN_SPLIT_LARGE") ? atoi(getenv("KMB_GEN_SPLIT_LARGE")) : 6;
+    static const int s_small = KMB_DIAG_ENV("KMB_GEN_SPLIT_SMALL") ? atoi(KMB_DIAG_ENV("KMB_GEN_SPLIT_SMALL")) : 3;   // tuning knobs
+    static const int s_large = KMB_DIAG_ENV("KMB_GEN_SPLIT_LARGE") ? atoi(KMB_DIAG_ENV("KMB_GEN_SPLIT_LARGE")) : 6;
     int S = K >= 2048 ? s_large : s_small;
     if (S > nt / 2) S = nt / 2;
     if (S > GEN_MAX_SPLIT) S = GEN_MAX_SPLIT;

@@ -23,6 +23,7 @@
 #include <vector>
 #include <type_traits>
 #include "common.h"
+#include "diag.h"
 #include "kernels.h"
 
 // ---- diagnostic build only (tools/gemm_stamps.py compiles this file with -DKMB_GEMM_STAMP into a separate library):
@@ -168,7 +169,7 @@ __device__ __forceinline__ void gemm_epilogue_phase2(const KmbGemm& p, const flo
 template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const KmbGemm& p, char* smem, f32x4 (&acc)[4][4], int tid, int wm, int wn,
                                               int r, int g, int row0, int col0, int slice) {
-  if (p.tile_order & 512) {   // epilogue ablation (diagnostic): keep the accumulators alive, write nothing
+  if (KMB_DIAG_BIT(p.tile_order, 512)) {   // epilogue ablation (diagnostic build only): keep the accumulators alive, write nothing
     float keep = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -245,7 +246,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const KmbGemm& p, const float
     for (int it = 0; it < NIT; ++it) gather(it, it);
   }
   const bool drop = p.drop_thr16 != 0u;
-  const bool skip_stores = (p.tile_order & 256) != 0;  // ablation (tools/gemm_ablate.py): keep the math, drop the stores
+  const bool skip_stores = KMB_DIAG_BIT(p.tile_order, 256);  // ablation (diagnostic build only, tools/gemm_ablate.py): keep the math, drop the stores
   auto process = [&](int it0, int it) -> bool {
     const int lrow = (tid >> 4) + RPP * it0;
     const int grow = row0 + lrow;
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
   __syncthreads();
   KMB_STAMP(2);
   KMB_STAMP_VALUE(5, kmb_wait_ticks);
-  if (p.tile_order & 512) {   // epilogue ablation (diagnostic)
+  if (KMB_DIAG_BIT(p.tile_order, 512)) {   // epilogue ablation (diagnostic build only)
     float keep = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -1881,15 +1882,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     int tm, tn;
     decode_tile(tile, tm, tn);
     const int row0w = tm * BM4 + wm * WROWS, col0w = tn * BNT + wn * WCOLS;
-    if (row0w < p.M && col0w < p.N && (p.tile_order & 512) == 0) {   // bit 9: epilogue ablation (tools/gemm_epilogue_bound.py)
+    if (row0w < p.M && col0w < p.N && !KMB_DIAG_BIT(p.tile_order, 512)) {   // bit 9: epilogue ablation (diagnostic build only, tools/gemm_epilogue_bound.py)
       const bool interior = (row0w + WROWS <= p.M) && (col0w + WCOLS <= p.N);
       const bool hb = p.bias != nullptr, hr = p.residual != nullptr, hd = p.drop_thr16 != 0u, hc = p.colsum != nullptr;
       const bool hs = col0w < p.col_scale_n;   // wave-uniform when col_scale_n is a multiple of 128 (checked below)
-      const bool lean_ok = interior && p.out_bf16 != nullptr && p.out_f32 == nullptr && (p.tile_order & 256) == 0 &&
+      const bool lean_ok = interior && p.out_bf16 != nullptr && p.out_f32 == nullptr && !KMB_DIAG_BIT(p.tile_order, 256) &&
                            (p.col_scale_n <= 0 || (p.col_scale_n % WCOLS) == 0);
 #define KMB_LEAN(B, S, A, R, D, C) v11_epilogue_lean<B, S, A, R, D, C, WROWS, false, NJ>(p, acc, ef, lane, r, g, row0w, col0w)
       if (interior && p.out_f32 != nullptr && p.out_bf16 == nullptr && p.beta == 0.f && (p.ld_out_f32 & 3) == 0 &&
-          (p.tile_order & 256) == 0 && p.act == 0 && hb && !hr && !hd && !hc && p.col_scale_n <= 0) {
+          !KMB_DIAG_BIT(p.tile_order, 256) && p.act == 0 && hb && !hr && !hd && !hc && p.col_scale_n <= 0) {
         v11_epilogue_lean<true, false, 0, false, false, false, WROWS, true, NJ>(p, acc, ef, lane, r, g, row0w, col0w);   // logits
       } else if (lean_ok && p.act == 0 && hb && !hr && !hd && !hc) {
         if (hs) KMB_LEAN(true, true, 0, false, false, false);
@@ -2240,7 +2241,7 @@ bool v11_ok(const KmbGemm& p, int bn = BN4) {
 bool prefetch_a(const KmbGemm& p) {
   static int mode = -1;   // KMB_GEMM_PREFETCH = 0 (never) | 1 (always) | 2 (round 2's rule) | unset (always)
   if (mode < 0) {
-    const char* e = getenv("KMB_GEMM_PREFETCH");
+    const char* e = KMB_DIAG_ENV("KMB_GEMM_PREFETCH");
     mode = e ? atoi(e) : 1;
   }
   if (mode != 2) return mode == 1 && p.a_kc;
@@ -2279,17 +2280,17 @@ hipError_t launch_config(const KmbGemm& p, int cfg, hipStream_t stream) {
     // measures 0.5-2 % slower (tools/gemm_ab_env.sh).  KMB_GEMM_FORCE_ORDER = 0 | 1 overrides bit 0, KMB_GEMM_COLBLOCKS=0
     // switches the column blocks off (A/B measurements).
     static int fo = -2, cbk = -1;
-    if (fo == -2) { const char* e = getenv("KMB_GEMM_FORCE_ORDER"); fo = e ? atoi(e) : -1; }
-    if (cbk < 0) { const char* e = getenv("KMB_GEMM_COLBLOCKS"); cbk = e ? atoi(e) : 1; }
+    if (fo == -2) { const char* e = KMB_DIAG_ENV("KMB_GEMM_FORCE_ORDER"); fo = e ? atoi(e) : -1; }
+    if (cbk < 0) { const char* e = KMB_DIAG_ENV("KMB_GEMM_COLBLOCKS"); cbk = e ? atoi(e) : 1; }
     q.tile_order = (q.tile_order & ~1) | (fo >= 0 ? (fo & 1) : 1);
     if (cbk && p.a_kc && p.b_kc && p.N >= 32 * 256) q.tile_order |= 8;
   }
   {
     // diagnostic (tools/gemm_epilogue_bound.py): KMB_GEMM_ABLATE_DYNAMIC=1 at process start makes the launcher re-read
     // KMB_GEMM_ABLATE at every launch; "1" skips every epilogue (outputs are NOT written: timing only)
-    static const bool dyn_ablate = getenv("KMB_GEMM_ABLATE_DYNAMIC") != nullptr;
+    static const bool dyn_ablate = KMB_DIAG_ENV("KMB_GEMM_ABLATE_DYNAMIC") != nullptr;
     if (dyn_ablate) {
-      const char* ab = getenv("KMB_GEMM_ABLATE");
+      const char* ab = KMB_DIAG_ENV("KMB_GEMM_ABLATE");
       if (ab && ab[0] == '1') q.tile_order |= 512;
     }
   }
@@ -2301,10 +2302,11 @@ hipError_t launch_config(const KmbGemm& p, int cfg, hipStream_t stream) {
     // 628; profiles/r03_gemm_traffic_by_shape_b1024.txt).  In-step: b = 1024 neutral, b = 256 -0.4...-1.3 %
     // (profiles/r03_ab_split_order_instep.txt).  KMB_GEMM_SPLIT_ORDER = 0 | 2: force slice-minor / leave the tuner's pick.
     static int so = -2;
-    if (so == -2) { const char* e = getenv("KMB_GEMM_SPLIT_ORDER"); so = e ? atoi(e) : 1; }
+    if (so == -2) { const char* e = KMB_DIAG_ENV("KMB_GEMM_SPLIT_ORDER"); so = e ? atoi(e) : 1; }
     if (so == 0) q.tile_order &= ~4;
     else if (so == 1) q.tile_order |= 5;
   }
+  if (p.act == 5) q.tile_order &= ~256;   // (diagnostic build) the store ablation has no exp / row-sum form: act 5 always takes its lean epilogue
   return launch_variant(variant, q, stream);
 }
 
@@ -2390,7 +2392,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     forced = ev ? atoi(ev) : 0;
     const char* ea = getenv("KMB_GEMM_AUTOTUNE");
     if (ea && ea[0] == '0') autotune = 0;
-    verbose = getenv("KMB_GEMM_VERBOSE") != nullptr;
+    verbose = KMB_DIAG_ENV("KMB_GEMM_VERBOSE") != nullptr;
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -2423,7 +2425,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   {
     static int narrow_ok = -1;
     if (narrow_ok < 0) {
-      const char* e = getenv("KMB_GEMM_NARROW");
+      const char* e = KMB_DIAG_ENV("KMB_GEMM_NARROW");
       narrow_ok = !(e && e[0] == '0');
       (void)hipFuncSetAttribute((const void*)gemm_kernel_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
     }
@@ -2465,7 +2467,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     static unsigned exclude = ~0u;   // KMB_GEMM_EXCLUDE=14,15: variants the tuner may not pick (same-box A/B measurements)
     if (exclude == ~0u) {
       exclude = 0u;
-      if (const char* ex = getenv("KMB_GEMM_EXCLUDE"))
+      if (const char* ex = KMB_DIAG_ENV("KMB_GEMM_EXCLUDE"))
         for (const char* q = ex; *q;) {
           const int v = atoi(q);
           if (v > 0 && v < 32) exclude |= 1u << v;
@@ -2504,7 +2506,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     it = g_best.emplace(key, best).first;
-    static const bool refine_on = getenv("KMB_GEMM_REFINE") && getenv("KMB_GEMM_REFINE")[0] == '1';   // opt-in: see Refine
+    static const bool refine_on = KMB_DIAG_ENV("KMB_GEMM_REFINE") && KMB_DIAG_ENV("KMB_GEMM_REFINE")[0] == '1';   // opt-in: see Refine
     Refine& R = g_refine[key];
     R.final_cfg = best;
     R.done = true;

@@ -85,8 +85,8 @@ hipError_t kmb_pos_bwd_launch(const bf16_t* dz, int B, int S, int D, float* dP, 
                               hipStream_t stream);
 
 // ----------------------------------------------------------------- loss.hip
-// count[0] = number of labels != -100
-hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, hipStream_t stream);
+// count[0] = number of labels in [0, V); labels that are neither -100 nor in range set bit 1 of status[0] (status may be null)
+hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int V, int32_t* count, int32_t* status, hipStream_t stream);
 // tied-head cross-entropy without a pass over the logits (loss.hip, KmbGemm act 5)
 hipError_t kmb_ce_label_logit_launch(const bf16_t* H, int ldh, const bf16_t* E, int lde, const float* bias, const int64_t* labels,
                                      int rows, int d, int V, float* shift, hipStream_t stream);

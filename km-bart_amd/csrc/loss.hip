@@ -47,22 +47,36 @@ __device__ __forceinline__ void row_lse(const float* __restrict__ row, int V, fl
 
 // one workgroup of 1024 threads, eight independent loads in flight per thread (a 256-thread loop of dependent loads took
 // 54 us for the 32768 labels of the benchmark batch)
-__global__ __launch_bounds__(1024) void count_valid_kernel(const int64_t* __restrict__ labels, int n,
-                                                           int32_t* __restrict__ count) {
+// A label is VALID when 0 <= label < V; -100 is ignored (CrossEntropyLoss(ignore_index=-100), reference
+// src/model/model.py:400-402); any other value is an input error the reference's loss raises on: such rows are treated as
+// ignored by every cross-entropy kernel here, are NOT counted, and set bit 1 (value 2) of `status` (may be null) so that the
+// host's input check reports them.
+__global__ __launch_bounds__(1024) void count_valid_kernel(const int64_t* __restrict__ labels, int n, int V,
+                                                           int32_t* __restrict__ count, int32_t* __restrict__ status) {
   __shared__ int sh[16];
-  int c = 0;
+  int c = 0, bad = 0;
   int i = threadIdx.x;
   for (; i + 7 * 1024 < n; i += 8 * 1024) {
     int64_t v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = labels[i + k * 1024];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c += (v[k] != -100) ? 1 : 0;
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = v[k] >= 0 && v[k] < V;
+      c += ok ? 1 : 0;
+      bad |= (!ok && v[k] != -100) ? 1 : 0;
+    }
   }
-  for (; i < n; i += 1024) c += (labels[i] != -100) ? 1 : 0;
+  for (; i < n; i += 1024) {
+    const int64_t v = labels[i];
+    const bool ok = v >= 0 && v < V;
+    c += ok ? 1 : 0;
+    bad |= (!ok && v != -100) ? 1 : 0;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  if (bad && status != nullptr) atomicOr(status, 2);
   __syncthreads();
   if (threadIdx.x == 0) {
     int t = 0;
@@ -80,7 +94,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   const int r = blockIdx.x, tid = threadIdx.x;
   const float* row = logits + (size_t)r * ldv;
   const int64_t label = labels[r];
-  const bool valid = (label != -100);
+  const bool valid = label >= 0 && label < V;   // ignored: -100; out of range: flagged by count_valid
   float m = 0.f, s = 1.f;
   if (valid) row_lse(row, V, sh, m, s);  // block-uniform branch
   const float lse = m + __logf(s);
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(1024) void ce_kernel_reg(const float* __restrict__ 
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* row = logits + (size_t)r * ldv;
   const int64_t label = labels[r];
-  const bool valid = (label != -100);  // block-uniform
+  const bool valid = label >= 0 && label < V;  // block-uniform (ignored: -100; out of range: flagged by count_valid)
   typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
   if (!valid) {
     if (tid == 0) loss_rows[r] = 0.f;
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(1024) void ce_kernel_reg_bf16(const bf16_t* logits,
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bf16_t* row = logits + (size_t)r * ldv;
   const int64_t label = labels[r];
-  const bool valid = (label != -100);  // block-uniform
+  const bool valid = label >= 0 && label < V;  // block-uniform (ignored: -100; out of range: flagged by count_valid)
   if (!valid) {
     if (tid == 0) loss_rows[r] = 0.f;
     if (dlogits != nullptr) {
@@ -739,7 +753,8 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
 // Tied-head cross-entropy WITHOUT a pass over the logits (round 3).  Reference src/model/model.py:397-402:
 //   loss = mean over valid rows of  lse(v_r) - v_r[label_r],   v_r = h_r E^T + b.
 // The head GEMM (KmbGemm act 5) stores  P[r][j] = exp(v_rj - c_r)  in bf16 with c_r = the label's logit, so that
-// P[r][label] = 1 exactly and the row cannot overflow unless some logit exceeds the label's by 88 (a loss of 88), and
+// P[r][label] = 1 exactly; a logit more than 80 above the label's (a row whose loss exceeds 80 nats) saturates at 2^115
+// instead of overflowing (the epilogue clamps the exponent), ignored rows store zeros (their shift is +1e30); the GEMM
 // leaves the fp32 row sums S_r = sum_j P[r][j] (per 64-column block) and d_r = v_r[label] - c_r.  Then
 //   loss_r = log S_r - d_r,      softmax_rj = P[r][j] / S_r,
 //   dlogits_rj = g (P[r][j] / S_r - [j == label_r]),          g = lm_factor / (number of valid rows)
@@ -753,15 +768,19 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
 // (A first version kept P intact and corrected both products afterwards -- S_r E[label_r] in the finish and an atomic
 // scatter of S_r (a . H)_r into dE: 115 us of fp32 atomics per b = 1024 step for the same precision.)
 
-// c_r = h_r . E[label_r] + bias[label_r]   (ignored rows: column 0, only to keep their exps finite); one wave per row
+// c_r = h_r . E[label_r] + bias[label_r]; ignored / out-of-range rows get c_r = +1e30, so that their stored row is
+// exp(v - 1e30) = 0 and their sum 0 whatever the logits are (nothing downstream has to rely on a zero factor); one wave per row
 __global__ __launch_bounds__(256) void ce_label_logit_kernel(const bf16_t* __restrict__ H, int ldh, const bf16_t* __restrict__ E,
                                                              int lde, const float* __restrict__ bias,
                                                              const int64_t* __restrict__ labels, int rows, int d, int V,
                                                              float* __restrict__ shift) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= rows) return;
-  long long lab = labels[r];
-  if (lab < 0 || lab >= V) lab = 0;
+  const long long lab = labels[r];
+  if (lab < 0 || lab >= V) {
+    if (lane == 0) shift[r] = 1e30f;
+    return;
+  }
   const bf16_t* h = H + (size_t)r * ldh;
   const bf16_t* e = E + (size_t)lab * lde;
   float acc = 0.f;
@@ -873,8 +892,8 @@ hipError_t kmb_ce_dgrad_finish_launch(const float* slab, int nslabs, size_t stri
   return hipGetLastError();
 }
 
-hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int32_t* count, hipStream_t stream) {
-  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, stream, labels, n, count);
+hipError_t kmb_count_valid_launch(const int64_t* labels, int n, int V, int32_t* count, int32_t* status, hipStream_t stream) {
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, stream, labels, n, V, count, status);
   return hipGetLastError();
 }
 

@@ -266,9 +266,16 @@ class Engine:
         st = C.c_int32(0)
         with torch.cuda.device(self.device):
             check(self.lib.kmb_read_status(self.h, C.byref(st), _stream()))
-        if st.value & 1:
+        self._raise_on_status(st.value)
+
+    @staticmethod
+    def _raise_on_status(st):
+        if st & 1:
             raise RuntimeError("number of <img_feat>/<cls> ids differs from the number of region features "
                                "(reference src/model/modules.py:98-100 would raise a shape mismatch)")
+        if st & 2:
+            raise RuntimeError("a label is neither -100 nor inside [0, number of classes) "
+                               "(the reference's CrossEntropyLoss raises on such a target, src/model/model.py:400-402)")
 
     def check_inputs_begin(self):
         """check_inputs without the wait: the status word is copied to page-locked memory in stream order; the caller
@@ -286,9 +293,7 @@ class Engine:
             return
         st, ev = pend
         ev.synchronize()
-        if int(st[0]) & 1:
-            raise RuntimeError("number of <img_feat>/<cls> ids differs from the number of region features "
-                               "(reference src/model/modules.py:98-100 would raise a shape mismatch)")
+        self._raise_on_status(int(st[0]))
 
     def backward(self, loss_scale=1.0):
         """loss_scale: a Python float, or a 1-element fp32 device tensor (autograd's upstream gradient: no host sync)."""

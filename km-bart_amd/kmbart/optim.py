@@ -174,6 +174,10 @@ class AdamW(torch.optim.Optimizer):
             "step": [e.step_count for e in eng],
             "exp_avg": [e.exp_avg.detach().cpu() for e in eng],
             "exp_avg_sq": [e.exp_avg_sq.detach().cpu() for e in eng],
+            # the arena layout the two moment arenas were dumped in: name -> (offset, element count).  The arena order is an
+            # implementation detail of the engine (round 3 moved every decoder layer's cross-attention k | v block), so a
+            # raw dump is only meaningful together with it: load_state_dict maps by NAME.
+            "layout": [{n: (int(off), int(rows) * int(cols)) for n, (off, rows, cols) in e.index.items()} for e in eng],
             "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
         }
 
@@ -182,10 +186,32 @@ class AdamW(torch.optim.Optimizer):
         `training_data.pt` (reference src/utils.py:20-39: {'state': {index: {'step', 'exp_avg', 'exp_avg_sq'}},
         'param_groups': [{..., 'params': [indices]}]}): per-parameter moments are copied into the arena slices."""
         if state.get("kmbart_adamw"):
+            layouts = state.get("layout")
+            if layouts is None:
+                raise ValueError("this kmbart AdamW state has no arena layout (saved before the layout was recorded): the "
+                                 "moment arenas cannot be assigned to parameters safely; save the optimizer again with this "
+                                 "build, or load a torch-format {state, param_groups} dict")
             for i, e in enumerate(self._engines()):
+                saved = layouts[i]
+                here = {n: (int(off), int(rows) * int(cols)) for n, (off, rows, cols) in e.index.items()}
+                if set(saved) != set(here):
+                    raise ValueError("optimizer state was saved for a different parameter set: %s"
+                                     % sorted(set(saved) ^ set(here))[:4])
                 e.step_count = int(state["step"][i])
-                e.exp_avg.copy_(state["exp_avg"][i])
-                e.exp_avg_sq.copy_(state["exp_avg_sq"][i])
+                if all(tuple(saved[n]) == here[n] for n in here) and state["exp_avg"][i].numel() == e.exp_avg.numel():
+                    e.exp_avg.copy_(state["exp_avg"][i])
+                    e.exp_avg_sq.copy_(state["exp_avg_sq"][i])
+                    continue
+                # a different arena order: copy every parameter's moments by name (alignment gaps stay zero)
+                m, v = state["exp_avg"][i].reshape(-1), state["exp_avg_sq"][i].reshape(-1)
+                e.exp_avg.zero_()
+                e.exp_avg_sq.zero_()
+                for n, (off, cnt) in here.items():
+                    soff, scnt = (int(x) for x in saved[n])
+                    if scnt != cnt:
+                        raise ValueError("optimizer state of %s has %d elements, expected %d" % (n, scnt, cnt))
+                    e.exp_avg[off: off + cnt].copy_(m[soff: soff + cnt])
+                    e.exp_avg_sq[off: off + cnt].copy_(v[soff: soff + cnt])
             for g, s in zip(self.param_groups, state["param_groups"]):
                 g.update(s)
             return

@@ -185,3 +185,33 @@ def test_adamw_param_groups_and_torch_state_dict():
         assert torch.equal(eng.exp_avg_sq[o: o + cnt].cpu(), state["state"][i]["exp_avg_sq"].reshape(-1)), n
     with pytest.raises(ValueError):
         opt.load_state_dict({"foo": 1})
+    # the optimizer's OWN format records the arena layout: it round-trips, a state saved under a DIFFERENT arena
+    # order is remapped by name, and a state without a layout is refused instead of being copied blindly
+    own = opt.state_dict()
+    assert set(own["layout"][0]) == set(eng.index)
+    m_before, v_before = eng.exp_avg.clone(), eng.exp_avg_sq.clone()
+    eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+    opt.load_state_dict(own)
+    assert torch.equal(eng.exp_avg, m_before) and torch.equal(eng.exp_avg_sq, v_before)
+    names = sorted(eng.index)                     # "another build": the same parameters packed in name order
+    perm_layout, cur = {}, 0
+    for n in names:
+        cnt = eng.index[n][1] * eng.index[n][2]
+        perm_layout[n] = (cur, cnt)
+        cur += cnt + 3                            # and with different alignment gaps
+    pm, pv = torch.zeros(cur), torch.zeros(cur)
+    for n in names:
+        so, cnt = perm_layout[n]
+        o = eng.index[n][0]
+        pm[so: so + cnt] = m_before[o: o + cnt].cpu()
+        pv[so: so + cnt] = v_before[o: o + cnt].cpu()
+    other = dict(own, exp_avg=[pm], exp_avg_sq=[pv], layout=[perm_layout])
+    eng.exp_avg.fill_(9.0); eng.exp_avg_sq.fill_(9.0)
+    opt.load_state_dict(other)
+    for n in names:
+        o, cnt = eng.index[n][0], eng.index[n][1] * eng.index[n][2]
+        assert torch.equal(eng.exp_avg[o: o + cnt], m_before[o: o + cnt]), n
+        assert torch.equal(eng.exp_avg_sq[o: o + cnt], v_before[o: o + cnt]), n
+    legacy = {k: v for k, v in own.items() if k != "layout"}
+    with pytest.raises(ValueError):
+        opt.load_state_dict(legacy)

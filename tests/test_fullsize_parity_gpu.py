@@ -111,6 +111,22 @@ def test_vcg_base_every_gradient_ragged_b2():
     check_grads(model, {k: v.grad for k, v in osd.items() if v.grad is not None}, "vcg_base ragged b=2")
 
 
+def test_fp32_head_env_with_gradients_b2():
+    """KMB_FP32_HEAD=1 (fp32 logits + register-resident fp32 cross-entropy in the bf16 product mode) WITH gradients: the
+    workspace's logits buffer must be sized for the fp32 chunk (it was not, and the head GEMM overran it).
+    The knob is read once per process, so the gradient test above is re-run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("KMB_FP32_HEAD") == "1":
+        pytest.skip("already inside the child")
+    env = dict(os.environ, KMB_FP32_HEAD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_vcg_base_every_gradient_ragged_b2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+
+
 def _pretrain_setup(bsz=2):
     over = dict(num_labels=1601, num_attributes=129, num_relations=129, lm_loss_factor=5.0, mrm_loss_factor=1.0,
                 attribute_loss_factor=1.0, relation_loss_factor=1.0)

@@ -3,6 +3,9 @@ interleaved layout [row, 3d] as the engine uses it; B from the environment (defa
 import ctypes as C
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: E402
+_diag.use_diag_lib()   # the A/B knobs live in the diagnostic build only (csrc/diag.h)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "km-bart_amd"))

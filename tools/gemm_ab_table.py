@@ -8,6 +8,9 @@ import collections
 import os
 import subprocess
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: E402
+_diag.use_diag_lib()   # the A/B knobs live in the diagnostic build only (csrc/diag.h)
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

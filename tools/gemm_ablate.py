@@ -2,6 +2,9 @@
 The per-phase timeline comes from tools/gemm_stamps.py."""
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: E402
+_diag.use_diag_lib()   # the A/B knobs live in the diagnostic build only (csrc/diag.h)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "km-bart_amd"))

@@ -9,6 +9,9 @@ epilogues under the next tile's K loop could buy inside a step.
 import collections
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: E402
+_diag.use_diag_lib()   # the A/B knobs live in the diagnostic build only (csrc/diag.h)
 
 os.environ["KMB_GEMM_ABLATE_DYNAMIC"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

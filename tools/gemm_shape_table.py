@@ -2,6 +2,10 @@
 import collections
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: E402
+if os.environ.get("KMB_USE_DIAG") == "1":   # A/B runs (tools/gemm_ab_*.sh): the knobs live in the diagnostic build only (csrc/diag.h)
+    _diag.use_diag_lib()
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "km-bart_amd"))
