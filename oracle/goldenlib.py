@@ -84,3 +84,11 @@ def trained_state_dict():
                         "tiny_trained_fp16.npz")
     z = np.load(path)
     return {k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}
+
+
+class IdTokenizer:
+    """Stand-in for BartTokenizer.decode in the generate_text fixtures (the BART vocabulary files are absent offline): the
+    text of a sequence is its ids in decimal, special ids (< 3: <s>, <pad>, </s>) dropped when skip_special_tokens."""
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(int(t)) for t in ids if not (skip_special_tokens and int(t) < 3))

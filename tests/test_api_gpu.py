@@ -215,3 +215,21 @@ def test_adamw_param_groups_and_torch_state_dict():
     legacy = {k: v for k, v in own.items() if k != "layout"}
     with pytest.raises(ValueError):
         opt.load_state_dict(legacy)
+
+
+def test_generate_text_on_the_hip_path_equals_the_reference_records(gold_dir):
+    """The records the REFERENCE's generate_text returned over the oracle (tests/golden/generate_text_reference.json,
+    oracle/make_golden_reference_api.py) against the product's generate_text over the HIP model: same ids, same text."""
+    import json
+    import os
+    import types
+    from oracle.make_golden_reference_api import gen_loader
+    from src.generation import generate_text
+    ref = json.load(open(os.path.join(gold_dir, "generate_text_reference.json")))
+    ocfg = G.tiny_config()
+    model = build(ocfg, G.trained_state_dict()).eval()
+    model.config.max_length = 12            # the fixture's adapter generated with max_length 12
+    for case in ref["cases"]:
+        recs = generate_text(model, gen_loader(), G.IdTokenizer(), types.SimpleNamespace(amp=False, **case["args"]),
+                             torch.device(DEV), logger=types.SimpleNamespace(info=lambda m: None))
+        assert recs == case["records"], (case["args"], recs[:2], case["records"][:2])

@@ -127,6 +127,56 @@ def test_generate_text_record_schema():
     assert set(out[0]) == {"index", "task_type", "generations"}
 
 
+def test_config_equals_the_reference_class_dump(gold_dir):
+    """tests/golden/config_reference.json was written by the REFERENCE's own MultiModalBartConfig (imported from
+    /root/reference/src/model/config.py by oracle/make_golden_reference_api.py): defaults, from_dict of both shipped JSON
+    files, and the attribute writes vcg_train.py:71-83 makes afterwards.  The product class must hold the same values."""
+    import os
+    ref = json.load(open(os.path.join(gold_dir, "config_reference.json")))
+    vcg = {"d_model": 768, "decoder_attention_heads": 12, "decoder_ffn_dim": 3072, "decoder_layers": 6,
+           "encoder_attention_heads": 12, "encoder_ffn_dim": 3072, "encoder_layers": 6,
+           "partial_load": ["final_logits_bias", "model.shared.weight", "model.encoder.embed_tokens.weight",
+                            "model.decoder.embed_tokens.weight"]}
+    pre = dict(vcg, num_labels=1601, num_attributes=129, num_relations=129, lm_loss_factor=5, mrm_loss_factor=1,
+               attribute_loss_factor=1, relation_loss_factor=1)
+
+    def same(cfg, want, tag):
+        for k, v in want.items():
+            got = getattr(cfg, k)
+            got = list(got) if isinstance(got, tuple) else got
+            assert got == v and type(got) is type(v), (tag, k, got, v)
+
+    same(MultiModalBartConfig(), ref["defaults"], "defaults")
+    same(MultiModalBartConfig.from_dict(vcg), ref["vcg_base"], "vcg_base")
+    same(MultiModalBartConfig.from_dict(pre), ref["pretrain_base"], "pretrain_base")
+    cfg = MultiModalBartConfig.from_dict(vcg)
+    cfg.dropout, cfg.attention_dropout, cfg.classif_dropout, cfg.activation_dropout = 0.3, 0.2, 0.1, 0.05
+    same(cfg, ref["vcg_base_after_cli_writes"], "cli writes")
+    # every attribute the product defines is either dumped from the reference or declared as restated
+    from src.model.config import _DEFAULTS
+    assert set(_DEFAULTS) == set(ref["defaults"]) | set(ref["restated_not_dumped"])
+
+
+def test_generate_text_equals_the_reference_function(gold_dir):
+    """tests/golden/generate_text_reference.json: the REFERENCE's own generate_text (src/generation.py:6-52) driven over
+    the oracle's beam search on the trained tiny fixture.  The product's generate_text over the SAME adapter must pass
+    the same keyword arguments to `generate`, return the same records and log the same lines."""
+    import os
+    from oracle import goldenlib as G
+    from oracle.make_golden_reference_api import OracleGenerateAdapter, gen_loader
+    from src.generation import generate_text
+    ref = json.load(open(os.path.join(gold_dir, "generate_text_reference.json")))
+    cfg, sd = G.tiny_config(), G.trained_state_dict()
+    for case in ref["cases"]:
+        calls, lines = [], []
+        recs = generate_text(OracleGenerateAdapter(cfg, sd, calls), gen_loader(), G.IdTokenizer(),
+                             types.SimpleNamespace(amp=False, **case["args"]), torch.device("cpu"),
+                             logger=types.SimpleNamespace(info=lambda m: lines.append(m)), log_interval=1)
+        assert calls == case["generate_kwargs"]
+        assert recs == case["records"]
+        assert [ln.split(", ETA")[0] for ln in lines] == case["log_prefixes"]
+
+
 def test_pretrain_loop_uses_the_loss_dict():
     """reference src/training.py:9-93: outputs[0] is a dict; 'loss' drives backward; kwargs of the forward call."""
     from src.data.synthetic import make_pretrain_batch
