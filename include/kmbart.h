@@ -239,6 +239,9 @@ int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretra
 /* ================= generation ================= */
 /* encoder once (src/model/mixins.py:281-283) + cross-attention K/V of every decoder layer */
 int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_length, void* stream);
+/* encoder output [B*S, d_model] (bf16) of the kmb_gen_begin still active: the `encoder_outputs` element of the cached
+ * forward's return tuple (src/model/model.py:384-397 returns decoder_outputs + encoder_outputs) */
+int kmb_gen_encoder_states(kmb_handle* h, kmb_bf16* enc_out, void* stream);
 /* one cached decoder step (src/model/mixins.py:386-398 -> model.py:384-397): tokens [B*num_beams]
  * at position `step` (0-based), logits_out fp32 [B*num_beams, kmb_logits_ld()] */
 int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_out, void* stream);

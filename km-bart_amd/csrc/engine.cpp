@@ -166,7 +166,8 @@ struct kmb_handle {
     std::vector<bf16_t*> ckv;              // per layer [B*S, 2d]
     std::vector<bf16_t*> kc[2], vc[2];     // per layer self caches, double buffered [R, Tmax, d]
     int cur = 0;
-    int32_t *kv_row = nullptr;             // [R] -> batch item
+    int32_t *kv_row = nullptr;             // [R] -> batch item (the current one of the two copies at kv_row_base)
+    int32_t *kv_row_base = nullptr;
     bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd; float* slab;
     std::vector<bf16_t*> wp;               // fused decode blocks: fragment-order weight copies, 6 per layer (empty: not eligible)
   } gen;
@@ -1632,7 +1633,7 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
     g.ckv[l] = ckv_all + (size_t)l * 2 * d;
     for (int i = 0; i < 2; ++i) { g.kc[i][l] = bp.act(R * Tmax * d); g.vc[i][l] = bp.act(R * Tmax * d); }
   }
-  g.kv_row = bp.take<int32_t>(R);
+  g.kv_row = bp.take<int32_t>(2 * R);   // two copies: a reorder of independent rows (num_beams == 1) gathers it into the other one
   g.x0 = bp.act(R * d); g.x1 = bp.act(R * d); g.qkv = bp.act(R * 3 * d);
   g.o = bp.act(R * d); g.z = bp.act(R * d); g.y = bp.act(R * d); g.cq = bp.act(R * d);
   g.u = bp.act(R * Fd); g.hh = bp.act(R * Fd);
@@ -1684,7 +1685,7 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   auto& G = h->gen;
   G.active = true; G.B = B; G.S = S; G.nb = num_beams; G.R = B * num_beams; G.Tmax = max_length; G.bt = bt; G.cur = 0;
   G.ckv = g.ckv; G.kc[0] = g.kc[0]; G.kc[1] = g.kc[1]; G.vc[0] = g.vc[0]; G.vc[1] = g.vc[1];
-  G.kv_row = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
+  G.kv_row = g.kv_row; G.kv_row_base = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
   G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab; G.wp = g.wp;
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam), all layers in ONE GEMM
   if (Ld > 0) {
@@ -1711,6 +1712,15 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   for (int i = 0; i < G.R; ++i) g_kvrow_host[i] = i / num_beams;
   HIPCHK(hipMemcpyAsync(G.kv_row, g_kvrow_host.data(), (size_t)G.R * sizeof(int32_t), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));  // the staging vector may be reused by the next call
+  return 0;
+}
+
+int kmb_gen_encoder_states(kmb_handle* h, kmb_bf16* enc_out, void* stream) {
+  auto& G = h->gen;
+  if (!G.active) return fail("kmb_gen_encoder_states: call kmb_gen_begin first");
+  if (!enc_out) return fail("kmb_gen_encoder_states: enc_out is required");
+  const bf16_t* enc = h->xe[h->cfg.encoder_layers];
+  HIPCHK(hipMemcpyAsync(enc_out, enc, (size_t)G.B * G.S * h->d * sizeof(bf16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 
@@ -1867,6 +1877,14 @@ int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stre
   }
   if (n) HIPCHK(kmb_gather_rows_multi_launch(src, dst, n, beam_idx, G.R, row_bytes, stride, s));
   G.cur ^= 1;
+  if (G.nb == 1) {
+    // rows are independent sequences (the cached forward of src/model/model.py:384-397 with caller-expanded rows):
+    // _reorder_cache (mixins.py:419-434) also permutes the encoder side, here the row -> cross-attention item table.
+    // (With num_beams > 1 a beam search only permutes rows inside a batch item and the table is unchanged.)
+    int32_t* other = G.kv_row == G.kv_row_base ? G.kv_row_base + G.R : G.kv_row_base;
+    HIPCHK(kmb_gather_i32_launch(G.kv_row, beam_idx, other, G.R, s));
+    G.kv_row = other;
+  }
   return 0;
 }
 

@@ -135,6 +135,8 @@ hipError_t kmb_kv_append_launch(const bf16_t* src, int ld_src, bf16_t* cache, in
 // gather rows: dst[i] = src[idx[i]]  (16-byte chunks, row_bytes % 16 == 0; rows are `stride_bytes` apart)
 hipError_t kmb_gather_rows_multi_launch(const void* const* src, void* const* dst, int n, const int32_t* idx, int rows,
                                         int row_bytes, size_t stride_bytes, hipStream_t stream);
+// dst[i] = src[idx[i]]  (dst must not alias src)
+hipError_t kmb_gather_i32_launch(const int32_t* src, const int32_t* idx, int32_t* dst, int n, hipStream_t stream);
 hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst, int rows, int row_bytes,
                                   size_t stride_bytes, hipStream_t stream);
 

@@ -116,6 +116,12 @@ __global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet gs, co
   }
 }
 
+__global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                         int32_t* __restrict__ dst, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
 inline int grid_for(size_t work, int cap = 4096) {
   size_t b = (work + 255) / 256;
   if (b > (size_t)cap) b = cap;
@@ -172,6 +178,12 @@ hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst
   if ((row_bytes & 15) || (stride_bytes & 15)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)rows * (row_bytes >> 4))), dim3(256), 0, stream,
                      (const char*)src, idx, (char*)dst, rows, row_bytes, stride_bytes);
+  return hipGetLastError();
+}
+
+hipError_t kmb_gather_i32_launch(const int32_t* src, const int32_t* idx, int32_t* dst, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, idx, dst, n);
   return hipGetLastError();
 }
 

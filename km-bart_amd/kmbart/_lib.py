@@ -113,6 +113,7 @@ PROTOTYPES = {
     "kmb_read_status": (C.c_int, [c_p, C.POINTER(i32), c_p]),
     "kmb_read_status_async": (C.c_int, [c_p, c_p, c_p]),
     "kmb_gen_begin": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p]),
+    "kmb_gen_encoder_states": (C.c_int, [c_p, c_p, c_p]),
     "kmb_gen_step": (C.c_int, [c_p, c_p, C.c_int, c_p, c_p]),
     "kmb_gen_reorder": (C.c_int, [c_p, c_p, C.c_int, c_p]),
     "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),

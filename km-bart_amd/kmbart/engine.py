@@ -373,7 +373,17 @@ class Engine:
             check(self.lib.kmb_gen_begin(self.h, C.byref(b), num_beams, max_length, _stream()))
             self._keep = keep
             self._gen_rows = B * num_beams
+            self._gen_enc_shape = (B, S)
+            self._gen_max_length = int(max_length)
             self._gen_logits = torch.empty((self._gen_rows, self.logits_ld), dtype=torch.float32, device=self.device)
+
+    def gen_encoder_states(self):
+        """[B, S, d] bf16: the encoder output of the active gen_begin (a copy)."""
+        B, S = self._gen_enc_shape
+        out = torch.empty((B, S, int(self.config.d_model)), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_gen_encoder_states(self.h, ptr(out), _stream()))
+        return out
 
     def gen_step(self, tokens, step, want_logits=True):
         """tokens int64 [B*num_beams] (device) at 0-based position `step` -> fp32 logits [R, V] (padded view).

@@ -153,6 +153,49 @@ class BeamHypotheses:
         return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
 
 
+class DecoderCache:
+    """`decoder_cached_states` of the cached forward (reference src/model/model.py:384-397 returns the per-layer dicts of
+    transformers 3.0.2's BartDecoder; src/model/mixins.py:386-398 hands them back through `past`).  Here the keys / values
+    live in the engine's generation workspace (kmb_gen_begin / kmb_gen_step); this handle names them: the engine, the
+    number of decoder positions fed so far, and the engine serial they were built under (any other forward, generate or
+    optimizer step on the same model re-uses that workspace and invalidates the handle)."""
+
+    def __init__(self, engine, rows, max_length):
+        self.engine, self.rows, self.max_length, self.length = engine, rows, max_length, 0
+        self.serial = engine.fwd_serial
+
+    def check(self):
+        if self.serial != self.engine.fwd_serial:
+            raise RuntimeError("decoder_cached_states is stale: another forward / generate / optimizer step ran on this "
+                               "model since the cache was created (the KV cache lives in the engine's workspace)")
+
+    def __len__(self):
+        return self.length
+
+
+class _EncoderHandle:
+    """`model.get_encoder()` (reference src/model/mixins.py:436-437).  Calling it runs the multimodal encoder once and
+    returns the reference's filtered encoder tuple `(encoder_states,)`; the states are also left in the engine's generation
+    workspace together with every decoder layer's cross-attention keys / values, so a cached forward that receives this
+    tuple as `encoder_outputs` (prepare_inputs_for_generation, mixins.py:386-398) continues from it without input_ids."""
+
+    def __init__(self, model):
+        self._model = model
+
+    def __call__(self, input_ids, image_features, attention_mask=None, max_cache_length=None, **unused):
+        m = self._model
+        eng = m._need_engine()
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        cap = int(max_cache_length or max(int(m.config.max_length), 64))
+        eng.gen_begin(input_ids, image_features, attention_mask, 1, cap)
+        enc = eng.gen_encoder_states()
+        enc._kmb_cache = DecoderCache(eng, input_ids.shape[0], cap)
+        return (enc,)
+
+    forward = __call__
+
+
 class MultiModalBartForConditionalGeneration(nn.Module):
     base_model_prefix = "model"
     config_class = MultiModalBartConfig
@@ -282,11 +325,20 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 decoder_attention_mask=None, decoder_cached_states=None, labels=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_logits=None, **unused):
         """Reference src/model/model.py:325-405.  Returns (loss, logits, encoder_last_hidden) with labels,
-        (logits, encoder_last_hidden) without.  The cached-decode branch is served by generate()."""
+        (logits, encoder_last_hidden) without; with `use_cache=True` (and no labels) the KV-cached step of
+        src/model/model.py:384-397: (logits of the LAST decoder position [rows, 1, V], decoder_cached_states,
+        encoder_last_hidden), see _forward_cached.  Deliberate difference: `use_cache=None` means False here -- the
+        reference falls back to config.use_cache (True), i.e. an eval forward without labels returns only the last
+        position there; no caller of the reference relies on that (fine_tune / validation pass labels, generate passes
+        use_cache), and the teacher-forced logits of every position are what the parity tests compare."""
         eng = self._need_engine()
-        if decoder_cached_states is not None or use_cache:
-            raise NotImplementedError("the KV-cached decode step runs inside generate() (kmb_gen_step); forward() is the "
-                                      "teacher-forced pass")
+        if labels is not None:
+            use_cache = False     # src/model/model.py:381-382
+        if use_cache or decoder_cached_states is not None:
+            if output_attentions or output_hidden_states:
+                raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
+            return self._forward_cached(input_ids, image_features, attention_mask, encoder_outputs, decoder_input_ids,
+                                        decoder_cached_states, unused.get("max_cache_length"))
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
         enc_states = None
@@ -316,6 +368,118 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         if logits is None:
             logits = LazyLogits(eng)
         return (loss, logits, enc)
+
+    def _forward_cached(self, input_ids, image_features, attention_mask, encoder_outputs, decoder_input_ids,
+                        decoder_cached_states, max_cache_length=None):
+        """One KV-cached decoder step over kmb_gen_step (reference src/model/model.py:384-397, mixins.py:386-398;
+        transformers 3.0.2 BartDecoder with use_cache: only the last column of decoder_input_ids is embedded, at position
+        len - 1).  First call (decoder_cached_states None): the encoder runs from input_ids / image_features -- or is
+        taken from `encoder_outputs` when that is what get_encoder()(...) returned -- and every column of
+        decoder_input_ids is fed in order; later calls feed the last column.  Rows are independent (a beam search
+        passes already-expanded rows and permutes them with _reorder_cache)."""
+        eng = self._need_engine()
+        if self.training:
+            raise RuntimeError("the cached decoder step is an inference path: call model.eval() first")
+        if decoder_input_ids is None:
+            raise ValueError("use_cache=True needs decoder_input_ids (src/model/model.py:52-53 turns the cache off without them)")
+        cache = decoder_cached_states
+        enc = encoder_outputs[0] if isinstance(encoder_outputs, (tuple, list)) else encoder_outputs
+        if cache is None and enc is not None and getattr(enc, "_kmb_cache", None) is not None:
+            cache = enc._kmb_cache
+            if cache.length != 0:
+                raise RuntimeError("this encoder output already has decoder positions behind it; pass its decoder_cached_states")
+        new_cache = cache is None
+        if new_cache:
+            if input_ids is None:
+                raise ValueError("the first cached step needs input_ids / image_features, or the tuple returned by "
+                                 "model.get_encoder()(...) as encoder_outputs (expanded or re-created encoder states cannot "
+                                 "be mapped back to the engine's cross-attention cache)")
+            enc = self.get_encoder()(input_ids, image_features, attention_mask, max_cache_length=max_cache_length)[0]
+            cache = enc._kmb_cache
+        elif not isinstance(cache, DecoderCache) or cache.engine is not eng:
+            raise TypeError("decoder_cached_states must be the DecoderCache a previous cached forward of this model returned")
+        cache.check()
+        R, t = decoder_input_ids.shape
+        if R != cache.rows:
+            raise ValueError("decoder_input_ids has %d rows, the cache was created for %d" % (R, cache.rows))
+        first = cache.length if t == cache.length + 1 else (0 if cache.length == 0 else None)
+        if first is None:
+            raise ValueError("decoder_input_ids must hold the %d cached positions plus the new one (got %d columns)"
+                             % (cache.length, t))
+        if t > cache.max_length:
+            raise ValueError("decoder position %d exceeds the cache (max_cache_length=%d)" % (t, cache.max_length))
+        logits = None
+        for pos in range(first, t):
+            logits = eng.gen_step(decoder_input_ids[:, pos], pos, want_logits=(pos == t - 1))
+        cache.length = t
+        V = int(self.config.vocab_size)
+        out = logits[:, :V].clone().view(R, 1, V)
+        if enc is None:
+            enc = eng.gen_encoder_states()
+        return (out, cache, enc)
+
+    def _reorder_cache(self, past, beam_idx):
+        """Reference src/model/mixins.py:419-434: `past` = ((encoder_states, encoder_mask), decoder_cached_states): the
+        self-attention caches AND the rows' cross-attention keys / values / masks follow beam_idx (kmb_gen_reorder: the
+        cached forward's rows are independent sequences, so the row -> encoder-item table is permuted with them), as do
+        the encoder states and mask handed back to the caller."""
+        (enc_out, enc_mask), cache = past
+        cache.check()
+        if cache.length > 0:
+            cache.engine.gen_reorder(beam_idx, cache.length - 1)
+        new_enc = enc_out if enc_out is None else enc_out.index_select(0, beam_idx.to(enc_out.device))
+        new_mask = enc_mask if enc_mask is None else enc_mask.index_select(0, beam_idx.to(enc_mask.device))
+        return ((new_enc, new_mask), cache)
+
+    def prepare_inputs_for_generation(self, decoder_input_ids, past, attention_mask, use_cache, **kwargs):
+        """Reference src/model/mixins.py:386-398."""
+        assert past is not None, "past has to be defined for encoder_outputs"
+        encoder_outputs, decoder_cached_states = past
+        return {"input_ids": None, "image_features": None, "encoder_outputs": encoder_outputs,
+                "decoder_cached_states": decoder_cached_states, "decoder_input_ids": decoder_input_ids,
+                "attention_mask": attention_mask, "use_cache": use_cache}
+
+    # ------------------------------------------------------------------ embeddings surface
+    def get_encoder(self):
+        """Reference src/model/mixins.py:436-437."""
+        return _EncoderHandle(self)
+
+    def get_input_embeddings(self):
+        """nn.Embedding view of model.shared (reference src/model/model.py:105-106): shares the parameter's storage."""
+        emb = nn.Embedding(self.config.vocab_size, self.config.d_model, padding_idx=self.config.pad_token_id,
+                           _weight=self._p["model.shared.weight"].detach())
+        return emb
+
+    def get_output_embeddings(self):
+        """The tied head as an nn.Linear made on the fly from model.shared, without bias (reference
+        src/model/mixins.py:439-440, model.py:113-114: _make_linear_from_emb); shares the parameter's storage."""
+        w = self._p["model.shared.weight"]
+        lin = nn.Linear(w.shape[1], w.shape[0], bias=False, device=w.device, dtype=w.dtype)
+        lin.weight.data = w.detach()
+        return lin
+
+    def resize_token_embeddings(self, new_num_tokens=None):
+        """Reference src/model/mixins.py:442-455 (+ transformers 3.0.2 _get_resized_embeddings): model.shared becomes
+        [new_num_tokens, d] -- the first min(old, new) rows are kept, new rows are N(0, init_std) -- and
+        final_logits_bias is cut or zero-extended.  Only before the model is moved to the device (the engine's arenas
+        are sized at .to(device); the reference's callers resize right after construction / from_pretrained)."""
+        if new_num_tokens is None:
+            return self.get_input_embeddings()
+        if self._engine is not None:
+            raise RuntimeError("resize_token_embeddings after .to(device) is not supported: resize first, then move the model")
+        old = self._p["model.shared.weight"].detach()
+        new_num_tokens = int(new_num_tokens)
+        if new_num_tokens != old.shape[0]:
+            g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+            w = torch.randn((new_num_tokens, old.shape[1]), generator=g) * self.config.init_std
+            n = min(old.shape[0], new_num_tokens)
+            w[:n] = old[:n]
+            self._p["model.shared.weight"] = nn.Parameter(w)
+            flb = torch.zeros((1, new_num_tokens))
+            flb[:, :n] = self._flb[:, :n]
+            self._flb = flb
+            self.config.vocab_size = new_num_tokens
+        return self.get_input_embeddings()
 
     def _backward(self, loss_scale=1.0):
         self._engine.backward(loss_scale)

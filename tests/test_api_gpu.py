@@ -233,3 +233,98 @@ def test_generate_text_on_the_hip_path_equals_the_reference_records(gold_dir):
         recs = generate_text(model, gen_loader(), G.IdTokenizer(), types.SimpleNamespace(amp=False, **case["args"]),
                              torch.device(DEV), logger=types.SimpleNamespace(info=lambda m: None))
         assert recs == case["records"], (case["args"], recs[:2], case["records"][:2])
+
+
+def test_cached_forward_returns_logits_cache_and_encoder_states():
+    """forward(use_cache=True, decoder_cached_states=...) (reference src/model/model.py:384-397, mixins.py:386-434): the
+    last position's logits, a cache handle and the encoder states; step by step it reproduces the teacher-forced logits of
+    the same model (and through them the oracle's), _reorder_cache moves whole sequences, and a hand-written greedy loop
+    over get_encoder() / prepare_inputs_for_generation returns what generate() returns."""
+    from oracle.make_golden import copy_task_batch
+    from src.model.model import DecoderCache
+    ocfg = G.tiny_config()
+    sd = G.trained_state_dict()
+    model = build(ocfg, sd).eval()
+    b = copy_task_batch(13, 4)
+    kw = dev_batch(b)
+    g = torch.Generator().manual_seed(3)
+    dec = torch.randint(3, 400, (4, 8), generator=g)      # no pads: the cached step has no decoder padding mask (HF 3.0.2)
+    dec[:, 0] = 0
+    dec = dec.to(DEV)
+    V = ocfg.vocab_size
+    with torch.no_grad():
+        full_logits, enc_full = model(decoder_input_ids=dec, **kw)[:2]
+        ref_logits = O.forward(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], dec.cpu(), None, None)[1]
+    assert rel(full_logits, ref_logits) < ACT_TOL
+    # (a) one call with several columns = prefill: logits of the last position, the cache, the encoder states
+    out = model(decoder_input_ids=dec[:, :7], use_cache=True, **kw)
+    assert len(out) == 3 and isinstance(out[1], DecoderCache) and tuple(out[0].shape) == (4, 1, V)
+    assert out[1].length == 7 and tuple(out[2].shape) == tuple(enc_full.shape)
+    assert rel(out[0][:, 0], full_logits[:, 6]) < 1e-2 and rel(out[2], enc_full) < 1e-2
+    # (b) column by column through the returned cache
+    cache = None
+    for t in range(1, 8):
+        first = dict(kw) if cache is None else {"input_ids": None, "image_features": None}
+        step = model(decoder_input_ids=dec[:, :t], use_cache=True, decoder_cached_states=cache, **first)
+        cache = step[1]
+        assert rel(step[0][:, 0], full_logits[:, t - 1]) < 1e-2, t
+    # (c) _reorder_cache with a permutation ACROSS sequences: every row keeps decoding its own sequence
+    perm = torch.tensor([2, 0, 3, 1], device=DEV)
+    (enc_p, mask_p), cache = model._reorder_cache(((step[2], kw["attention_mask"]), cache), perm)
+    assert torch.equal(enc_p, step[2][perm]) and torch.equal(mask_p, kw["attention_mask"][perm])
+    nxt = model(input_ids=None, image_features=None, decoder_input_ids=dec[perm][:, :8], use_cache=True, decoder_cached_states=cache)
+    assert rel(nxt[0][:, 0], full_logits[perm][:, 7]) < 1e-2
+    # a stale cache is refused (another forward re-used the workspace); labels switch the cache off (model.py:381-382)
+    model(decoder_input_ids=dec, **kw)
+    with pytest.raises(RuntimeError):
+        model(input_ids=None, image_features=None, decoder_input_ids=dec, use_cache=True, decoder_cached_states=cache)
+    three = model(decoder_input_ids=dec, labels=dec, use_cache=True, **kw)
+    assert three[0].dim() == 0 and tuple(three[1].shape) == (4, 8, V)
+    # (d) the reference's generation plumbing by hand: greedy search over the cached forward == generate(num_beams=1)
+    want = model.generate(max_length=12, num_beams=1, **kw)
+    enc_out = model.get_encoder()(kw["input_ids"], kw["image_features"], kw["attention_mask"])
+    ids = torch.full((4, 1), model.config.decoder_start_token_id, dtype=torch.long, device=DEV)
+    unfinished = torch.ones(4, dtype=torch.long, device=DEV)
+    cache = None
+    while ids.shape[1] < 12:
+        inp = model.prepare_inputs_for_generation(ids, past=(enc_out, cache), attention_mask=kw["attention_mask"], use_cache=True)
+        logits, cache = model(**inp)[:2]
+        tok = logits[:, -1].argmax(-1) * unfinished + model.config.pad_token_id * (1 - unfinished)
+        ids = torch.cat([ids, tok[:, None]], dim=1)
+        unfinished = unfinished * (tok != model.config.eos_token_id).long()
+        if int(unfinished.max()) == 0:
+            break
+    assert ids.cpu().tolist() == want.cpu().tolist()
+
+
+def test_embedding_accessors_and_resize():
+    """get_output_embeddings (a bias-free Linear over model.shared, reference mixins.py:439-440), get_input_embeddings,
+    resize_token_embeddings (mixins.py:442-455: rows kept, final_logits_bias cut / zero-extended; before .to(device))."""
+    from src.model import MultiModalBartForConditionalGeneration
+    ocfg = G.tiny_config()
+    sd = G.golden_state_dict(ocfg, seed=3)
+    model = MultiModalBartForConditionalGeneration(cfg_from_oracle(ocfg))
+    model.load_state_dict(sd, strict=False)
+    old = dict(model.named_parameters())["model.shared.weight"].detach().clone()
+    flb_old = model.final_logits_bias.clone()
+    emb = model.resize_token_embeddings(ocfg.vocab_size + 16)
+    w = dict(model.named_parameters())["model.shared.weight"]
+    assert tuple(w.shape) == (ocfg.vocab_size + 16, ocfg.d_model) and emb.weight.shape == w.shape
+    assert torch.equal(w[: ocfg.vocab_size], old) and model.config.vocab_size == ocfg.vocab_size + 16
+    assert model.final_logits_bias.shape == (1, ocfg.vocab_size + 16)
+    assert torch.equal(model.final_logits_bias[:, : ocfg.vocab_size], flb_old) and float(model.final_logits_bias[:, ocfg.vocab_size:].abs().sum()) == 0.0
+    model.resize_token_embeddings(ocfg.vocab_size)       # and back: the kept rows are the original ones
+    assert torch.equal(dict(model.named_parameters())["model.shared.weight"], old)
+    model.to(DEV).eval()
+    lin = model.get_output_embeddings()
+    wdev = dict(model.named_parameters())["model.shared.weight"]
+    assert lin.bias is None and lin.weight.data_ptr() == wdev.data_ptr() and tuple(lin.weight.shape) == tuple(wdev.shape)
+    assert model.get_input_embeddings().weight.data_ptr() == wdev.data_ptr()
+    with pytest.raises(RuntimeError):
+        model.resize_token_embeddings(ocfg.vocab_size + 8)
+    # the resized-and-restored model still computes the golden loss
+    b = tiny_batch(seed=5)
+    loss = run_fwd(model, b)[0]
+    ref = O.forward(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], b["decoder_input_ids"],
+                    b["decoder_attention_mask"], b["labels"])[0]
+    assert abs(float(loss) - float(ref)) / float(ref) < 1e-3
