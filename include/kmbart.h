@@ -276,6 +276,34 @@ int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams
  * Process-wide; results do not depend on it. */
 int kmb_gemm_shared_device(int on);
 
+/* ================= data parallelism: native RCCL (vcg_train.py:98 DDP, src/utils.py:9-17 init_process_group) =================
+ * One process per GPU; the library owns the communicator and a communication stream, and a step's whole gradient
+ * exchange is ONE call: every gradient bucket (kmb_bucket_range, backward completion order) is reduced on the
+ * communication stream behind that bucket's completion event of kmb_backward, in pieces of at most max_piece_elems,
+ * so the collectives overlap the rest of backward; with `adamw` set each piece's fused optimizer update is chained
+ * right behind its collective on the same stream.  Semantics = torch DistributedDataParallel's: after the call every
+ * rank holds the arithmetic MEAN over ranks of the per-rank gradients.  The communicator is bootstrapped with a
+ * 128-byte id made by rank 0 (kmb_comm_unique_id) and handed to the other ranks by any host channel. */
+#define KMB_COMM_ID_BYTES 128
+int kmb_comm_unique_id(void* id_host);                                   /* ncclGetUniqueId: call on rank 0 */
+int kmb_comm_init(kmb_handle* h, int rank, int world, const void* id_host);   /* ncclCommInitRank on the current device */
+int kmb_comm_destroy(kmb_handle* h);
+int kmb_comm_info(const kmb_handle* h, int32_t* rank, int32_t* world);   /* world 0: no communicator */
+/* parameters and final_logits_bias of rank `root` to every rank (DDP's broadcast at wrap time), bf16 mirror refreshed */
+int kmb_comm_broadcast_params(kmb_handle* h, int root, void* stream);
+typedef struct kmb_allreduce_opts {
+  int32_t algo;               /* 0: ncclAllReduce(avg) per piece; 1: ncclReduceScatter(avg) -> [AdamW on this rank's shard ->
+                               * ncclAllGather of the updated parameters] (ZeRO-1 form: optimizer traffic / world; moments are
+                               * valid on the owning rank only until kmb_comm_gather_moments); world must divide 8 */
+  int32_t after_compute;      /* 1: the communication stream first waits for everything already enqueued on compute_stream */
+  int64_t max_piece_elems;    /* <= 0: 16 Mi elements (64 MB of fp32) */
+  const KmbAdamW* adamw;      /* NULL: gradients only (algo 1 then all-gathers the gradients) */
+} kmb_allreduce_opts;
+int kmb_allreduce_grads(kmb_handle* h, const kmb_allreduce_opts* opts, void* compute_stream);
+int kmb_comm_wait(kmb_handle* h, void* compute_stream);                  /* compute_stream waits for the communication stream */
+int kmb_comm_gather_moments(kmb_handle* h, void* compute_stream);        /* algo 1: every rank gets every shard's exp_avg / exp_avg_sq */
+int64_t kmb_comm_pieces(const kmb_handle* h, int64_t max_piece_elems);   /* number of collectives one kmb_allreduce_grads issues */
+
 /* ================= measurement ================= */
 /* time every GEMM launch of the following calls with HIP events on its own stream (bench.py roofline leg);
  * variant = a_kc*2 + b_kc: 3 forward (X W^T), 2 dgrad (dY W), 0 wgrad (dY^T X) */

@@ -20,6 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-f
 # -O2 / -O3, also with the SDWA peephole or early if-conversion off or the division replaced; 0 of 20 at -O1 and at -O3
 # without the SLP vectoriser).  Explicit two-wide vector code (kmb_f32x2) is not affected.  DESIGN.md section 5.
 FILE_FLAGS = {}
+# the gradient exchange (kmb_allreduce_grads, csrc/engine.cpp) calls RCCL directly
+RCCL_LINK = ["-L/opt/rocm/lib", "-lrccl"]
 
 
 def _stale(target, deps):
@@ -56,7 +58,7 @@ def build(force=False, verbose=True):
                 print("[build] compiled", os.path.basename(s))
     objs = [os.path.join(objdir, src + ".o") for src in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + RCCL_LINK
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
@@ -81,7 +83,7 @@ def build_variant(name, defines, sources=("gemm.hip",)):
                 raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
         objs.append(o)
     lib = os.path.join(LIBDIR, "libkmbart_hip_%s.so" % name)
-    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + RCCL_LINK, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     return lib

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
 #include "kernels.h"
 #include "diag.h"
 
@@ -151,6 +152,10 @@ struct kmb_handle {
   std::vector<hipEvent_t> ring; size_t ring_pos = 0;
   std::vector<hipEvent_t> layer_done;   // recorded on the side stream
   hipEvent_t head_wgrad_done = nullptr; bool head_wgrad_pending = false;
+  // ---- native data parallelism (kmb_comm_*)
+  ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 0;
+  hipStream_t comm_stream = nullptr; hipEvent_t comm_ev = nullptr;
+  int64_t comm_piece_cap = 0;   // piece size of the last algo-1 exchange: the moments' shards follow its piece boundaries
   float* parts = nullptr;
   // pre-training head scratch
   bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr; float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
@@ -960,6 +965,7 @@ void kmb_destroy(kmb_handle* h) {
   for (auto e : h->layer_done) if (e) (void)hipEventDestroy(e);
   if (h->head_wgrad_done) (void)hipEventDestroy(h->head_wgrad_done);
   if (h->side) (void)hipStreamDestroy(h->side);
+  (void)kmb_comm_destroy(h);
   delete h;
 }
 
@@ -1588,6 +1594,173 @@ int kmb_adamw_step(kmb_handle* h, const KmbAdamW* hp, int64_t offset, int64_t co
   const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
   if ((size_t)offset < iw1 && (size_t)(offset + count) > iw0)
     HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, s));
+  return 0;
+}
+
+}  // extern "C"
+
+
+// ================================================================================= native data parallelism (RCCL)
+namespace {
+
+#define NCCLCHK(expr)                                                                                          \
+  do {                                                                                                         \
+    ncclResult_t r_ = (expr);                                                                                  \
+    if (r_ != ncclSuccess) return fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+struct Piece { int bucket; size_t off, cnt; };
+
+// the collectives of one gradient exchange: every bucket (backward completion order) cut into pieces of at most `cap`
+// elements whose boundaries stay 64-element aligned (the fused optimizer's and the shards' alignment)
+std::vector<Piece> comm_pieces(const kmb_handle* h, int64_t max_piece_elems) {
+  const size_t cap = max_piece_elems > 0 ? (size_t)max_piece_elems : (size_t)16 << 20;
+  std::vector<Piece> out;
+  for (size_t i = 0; i < h->buckets.size(); ++i) {
+    const size_t off = h->buckets[i].off, cnt = h->buckets[i].count;
+    if (cnt == 0) continue;
+    if (cnt > cap) {
+      const size_t n = (cnt + cap - 1) / cap;
+      const size_t step = align_up((cnt + n - 1) / n, 64);
+      for (size_t s0 = 0; s0 < cnt; s0 += step) out.push_back({(int)i, off + s0, std::min(step, cnt - s0)});
+    } else {
+      out.push_back({(int)i, off, cnt});
+    }
+  }
+  return out;
+}
+
+int comm_ready(const kmb_handle* h, const char* who) {
+  if (!h->comm || !h->comm_stream) return fail("%s: no communicator (call kmb_comm_init first)", who);
+  if (!h->P || !h->G) return fail("%s: arenas are not bound", who);
+  return 0;
+}
+
+// the optimizer update of arena range [off, off + cnt) on stream s (what kmb_adamw_step does, shared with it)
+int adamw_range(kmb_handle* h, const KmbAdamW& hp, size_t off, size_t cnt, hipStream_t s) {
+  if (!h->M1 || !h->M2) return fail("fused optimizer step: the moment arenas are not bound");
+  HIPCHK(kmb_adamw_launch(h->P + off, h->G + off, h->M1 + off, h->M2 + off, h->PB + off, cnt, hp, s));
+  const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
+  if (off < iw1 && off + cnt > iw0)
+    HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kmb_comm_unique_id(void* id_host) {
+  static_assert(sizeof(ncclUniqueId) == KMB_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  if (!id_host) return fail("kmb_comm_unique_id: id_host is required");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(id_host, &id, sizeof(id));
+  return 0;
+}
+
+int kmb_comm_init(kmb_handle* h, int rank, int world, const void* id_host) {
+  if (!id_host || world < 1 || rank < 0 || rank >= world) return fail("kmb_comm_init: bad rank / world / id");
+  if (h->comm) return fail("kmb_comm_init: this handle already has a communicator");
+  ncclUniqueId id;
+  memcpy(&id, id_host, sizeof(id));
+  NCCLCHK(ncclCommInitRank(&h->comm, world, id, rank));
+  h->comm_rank = rank; h->comm_world = world;
+  HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->comm_ev, hipEventDisableTiming));
+  return 0;
+}
+
+int kmb_comm_destroy(kmb_handle* h) {
+  if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+  if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+  if (h->comm_ev) { (void)hipEventDestroy(h->comm_ev); h->comm_ev = nullptr; }
+  h->comm_world = 0; h->comm_rank = 0;
+  return 0;
+}
+
+int kmb_comm_info(const kmb_handle* h, int32_t* rank, int32_t* world) {
+  if (rank) *rank = h->comm_rank;
+  if (world) *world = h->comm ? h->comm_world : 0;
+  return 0;
+}
+
+int kmb_comm_broadcast_params(kmb_handle* h, int root, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  KCHK(comm_ready(h, "kmb_comm_broadcast_params"));
+  if (root < 0 || root >= h->comm_world) return fail("kmb_comm_broadcast_params: root out of range");
+  NCCLCHK(ncclBroadcast(h->P, h->P, h->arena, ncclFloat, root, h->comm, s));
+  NCCLCHK(ncclBroadcast(h->flb, h->flb, (size_t)h->V, ncclFloat, root, h->comm, s));
+  return kmb_sync_params(h, stream);
+}
+
+int64_t kmb_comm_pieces(const kmb_handle* h, int64_t max_piece_elems) { return (int64_t)comm_pieces(h, max_piece_elems).size(); }
+
+int kmb_allreduce_grads(kmb_handle* h, const kmb_allreduce_opts* opts, void* compute_stream) {
+  KCHK(comm_ready(h, "kmb_allreduce_grads"));
+  static const kmb_allreduce_opts dflt{0, 0, 0, nullptr};
+  const kmb_allreduce_opts& o = opts ? *opts : dflt;
+  const int W = h->comm_world, rank = h->comm_rank;
+  if (o.algo != 0 && o.algo != 1) return fail("kmb_allreduce_grads: algo must be 0 (all-reduce) or 1 (reduce-scatter + all-gather)");
+  if (o.algo == 1 && (8 % W) != 0) return fail("kmb_allreduce_grads: algo 1 needs a world size that divides 8 (got %d)", W);
+  if (o.algo == 1) h->comm_piece_cap = o.max_piece_elems;
+  hipStream_t cs = h->comm_stream;
+  if (o.after_compute) {
+    HIPCHK(hipEventRecord(h->comm_ev, (hipStream_t)compute_stream));
+    HIPCHK(hipStreamWaitEvent(cs, h->comm_ev, 0));
+  }
+  int waited = -1;
+  for (const Piece& pc : comm_pieces(h, o.max_piece_elems)) {
+    if (pc.bucket != waited) {   // the bucket's gradients are complete (both compute streams are past it: kmb_backward)
+      if (!h->events[pc.bucket]) return fail("kmb_allreduce_grads: bucket %d has no completion event (run kmb_backward first)", pc.bucket);
+      HIPCHK(hipStreamWaitEvent(cs, h->events[pc.bucket], 0));
+      waited = pc.bucket;
+    }
+    float* g = h->G + pc.off;
+    if (o.algo == 0) {
+      NCCLCHK(ncclAllReduce(g, g, pc.cnt, ncclFloat, ncclAvg, h->comm, cs));
+      if (o.adamw) KCHK(adamw_range(h, *o.adamw, pc.off, pc.cnt, cs));
+      continue;
+    }
+    // reduce-scatter: rank r ends up with the mean of shard r (in place: recvbuff = sendbuff + r * shard)
+    const size_t shard = pc.cnt / (size_t)W;   // pieces are multiples of 64 elements and W divides 8: shards stay 8-aligned
+    if (shard * (size_t)W != pc.cnt || (shard & 7)) return fail("kmb_allreduce_grads: piece of %zu elements does not split into %d aligned shards", pc.cnt, W);
+    const size_t mine = pc.off + (size_t)rank * shard;
+    NCCLCHK(ncclReduceScatter(g, h->G + mine, shard, ncclFloat, ncclAvg, h->comm, cs));
+    if (o.adamw) {
+      KCHK(adamw_range(h, *o.adamw, mine, shard, cs));                                              // 30 B / parameter / W
+      NCCLCHK(ncclAllGather(h->P + mine, h->P + pc.off, shard, ncclFloat, h->comm, cs));           // updated fp32 masters
+      if (W > 1) {   // the other ranks' shards of the bf16 mirror (this rank's was written by the optimizer kernel)
+        HIPCHK(kmb_cast_f32_bf16_launch(h->P + pc.off, h->PB + pc.off, pc.cnt, cs));
+        const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
+        if (pc.off < iw1 && pc.off + pc.cnt > iw0)
+          HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, cs));
+      }
+    } else {
+      NCCLCHK(ncclAllGather(h->G + mine, g, shard, ncclFloat, h->comm, cs));
+    }
+  }
+  return 0;
+}
+
+int kmb_comm_wait(kmb_handle* h, void* compute_stream) {
+  if (!h->comm_stream) return fail("kmb_comm_wait: no communicator");
+  HIPCHK(hipEventRecord(h->comm_ev, h->comm_stream));
+  HIPCHK(hipStreamWaitEvent((hipStream_t)compute_stream, h->comm_ev, 0));
+  return 0;
+}
+
+int kmb_comm_gather_moments(kmb_handle* h, void* compute_stream) {
+  KCHK(comm_ready(h, "kmb_comm_gather_moments"));
+  if (!h->M1 || !h->M2) return fail("kmb_comm_gather_moments: the moment arenas are not bound");
+  const int W = h->comm_world, rank = h->comm_rank;
+  if ((8 % W) != 0) return fail("kmb_comm_gather_moments: world size must divide 8");
+  hipStream_t s = (hipStream_t)compute_stream;
+  for (const Piece& pc : comm_pieces(h, h->comm_piece_cap)) {
+    const size_t shard = pc.cnt / (size_t)W, mine = pc.off + (size_t)rank * shard;
+    NCCLCHK(ncclAllGather(h->M1 + mine, h->M1 + pc.off, shard, ncclFloat, h->comm, s));
+    NCCLCHK(ncclAllGather(h->M2 + mine, h->M2 + pc.off, shard, ncclFloat, h->comm, s));
+  }
   return 0;
 }
 

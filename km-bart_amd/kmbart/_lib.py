@@ -81,6 +81,10 @@ class KmbAdamW(C.Structure):
                 ("step", i32), ("correct_bias", i32), ("grad_scale", f32)]
 
 
+class KmbAllreduceOpts(C.Structure):
+    _fields_ = [("algo", i32), ("after_compute", i32), ("max_piece_elems", i64), ("adamw", C.POINTER(KmbAdamW))]
+
+
 # name -> (restype, argtypes); must list every function include/kmbart.h declares
 PROTOTYPES = {
     "kmb_last_error": (C.c_char_p, []),
@@ -124,6 +128,15 @@ PROTOTYPES = {
                                          C.c_int64, c_p]),
     "kmb_gen_workspace_bytes": (i64, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kmb_gemm_shared_device": (C.c_int, [C.c_int]),
+    "kmb_comm_unique_id": (C.c_int, [c_p]),
+    "kmb_comm_init": (C.c_int, [c_p, C.c_int, C.c_int, c_p]),
+    "kmb_comm_destroy": (C.c_int, [c_p]),
+    "kmb_comm_info": (C.c_int, [c_p, C.POINTER(i32), C.POINTER(i32)]),
+    "kmb_comm_broadcast_params": (C.c_int, [c_p, C.c_int, c_p]),
+    "kmb_allreduce_grads": (C.c_int, [c_p, C.POINTER(KmbAllreduceOpts), c_p]),
+    "kmb_comm_wait": (C.c_int, [c_p, c_p]),
+    "kmb_comm_gather_moments": (C.c_int, [c_p, c_p]),
+    "kmb_comm_pieces": (i64, [c_p, i64]),
     "kmb_debug_trace": (C.c_int, [C.c_int]),
     "kmb_debug_trace_dump": (C.c_int, [C.c_char_p]),
     "kmb_set_side_stream": (C.c_int, [c_p, C.c_int]),

@@ -363,6 +363,48 @@ class Engine:
     def stream_wait_bucket(self, i, stream):
         check(self.lib.kmb_stream_wait_bucket(self.h, i, C.c_void_p(stream.cuda_stream)))
 
+    # ---- native RCCL gradient exchange (kmb_comm_*, include/kmbart.h) ------------------------
+    def comm_init(self, process_group=None):
+        """Creates the library's own RCCL communicator over the ranks of `process_group` (torch.distributed is only the
+        bootstrap channel for the 128-byte id, as torchrun's rendezvous is for init_process_group in the reference,
+        src/utils.py:9-17).  Returns (rank, world)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        box = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            check(self.lib.kmb_comm_unique_id(buf))
+            box[0] = bytes(buf.raw)
+        src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=process_group)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_comm_init(self.h, rank, world, C.c_char_p(box[0])))
+        self.comm_world = world
+        return rank, world
+
+    def comm_broadcast_params(self, root=0):
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_comm_broadcast_params(self.h, int(root), _stream()))
+
+    def allreduce_grads(self, algo=0, adamw=None, max_piece_elems=0, after_compute=False):
+        """One call = the whole gradient exchange of a step on the library's communication stream (mean over ranks per
+        bucket behind its completion event, optionally each piece's fused AdamW behind it).  adamw: KmbAdamW or None."""
+        from ._lib import KmbAllreduceOpts
+        o = KmbAllreduceOpts(algo=int(algo), after_compute=1 if after_compute else 0, max_piece_elems=int(max_piece_elems),
+                             adamw=C.pointer(adamw) if adamw is not None else None)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_allreduce_grads(self.h, C.byref(o), _stream()))
+        if adamw is not None:
+            self.fwd_serial += 1   # the weights move
+
+    def comm_wait(self):
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_comm_wait(self.h, _stream()))
+
+    def comm_gather_moments(self):
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_comm_gather_moments(self.h, _stream()))
+
     # ---- generation -------------------------------------------------------------------------
     def gen_begin(self, input_ids, image_features, attention_mask, num_beams, max_length):
         with torch.cuda.device(self.device):

@@ -126,6 +126,14 @@ class AdamW(torch.optim.Optimizer):
         self._fused_done = set()
         return True
 
+    def fused_hyperparams(self, engine):
+        """The KmbAdamW record of this step for the native exchange (kmb_allreduce_grads chains the update of every
+        piece behind its collective itself); begin_fused_step has already advanced the step count."""
+        from ._lib import KmbAdamW
+        g = self.param_groups[0]
+        return KmbAdamW(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                        step=engine.step_count, correct_bias=1 if g["correct_bias"] else 0, grad_scale=1.0)
+
     def fused_piece_step(self, engine, off, cnt):
         g = self.param_groups[0]
         engine.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], g["correct_bias"], 1.0, offset=off,

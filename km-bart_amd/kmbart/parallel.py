@@ -22,7 +22,18 @@ update, so the un-overlapped tail is one piece, not 564 MB of all-reduce plus a 
 `grad_dtype="bf16"` halves the bytes on the wire (282 MB): a piece is cast into a bf16 staging buffer, reduced, and
 cast back (fp32 accumulation inside the optimizer is unchanged); off by default -- xGMI has the bandwidth at the
 benchmark batch, SURVEY.md section 5 prices when it does not.
+
+Native exchange (default on the nccl backend).  The library owns an RCCL communicator and a communication stream
+(include/kmbart.h "data parallelism: native RCCL"): `kmb_allreduce_grads` enqueues EVERY bucket's ncclAllReduce(avg)
+behind its completion event -- and, with an optimizer attached, each piece's fused AdamW behind its collective -- from
+C++ in one call; torch.distributed only bootstraps the communicator's id and serves bench.py's barrier.  `KMB_DP_ALGO=rsag`
+(or algo="rsag") selects ncclReduceScatter -> AdamW on this rank's shard -> ncclAllGather of the updated parameters
+(optimizer HBM traffic / world; exp_avg / exp_avg_sq are then valid on the owning rank only:
+`gather_optimizer_state()` before saving a checkpoint).  `native=False`, the gloo backend and `grad_dtype="bf16"` take the
+torch.distributed path below (BucketedAllReducer), which the CPU and two-ranks-on-one-GPU tests exercise.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -118,14 +129,37 @@ class _Null:
 
 class DistributedDataParallel(torch.nn.Module):
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None,
-                 max_bucket_mb=64, reduce_single_rank=False, grad_dtype=None):
+                 max_bucket_mb=64, reduce_single_rank=False, grad_dtype=None, native=None, algo=None):
         super().__init__()
         self.__dict__["module"] = module  # not a registered child: parameters() must not be re-wrapped
         eng = module._need_engine()
         self.engine = eng
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = None
-        if self.world > 1 or (reduce_single_rank and dist.is_initialized()):
+        self.native = False
+        active = self.world > 1 or (reduce_single_rank and dist.is_initialized())
+        if native is None:
+            native = os.environ.get("KMB_DP_NATIVE", "1") != "0"
+        if algo is None:
+            algo = os.environ.get("KMB_DP_ALGO", "allreduce")
+        if algo not in ("allreduce", "rsag"):
+            raise ValueError("algo must be 'allreduce' or 'rsag'")
+        if active and native and grad_dtype is None and dist.get_backend(process_group) == "nccl":
+            # native exchange: the library's own communicator and communication stream (module docstring)
+            self.native = True
+            self.algo = 1 if (algo == "rsag" and 8 % self.world == 0) else 0
+            self.max_piece_elems = max_bucket_mb * (1 << 20) // 4
+            eng.comm_init(process_group)
+            eng.comm_broadcast_params(0)      # C2: parameters and the logits-bias buffer start identical on every rank
+            self._opt = None
+            module._post_backward = self._reduce_native
+            from . import _lib
+            _lib.load().kmb_gemm_shared_device(1)
+            self._first_reduce = True
+            self._fusing = False
+            self._tail_events = []
+            eng.adamw_overlap_ok = False
+        elif active:
             # C2: parameters and the logits-bias buffer start identical on every rank
             dist.broadcast(eng.params, src=0, group=process_group)
             dist.broadcast(eng.final_logits_bias, src=0, group=process_group)
@@ -153,7 +187,7 @@ class DistributedDataParallel(torch.nn.Module):
         docstring).  Only for loops that call `optimizer.step()` right after `loss.backward()` with nothing touching the
         gradients in between: the parameters of a bucket are already updated when backward returns, `step()` becomes
         the point where the compute stream waits for the communication stream."""
-        if self.reducer is None or not hasattr(optimizer, "fused_piece_step"):
+        if (self.reducer is None and not self.native) or not hasattr(optimizer, "fused_piece_step"):
             return False
         self._opt = optimizer
         optimizer._ddp_fused = self
@@ -163,6 +197,19 @@ class DistributedDataParallel(torch.nn.Module):
         """What the data-parallel exchange of a step looked like, for bench.py's JSON line: ranks, collective backend,
         gradient buckets / pieces, bytes all-reduced per step and the exposed tail -- the time the compute stream spent
         waiting for the communication stream after backward's last kernel (median over the last steps; syncs)."""
+        if self.native:
+            tails = []
+            if self._tail_events:
+                torch.cuda.synchronize(self.engine.device)
+                tails = sorted(a.elapsed_time(b) for a, b in self._tail_events)
+            from . import _lib
+            return {"rccl_ranks": self.world, "backend": "rccl-native", "algo": "rsag" if self.algo == 1 else "allreduce",
+                    "buckets": len(self.engine.buckets()),
+                    "pieces": int(_lib.load().kmb_comm_pieces(self.engine.h, self.max_piece_elems)),
+                    "bytes_reduced_per_step": int(sum(c for _, c in self.engine.buckets()) * 4), "wire_dtype": "fp32",
+                    "fused_optimizer": self._opt is not None,
+                    "exposed_tail_ms": round(tails[len(tails) // 2], 3) if tails else None,
+                    "exposed_tail_ms_max": round(tails[-1], 3) if tails else None, "steps_measured": len(tails)}
         if self.reducer is None:
             return {"rccl_ranks": self.world, "reduced": False}
         r = self.reducer
@@ -188,6 +235,34 @@ class DistributedDataParallel(torch.nn.Module):
     def _step_piece(self, off, cnt):
         if self._opt is not None and self._fusing:
             self._opt.fused_piece_step(self.engine, off, cnt)
+
+    def gather_optimizer_state(self):
+        """rsag: exp_avg / exp_avg_sq are updated on the owning rank only; this all-gathers them (before a checkpoint)."""
+        if self.native and self.algo == 1:
+            self.engine.comm_gather_moments()
+
+    def _reduce_native(self):
+        """loss.backward()'s tail on the native path: ONE library call enqueues the step's whole exchange (and the fused
+        optimizer pieces) on the communication stream, a second makes the compute stream wait for it."""
+        eng = self.engine
+        first = self._first_reduce     # the first backward times the GEMM variants of every shape: keep RCCL out of it
+        self._first_reduce = False
+        if self._opt is not None and getattr(self._opt, "_fused_pending", False):
+            raise RuntimeError("loss.backward() ran twice without optimizer.step() while an optimizer is attached to the "
+                               "data-parallel wrapper (attach_optimizer fuses the AdamW step into backward); call "
+                               "detach_optimizer() for gradient accumulation or custom loops")
+        self._fusing = self._opt is not None and self._opt.begin_fused_step(eng)
+        hp = self._opt.fused_hyperparams(eng) if self._fusing else None
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        pair[0].record()
+        eng.allreduce_grads(algo=self.algo, adamw=hp, max_piece_elems=self.max_piece_elems, after_compute=first)
+        eng.comm_wait()
+        pair[1].record()
+        self._tail_events.append(pair)
+        del self._tail_events[:-32]
+        if self._fusing:
+            self._opt.end_fused_step(eng)
+        self._fusing = False
 
     def _reduce(self):
         if self._first_reduce:

@@ -18,7 +18,11 @@ for p in (ROOT, os.path.join(ROOT, "km-bart_amd"), os.path.dirname(os.path.abspa
 pytestmark = pytest.mark.gpu
 
 
-def test_single_rank_rccl_reducer_matches_plain_step():
+@pytest.mark.parametrize("mode", ["native", "native_rsag", "torch"])
+def test_single_rank_rccl_reducer_matches_plain_step(mode):
+    """mode native: the library's own communicator (kmb_comm_init / kmb_allreduce_grads: every bucket's ncclAllReduce and
+    the fused AdamW pieces enqueued from C++ on the library's communication stream); native_rsag: ncclReduceScatter ->
+    AdamW on the shard -> ncclAllGather; torch: the torch.distributed path (BucketedAllReducer)."""
     from oracle import goldenlib as G
     from oracle.make_golden import tiny_batch
     from kmbart.optim import AdamW
@@ -26,7 +30,7 @@ def test_single_rank_rccl_reducer_matches_plain_step():
     from test_model_gpu import build
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29533"
+    os.environ["MASTER_PORT"] = str({"native": 29533, "native_rsag": 29534, "torch": 29535}[mode])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -39,7 +43,8 @@ def test_single_rank_rccl_reducer_matches_plain_step():
 
         def run(wrap):
             model = build(ocfg, sd).train()
-            ddp = DistributedDataParallel(model, device_ids=[0], reduce_single_rank=True) if wrap else model
+            ddp = DistributedDataParallel(model, device_ids=[0], reduce_single_rank=True, native=(mode != "torch"),
+                                          algo="rsag" if mode == "native_rsag" else "allreduce") if wrap else model
             opt = AdamW(model.parameters(), lr=1e-3)
             opt.allow_overlap(True)
             if wrap:   # the production tail: AdamW of every piece behind its all-reduce on the communication stream
@@ -52,9 +57,16 @@ def test_single_rank_rccl_reducer_matches_plain_step():
                     grads = model._engine.grads.clone()
                 opt.step()
             torch.cuda.synchronize()
-            if wrap:
+            if wrap and mode == "torch":
                 assert ddp.reducer is not None and len(ddp.reducer.pieces) >= len(model._engine.buckets())
-                assert ddp.module is model
+            if wrap:
+                assert ddp.module is model and ddp.native == (mode != "torch")
+                rep = ddp.comm_report()
+                assert rep["rccl_ranks"] == 1 and rep["pieces"] >= len(model._engine.buckets()) and rep["fused_optimizer"]
+                if mode != "torch":
+                    assert rep["backend"] == "rccl-native" and rep["algo"] == ("rsag" if mode == "native_rsag" else "allreduce")
+                    ddp.gather_optimizer_state()      # a no-op all-gather on one rank; must not disturb anything
+                    torch.cuda.synchronize()
             assert model._engine.step_count == 3
             return losses, grads, model._engine, model._engine.params.clone()
 
@@ -82,14 +94,15 @@ def _n_gpus():
     return torch.cuda.device_count()   # counting devices does not initialise the GPU
 
 
+@pytest.mark.parametrize("algo", ["allreduce", "rsag"])
 @pytest.mark.parametrize("world", sorted({1, min(max(_n_gpus(), 1), 8)}))
-def test_multi_rank_rccl(world):
+def test_multi_rank_rccl(world, algo):
     """N ranks over RCCL on a multi-GPU node (world = min(device_count, 8)); on the one-GPU test box only the world = 1
     case exists, which still runs the worker end to end (process group, broadcast, bucketed all-reduce on the
     communication stream, fused optimizer tail, replica comparison)."""
     import subprocess
-    port = 29540 + world
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29540 + world + (20 if algo == "rsag" else 0)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", KMB_DP_ALGO=algo)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_rccl_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -100,5 +113,5 @@ def test_multi_rank_rccl(world):
     import json
     rep = json.loads(line[0][len("DP_RCCL_OK "):])
     print("[dp rccl world=%d]" % world, rep)
-    assert rep["rccl_ranks"] == world and rep["backend"] == "nccl" and rep["bytes_reduced_per_step"] > 0
-    assert rep["grad_rel_err"] < 1e-5
+    assert rep["rccl_ranks"] == world and rep["backend"] == "rccl-native" and rep["bytes_reduced_per_step"] > 0
+    assert rep["grad_rel_err"] < 1e-5 and rep["algo"] == (algo if 8 % world == 0 else "allreduce")
