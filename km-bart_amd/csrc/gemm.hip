@@ -949,6 +949,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 }
 
 
+#ifndef KMB_GEMM_DEVICE_ONLY   // (gemm_rolesplit.hip includes this file for the device helpers above and below only)
 // ------------------------------------------------------------------------------------------
 // "All rows" kernel: the vocabulary projection of a generation decode step (R = batch x beams <= 320 rows, N = 50320, K = 768,
 // forward layout, fp32 logits).  The 128x128 kernel re-reads the R activation rows for each of 394 column tiles and the tied
@@ -1039,6 +1040,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p) {
     }
   }
 }
+
+#endif  // KMB_GEMM_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------
 // v11: persistent 256x256 tile.  One workgroup per CU (grid = 256), four waves (2x2), each wave a 128x128 block of C
@@ -1931,6 +1934,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   retire();
 }
 
+#ifndef KMB_GEMM_DEVICE_ONLY
 // ------------------------------------------------------------------------------------------
 // Narrow tile for the generation path.  A decode step multiplies M = batch x beams rows (320 at the benchmark
 // setting) by every weight matrix: with 128x128 tiles that is 18-72 workgroups on 256 CUs and each launch costs a
@@ -2101,8 +2105,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_narrow(const KmbGemm p) {
 // (instruction fetch, not the stores, bounded the generic one), hoisted epilogue loads, hardware bf16 conversion,
 // split-K for the weight gradients, per-shape choice between the 128x128 and 256x256 tiles and the XCD tile order.
 
+#endif  // KMB_GEMM_DEVICE_ONLY
 }  // namespace
 
+#ifndef KMB_GEMM_DEVICE_ONLY   // host side: checks, launch rules, tuner
 void kmb_gemm_set_shared_device(int on) { g_shared_device = on ? 1 : 0; }
 
 const char* kmb_gemm_check(const KmbGemm& p) {
@@ -2162,9 +2168,11 @@ uint32_t* v11_sched_slot(hipStream_t stream) {
 }
 
 // variant 1: register-staged 128x128 (any K); 7: LDS-DMA + pipelined 128x128; 8: LDS-DMA + pipelined 256x256;
+// 10: role-split persistent 256x128 (eight waves: one group multiplies while the other fetches and runs the previous tile's epilogue);
 // 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192 (four waves); 14 / 15: persistent 256x256 / 256x192, eight waves
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
+  if (variant == 10) return kmb_gemm_rs_launch(p, stream);   // role-split persistent kernel (gemm_rolesplit.hip)
   if (variant == 11) {
     dim3 grid(v11_grid(p, BN4)), block(256);
     uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot(stream) : nullptr;
@@ -2272,6 +2280,7 @@ hipError_t launch_config(const KmbGemm& p, int cfg, hipStream_t stream) {
   if (cfg & 0x100) pf = false;
   if (cfg & 0x200) pf = p.a_kc != 0;
   q.tile_order = ((cfg >> 4) & 7) | (pf ? 2 : 0);
+  if (variant == 10 && p.a_kc && p.b_kc && p.N >= 32 * 256) q.tile_order |= 8;   // role-split: per-XCD ranges always; column blocks for wide outputs
   if (variant >= 11) {
     // Persistent variants: per-XCD contiguous tile ranges ALWAYS (bit 0), column blocks for wide outputs (bit 3).  The
     // tuner's back-to-back timing cannot see the difference (operands sit in the Infinity Cache there); inside a step
@@ -2439,14 +2448,15 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   }
   if (forced) {
     int v = forced;
+    if (v == 10 && !kmb_gemm_rs_ok(p)) v = 11;
     if (v == 11 && !v11_ok(p)) v = 8;
     if (v == 12 && !v11_ok(p, 128)) v = 8;
     if (v == 13 && !v11_ok(p, 192)) v = 8;
     if (v == 14 && !v11_ok(p)) v = 8;
     if (v == 15 && !v11_ok(p, 192)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
-    if (v != 1 && v != 7 && v != 8 && (v < 11 || v > 15)) v = 7;
-    if (p.act == 5 && (v < 11 || v == 13 || v == 15)) v = 11;
+    if (v != 1 && v != 7 && v != 8 && v != 10 && (v < 11 || v > 15)) v = 7;
+    if (p.act == 5 && v != 10 && (v < 11 || v == 13 || v == 15)) v = 11;
     KmbGemm q = p;
     q.tile_order = p.tile_order | (prefetch_a(p) ? 2 : 0);
     return launch_variant(v, q, stream);
@@ -2456,6 +2466,8 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return p.act == 5 ? launch_config(p, 11, stream) : launch_variant(7, p, stream);
+    // (variant 10, the role-split kernel of gemm_rolesplit.hip, is NOT a candidate: bit-identical and tested, but slower than
+    //  the persistent variants on every benchmark-batch shape but two -- DESIGN.md section 4 "Round 4"; KMB_GEMM_VARIANT=10 forces it)
     const int cands[16] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
                            14, 14 + 16, 15, 15 + 16,
                            7 + 16 * 5, 8 + 16 * 5};                                       // split-K only: slice-major
@@ -2477,12 +2489,13 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     }
     for (int c : cands) {
       if (exclude & (1u << (c & 15))) continue;
+      if ((c & 15) == 10 && !kmb_gemm_rs_ok(p)) continue;
       if ((c & 15) == 11 && !v11_ok(p)) continue;
       if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
       if ((c & 15) == 14 && !v11_ok(p)) continue;
       if ((c & 15) == 15 && !v11_ok(p, 192)) continue;
-      if (p.act == 5 && ((c & 15) < 11 || (c & 15) == 13 || (c & 15) == 15)) continue;   // lean epilogue of the 256- / 128-column persistent variants only
+      if (p.act == 5 && (c & 15) != 10 && ((c & 15) < 11 || (c & 15) == 13 || (c & 15) == 15)) continue;   // lean epilogue of the 256- / 128-column persistent variants (and the role-split one) only
       if (((c >> 4) & 4) && p.split_k <= 1) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;
@@ -2601,3 +2614,4 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   }
   return launch_config(p, it->second, stream);
 }
+#endif  // KMB_GEMM_DEVICE_ONLY
