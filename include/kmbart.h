@@ -200,6 +200,13 @@ int kmb_forward_ex(kmb_handle* h, const kmb_batch* batch, const kmb_forward_opts
 /* logits [B*T, kmb_logits_ld()] of the decoder states the LAST forward left in the workspace: `outputs[1]` of a training
  * forward (src/model/model.py:397-405) as one extra head GEMM instead of 1.6 GB written every step */
 int kmb_last_logits(kmb_handle* h, float* logits_out, void* stream);
+/* `output_hidden_states` / `output_attentions` of the forward still in the workspace (reference src/model/modules.py:143-165,
+ * transformers 3.0.2 BartDecoder): hidden state `index` of the encoder (which = 0: 0 .. encoder_layers, 0 = the embedding
+ * output, l + 1 = the output of layer l) or of the decoder (which = 1: 0 .. decoder_layers) as [rows, d_model] activations,
+ * and the self-attention probabilities of layer `layer` as fp32 [B, H, T, T], recomputed from the saved q | k and the rows'
+ * log-sum-exp (the fused attention kernels never store them).  bf16 product mode only. */
+int kmb_hidden_state(kmb_handle* h, int which, int index, kmb_bf16* out, void* stream);
+int kmb_attention_probs(kmb_handle* h, int which, int layer, float* out, void* stream);
 /* fp32 VALIDATION mode (1) / bf16 product mode (0, default).  Mode 1 keeps every activation in float and runs the
  * eval-mode forward on exact-fp32 kernels (csrc/fp32_validate.hip) against the fp32 master weights: parity evidence for
  * north_star's "logits within 1e-3 of the fp32 reference path", never the measured path.  Training, backward and

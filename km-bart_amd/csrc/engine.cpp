@@ -1298,6 +1298,36 @@ int kmb_forward_ex(kmb_handle* h, const kmb_batch* batch, const kmb_forward_opts
   return forward_impl(h, batch, nullptr, opts, train, need_grad, loss_out, logits_out, enc_out, stream);
 }
 
+int kmb_hidden_state(kmb_handle* h, int which, int index, kmb_bf16* out, void* stream) {
+  if (!h->have_hdec) return fail("kmb_hidden_state: no forward whose activations are still in the workspace");
+  if (h->fp32) return fail("kmb_hidden_state: not available in the fp32 validation mode");
+  const auto& xs = which == 0 ? h->xe : h->xd;
+  if ((which != 0 && which != 1) || index < 0 || index >= (int)xs.size() || !xs[index]) return fail("kmb_hidden_state: index out of range");
+  const size_t rows = which == 0 ? (size_t)h->Me : (size_t)h->Md;
+  HIPCHK(hipMemcpyAsync(out, xs[index], rows * h->d * sizeof(bf16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int kmb_attention_probs(kmb_handle* h, int which, int layer, float* out, void* stream) {
+  if (!h->have_hdec) return fail("kmb_attention_probs: no forward whose activations are still in the workspace");
+  if (h->fp32) return fail("kmb_attention_probs: not available in the fp32 validation mode");
+  const int d = h->d, B = h->bt.B;
+  if (which == 0) {
+    if (layer < 0 || layer >= (int)h->ea.size()) return fail("kmb_attention_probs: layer out of range");
+    const EncAct& a = h->ea[layer];
+    HIPCHK(kmb_attn_probs_launch(a.qkv, 3 * d, EP(a.qkv, d), 3 * d, a.lse, h->bt.attention_mask, 0, B, h->He, h->bt.S, h->bt.S, out,
+                                 (hipStream_t)stream));
+  } else if (which == 1) {
+    if (layer < 0 || layer >= (int)h->da.size()) return fail("kmb_attention_probs: layer out of range");
+    const DecAct& a = h->da[layer];
+    HIPCHK(kmb_attn_probs_launch(a.qkv, 3 * d, EP(a.qkv, d), 3 * d, a.lse1, h->bt.decoder_attention_mask, 1, B, h->Hd, h->bt.T, h->bt.T,
+                                 out, (hipStream_t)stream));
+  } else {
+    return fail("kmb_attention_probs: which must be 0 (encoder) or 1 (decoder)");
+  }
+  return 0;
+}
+
 int kmb_set_precision(kmb_handle* h, int fp32) {
   h->fp32 = fp32 != 0; h->have_fwd = false; h->have_hdec = false; h->gen.active = false;
   return 0;

@@ -133,3 +133,40 @@ hipError_t kmb_mean_rows_launch(const float* rows, int n, float factor, float de
   hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, stream, rows, n, factor, denom, out);
   return hipGetLastError();
 }
+
+namespace {
+// Attention probabilities of one self-attention, recomputed for `output_attentions` (reference src/model/modules.py:143-165;
+// HF 3.0.2 SelfAttention returns softmax(q k^T + masks) as [B, H, Tq, Tk]): the fused attention kernels never store them,
+// but they keep q | k (q already scaled) and the rows' log-sum-exp, so P[b,h,i,j] = exp(q_i . k_j - lse_i) with masked
+// entries exactly 0.  One workgroup per (b, h, i); not a hot path (diagnostic output of a forward).
+__global__ __launch_bounds__(64) void attn_probs_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                        const float* __restrict__ lse, const int64_t* __restrict__ key_mask, int causal,
+                                                        int H, int Tq, int Tk, float* __restrict__ out) {
+  const int i = blockIdx.x % Tq, h = (blockIdx.x / Tq) % H, b = blockIdx.x / (Tq * H);
+  const bf16_t* q = Q + ((size_t)b * Tq + i) * ldq + h * 64;
+  const float l = lse[((size_t)b * H + h) * Tq + i];
+  float qf[64];
+#pragma unroll
+  for (int e = 0; e < 64; e += 8) unpack8(*reinterpret_cast<const u32x4*>(q + e), qf + e);
+  for (int j = threadIdx.x; j < Tk; j += 64) {
+    const bf16_t* k = K + ((size_t)b * Tk + j) * ldk + h * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; e += 8) {
+      float kf[8];
+      unpack8(*reinterpret_cast<const u32x4*>(k + e), kf);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc = fmaf(qf[e + t], kf[t], acc);
+    }
+    const bool masked = (causal && j > i) || (key_mask != nullptr && key_mask[(size_t)b * Tk + j] == 0) || l == -INFINITY;
+    out[(((size_t)b * H + h) * Tq + i) * Tk + j] = masked ? 0.f : __expf(acc - l);
+  }
+}
+}  // namespace
+
+hipError_t kmb_attn_probs_launch(const bf16_t* Q, int ldq, const bf16_t* K, int ldk, const float* lse, const int64_t* key_mask,
+                                 int causal, int B, int H, int Tq, int Tk, float* out, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return hipSuccess;
+  hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)(B * H * Tq)), dim3(64), 0, stream, Q, ldq, K, ldk, lse, key_mask, causal, H, Tq, Tk, out);
+  return hipGetLastError();
+}

@@ -170,4 +170,7 @@ hipError_t kmb_gather_rows_bf16_launch(const bf16_t* src, int src_ld, const int3
 hipError_t kmb_scatter_add_rows_launch(const bf16_t* src, int src_ld, const int32_t* idx, float* acc, int rows, int cols,
                                        hipStream_t stream);
 hipError_t kmb_add_f32_into_bf16_launch(bf16_t* y, const float* a, size_t n, hipStream_t stream);
+// P[b,h,i,j] = exp(q_i . k_j - lse_i), 0 where masked: the attention probabilities the fused kernels do not store (head dim 64)
+hipError_t kmb_attn_probs_launch(const bf16_t* Q, int ldq, const bf16_t* K, int ldk, const float* lse, const int64_t* key_mask,
+                                 int causal, int B, int H, int Tq, int Tk, float* out, hipStream_t stream);
 hipError_t kmb_mean_rows_launch(const float* rows, int n, float factor, float denom, float* out, hipStream_t stream);

@@ -107,6 +107,8 @@ PROTOTYPES = {
     "kmb_forward": (C.c_int, [c_p, C.POINTER(KmbBatch), C.c_int, C.c_int, c_p, c_p, c_p, c_p]),
     "kmb_forward_ex": (C.c_int, [c_p, C.POINTER(KmbBatch), C.POINTER(KmbForwardOpts), C.c_int, C.c_int, c_p, c_p, c_p, c_p]),
     "kmb_last_logits": (C.c_int, [c_p, c_p, c_p]),
+    "kmb_hidden_state": (C.c_int, [c_p, C.c_int, C.c_int, c_p, c_p]),
+    "kmb_attention_probs": (C.c_int, [c_p, C.c_int, C.c_int, c_p, c_p]),
     "kmb_set_precision": (C.c_int, [c_p, C.c_int]),
     "kmb_act_bytes": (C.c_int, [c_p]),
     "kmb_reserve_head_rows": (C.c_int, [c_p, C.c_int]),

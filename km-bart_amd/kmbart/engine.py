@@ -206,7 +206,36 @@ class Engine:
             if logits is not None:
                 logits = logits.view(B, T, self.logits_ld)[:, :, : int(self.config.vocab_size)]
             self._last_bt = (B, T)
+            self._last_S = S
             return (loss, logits, enc, dec) if want_decoder_states else (loss, logits, enc)
+
+    def hidden_states(self, which):
+        """`output_hidden_states` of the forward still in the workspace: tuple of [B, T, d] activations of the encoder
+        (which = 0: embedding output + every layer's output) or decoder (which = 1) stack."""
+        B, T = self._last_bt
+        rows_T = T if which == 1 else self._last_S
+        n = int(self.config.encoder_layers if which == 0 else self.config.decoder_layers) + 1
+        out = []
+        with torch.cuda.device(self.device):
+            for i in range(n):
+                t = torch.empty((B, rows_T, int(self.config.d_model)), dtype=torch.bfloat16, device=self.device)
+                check(self.lib.kmb_hidden_state(self.h, which, i, ptr(t), _stream()))
+                out.append(t)
+        return tuple(out)
+
+    def attention_probs(self, which):
+        """`output_attentions`: tuple over layers of fp32 [B, H, T, T] self-attention probabilities."""
+        B, T = self._last_bt
+        Tq = T if which == 1 else self._last_S
+        H = int(self.config.encoder_attention_heads if which == 0 else self.config.decoder_attention_heads)
+        n = int(self.config.encoder_layers if which == 0 else self.config.decoder_layers)
+        out = []
+        with torch.cuda.device(self.device):
+            for l in range(n):
+                t = torch.empty((B, H, Tq, Tq), dtype=torch.float32, device=self.device)
+                check(self.lib.kmb_attention_probs(self.h, which, l, ptr(t), _stream()))
+                out.append(t)
+        return tuple(out)
 
     def last_logits(self):
         """fp32 logits [B,T,V] of the decoder states the last forward left in the workspace (one head GEMM)."""

@@ -339,8 +339,8 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
             return self._forward_cached(input_ids, image_features, attention_mask, encoder_outputs, decoder_input_ids,
                                         decoder_cached_states, unused.get("max_cache_length"))
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
+        output_attentions = self.config.output_attentions if output_attentions is None else output_attentions
+        output_hidden_states = self.config.output_hidden_states if output_hidden_states is None else output_hidden_states
         enc_states = None
         if encoder_outputs is not None:   # src/model/model.py:76-83: a tuple whose first element is the encoder output
             enc_states = encoder_outputs[0] if isinstance(encoder_outputs, (tuple, list)) else encoder_outputs
@@ -359,15 +359,31 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         loss, logits, enc = eng.forward(input_ids, image_features, attention_mask, decoder_input_ids,
                                         decoder_attention_mask, labels, train=self.training, need_grad=need_grad,
                                         want_logits=want_logits, encoder_states=enc_states)
+        # output_hidden_states / output_attentions (src/model/modules.py:143-165, transformers 3.0.2 BartDecoder; the tuple
+        # is decoder_outputs + encoder_outputs with empty entries filtered, src/model/model.py:100-103): decoder = the layers'
+        # INPUTS and their self-attention weights, encoder = the layers' inputs + the final output and the attention weights.
+        # Read back from the workspace of this forward (kmb_hidden_state / kmb_attention_probs).
+        dec_extra, enc_extra = (), ()
+        if output_hidden_states:
+            dec_extra += (eng.hidden_states(1)[:-1],)
+            if enc_states is None:
+                enc_extra += (list(eng.hidden_states(0)),)
+        if output_attentions:
+            dec_extra += (eng.attention_probs(1),)
+            if enc_states is None:
+                enc_extra += (list(eng.attention_probs(0)),)
+        if enc_states is not None and isinstance(encoder_outputs, (tuple, list)):
+            # a precomputed encoder tuple is passed through, empty entries filtered (_filter_out_falsey_values, model.py:102)
+            enc_extra = tuple(x for x in encoder_outputs[1:] if isinstance(x, torch.Tensor) or x)
         if labels is None:
-            return (logits, enc)
+            return (logits,) + dec_extra + (enc,) + enc_extra
         if need_grad:
             loss = _LossFn.apply(self._anchor, self, loss)
         else:
             loss = loss.view(())
         if logits is None:
             logits = LazyLogits(eng)
-        return (loss, logits, enc)
+        return (loss, logits) + dec_extra + (enc,) + enc_extra
 
     def _forward_cached(self, input_ids, image_features, attention_mask, encoder_outputs, decoder_input_ids,
                         decoder_cached_states, max_cache_length=None):
@@ -540,9 +556,14 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         assert 0 <= top_p <= 1, "`top_p` should be between 0 and 1."
         assert length_penalty > 0, "`length_penalty` should be strictly positive."
         assert isinstance(num_return_sequences, int) and num_return_sequences > 0
-        if repetition_penalty != 1.0 or no_repeat_ngram_size != 0 or bad_words_ids is not None:
-            raise NotImplementedError("repetition_penalty / no_repeat_ngram_size / bad_words_ids are not used by the "
-                                      "reference's generate_text (src/generation.py:22-32) and are not implemented")
+        assert repetition_penalty >= 1.0, "`repetition_penalty` should be >= 1."
+        assert isinstance(no_repeat_ngram_size, int) and no_repeat_ngram_size >= 0, "`no_repeat_ngram_size` should be a positive integer."
+        assert bad_words_ids is None or (isinstance(bad_words_ids, list) and isinstance(bad_words_ids[0], list)), \
+            "`bad_words_ids` is either `None` or a list of lists of tokens that should not be generated"
+        # the score post-processing of transformers 3.0.2 (postprocess_next_token_scores: mixins.py:150-235 validates these
+        # arguments, the loops apply them) needs every row's tokens on the host at every step: such searches take the
+        # step-by-step host loop (like beam sampling), not the pipelined one
+        processors_on = repetition_penalty != 1.0 or no_repeat_ngram_size > 0 or bad_words_ids is not None
         if not do_sample:
             if num_beams == 1:
                 assert num_return_sequences == 1, "Greedy decoding will always produce the same output"
@@ -584,7 +605,10 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             pending, keep = None, None
             while cur_len < max_length:
                 logits = eng.gen_step(cols[-1], cur_len - 1)[:, :V]
-                if eos_token_id is not None and cur_len < min_length:
+                if processors_on:
+                    _postprocess_next_token_scores(logits, torch.stack(cols, dim=1).tolist(), cur_len, min_length,
+                                                   eos_token_id, repetition_penalty, no_repeat_ngram_size, bad_words_ids)
+                elif eos_token_id is not None and cur_len < min_length:
                     logits[:, eos_token_id] = -float("inf")
                 if do_sample:
                     lg = logits / temperature if temperature != 1.0 else logits
@@ -652,7 +676,8 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 assert n_sent == num_beams, "Beam should always be full"
             return new_scores, new_tokens, new_idx
 
-        if not do_sample:
+        host_loop = do_sample or processors_on
+        if not host_loop:
             # Greedy beam search, pipelined: the device picks the next step's beams itself (kmb_beam_merge_select: the
             # first num_beams non-EOS candidates, exactly what the bookkeeping below sends on), so step t+1 is enqueued
             # before the host has seen step t.  The host replays the reference's bookkeeping one step behind from the
@@ -709,27 +734,37 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 cur_len += 1
             if pending is not None:
                 replay(pending)
-        while do_sample and cur_len < max_length:
-            # beam-search multinomial sampling (HF 3.0.2 _generate_beam_search, do_sample branch, reached from
-            # mixins.py:336-361 with generate_text's --do_sample/--top_p/--top_k and --num_beams): no forced BOS/EOS;
-            # 2*num_beams draws per batch item from softmax over the beams' filtered (log-prob + beam score) / T.
-            # The draw happens in torch, so this branch keeps the reference's step-by-step host loop.
-            logits = eng.gen_step(last_tokens, cur_len - 1)
-            # min_length: transformers 3.0.2 postprocess_next_token_scores sets the EOS score to -inf AFTER log_softmax
-            ban = eos_token_id if (eos_token_id is not None and cur_len < min_length) else -1
+        while host_loop and cur_len < max_length:
+            # The reference's step-by-step host loop (HF 3.0.2 _generate_beam_search), for the searches whose scores are
+            # post-processed on the host: beam-search multinomial sampling (do_sample branch, reached from mixins.py:336-361
+            # with generate_text's --do_sample/--top_p/--top_k and --num_beams: no forced BOS/EOS; 2*num_beams draws per batch
+            # item from softmax over the beams' filtered (log-prob + beam score) / T) and repetition_penalty /
+            # no_repeat_ngram_size / bad_words_ids (postprocess_next_token_scores on the log-probabilities).
+            logits = eng.gen_step(last_tokens, cur_len - 1)[:, :V].float()
+            if not do_sample:   # adjust_logits_during_generation (mixins.py:400-405): forced BOS / EOS, greedy beams only
+                force = cfg.bos_token_id if cur_len == 1 else (eos_token_id if (cur_len == max_length - 1 and eos_token_id is not None) else None)
+                if force is not None:
+                    kept = logits[:, force].clone()
+                    logits.fill_(-float("inf"))
+                    logits[:, force] = kept
             add = torch.tensor(beam_scores, dtype=torch.float32).to(dev)
-            sc = torch.log_softmax(logits[:, :V].float(), dim=-1)
-            if ban >= 0:
-                sc[:, ban] = -float("inf")
+            sc = torch.log_softmax(logits, dim=-1)
+            # min_length (EOS -inf AFTER log_softmax) and the other post-processing of transformers 3.0.2
+            _postprocess_next_token_scores(sc, seqs if processors_on else None, cur_len, min_length, eos_token_id,
+                                           repetition_penalty, no_repeat_ngram_size, bad_words_ids)
             sc = sc + add[:, None]
-            if temperature != 1.0:
-                sc = sc / temperature
-            sc = _top_k_top_p_filtering(sc, top_k=top_k, top_p=top_p, min_tokens_to_keep=2).view(B, num_beams * V)
-            drawn = sampler(torch.softmax(sc, dim=-1), k)
-            ns = torch.gather(sc, -1, drawn)
-            ns, order = torch.sort(ns, descending=True, dim=1)
-            next_scores = ns.cpu().tolist()
-            next_tokens = torch.gather(drawn, -1, order).cpu().tolist()
+            if do_sample:
+                if temperature != 1.0:
+                    sc = sc / temperature
+                sc = _top_k_top_p_filtering(sc, top_k=top_k, top_p=top_p, min_tokens_to_keep=2).view(B, num_beams * V)
+                drawn = sampler(torch.softmax(sc, dim=-1), k)
+                ns = torch.gather(sc, -1, drawn)
+                ns, order = torch.sort(ns, descending=True, dim=1)
+                next_scores = ns.cpu().tolist()
+                next_tokens = torch.gather(drawn, -1, order).cpu().tolist()
+            else:
+                ns, nt_ = torch.topk(sc.view(B, num_beams * V), k, dim=1, largest=True, sorted=True)
+                next_scores, next_tokens = ns.cpu().tolist(), nt_.cpu().tolist()
             new_scores, new_tokens, new_idx = bookkeeping(next_scores, next_tokens, cur_len)
             if all(done):
                 break
@@ -882,6 +917,47 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
         if logits is None:
             logits = LazyLogits(eng)
         return (out, logits)
+
+
+def _postprocess_next_token_scores(scores, prev_ids, cur_len, min_length, eos_token_id, repetition_penalty=1.0,
+                                   no_repeat_ngram_size=0, bad_words_ids=None):
+    """transformers 3.0.2 GenerationMixin.postprocess_next_token_scores on a device tensor `scores` [rows, V], in its
+    order: repetition penalty (CTRL: a score < 0 is multiplied by the penalty, a score >= 0 divided), EOS banned below
+    min_length, no-repeat n-grams (calc_banned_ngram_tokens), bad words (calc_banned_bad_words_ids, including its length
+    test against the number of ROWS).  prev_ids: the rows' tokens so far as Python lists (None: nothing but min_length).
+    The sets are built on the host, each kind is applied with one indexed update."""
+    dev = scores.device
+    if prev_ids is not None and repetition_penalty != 1.0:
+        rows = [i for i, row in enumerate(prev_ids) for _ in set(row)]
+        cols = [t for row in prev_ids for t in set(row)]
+        if rows:
+            ri, ci = torch.tensor(rows, device=dev), torch.tensor(cols, device=dev)
+            v = scores[ri, ci]
+            scores[ri, ci] = torch.where(v < 0, v * repetition_penalty, v / repetition_penalty)
+    if eos_token_id is not None and cur_len < min_length:
+        scores[:, eos_token_id] = -float("inf")
+    banned_rows, banned_cols = [], []
+    if prev_ids is not None and no_repeat_ngram_size > 0 and cur_len + 1 >= no_repeat_ngram_size:
+        n = no_repeat_ngram_size
+        for i, row in enumerate(prev_ids):
+            seen = {}
+            for ng in zip(*[row[j:] for j in range(n)]):
+                seen.setdefault(tuple(ng[:-1]), []).append(ng[-1])
+            for t in seen.get(tuple(row[cur_len + 1 - n:cur_len]), []):
+                banned_rows.append(i)
+                banned_cols.append(t)
+    if prev_ids is not None and bad_words_ids is not None:
+        n_rows = len(prev_ids)
+        for i, row in enumerate(prev_ids):
+            for seq in bad_words_ids:
+                assert len(seq) > 0, "Banned words token sequences {} cannot have an empty list".format(bad_words_ids)
+                head = list(seq[:-1])
+                if len(head) == 0 or (len(head) <= n_rows and row[-len(head):] == head):
+                    banned_rows.append(i)
+                    banned_cols.append(seq[-1])
+    if banned_rows:
+        scores[torch.tensor(banned_rows, device=dev), torch.tensor(banned_cols, device=dev)] = -float("inf")
+    return scores
 
 
 def _top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("inf"), min_tokens_to_keep=1):

@@ -183,7 +183,7 @@ def _lin(x, sd, prefix):
 
 
 def attention(sd, prefix, cfg, n_heads, query, key, key_padding_mask=None, causal_mask=None,
-              cache=None, static_kv=False, p_attn_drop=0.0, training=False):
+              cache=None, static_kv=False, p_attn_drop=0.0, training=False, probs_out=None):
     """HF3.0.2 `SelfAttention.forward`, batch-major.  query [B,Tq,D], key [B,Tk,D].
     q is scaled by head_dim**-0.5 BEFORE q.k^T; key padding via masked_fill(-inf).
     cache: dict with prev_key/prev_value [B,H,t,hd] (and prev_key_padding_mask)."""
@@ -211,6 +211,8 @@ def attention(sd, prefix, cfg, n_heads, query, key, key_padding_mask=None, causa
     if key_padding_mask is not None:  # True = pad
         w = w.masked_fill(key_padding_mask[:, None, None, :], NEG_INF)
     w = F.softmax(w, dim=-1)
+    if probs_out is not None:   # output_attentions: HF3.0.2 returns the weights [B, H, Tq, Tk] (before attention dropout)
+        probs_out.append(w)
     w = F.dropout(w, p=p_attn_drop, training=training)
     o = torch.matmul(w, v).transpose(1, 2).reshape(B, Tq, D)
     return _lin(o, sd, prefix + ".out_proj")
@@ -253,8 +255,12 @@ def _ffn_block(sd, p, cfg, x, drop, training):
     return _ln(r + h, sd, p + "final_layer_norm")
 
 
-def encoder_forward(sd, cfg, input_ids, image_features, attention_mask=None, training=False):
-    """src/model/modules.py:104-165 (batch-major; HF runs time-major, same arithmetic)."""
+def encoder_forward(sd, cfg, input_ids, image_features, attention_mask=None, training=False, taps=None):
+    """src/model/modules.py:104-165 (batch-major; HF runs time-major, same arithmetic).  taps: optional dict that receives
+    'hidden' (output_hidden_states: every layer's input and the final output, modules.py:143-160) and 'attn'
+    (output_attentions: every layer's self-attention weights)."""
+    hidden = taps.setdefault("hidden", []) if taps is not None else None
+    attn = taps.setdefault("attn", []) if taps is not None else None
     pad = attention_mask.eq(0) if attention_mask is not None else None
     scale = math.sqrt(cfg.d_model) if cfg.scale_embedding else 1.0
     S = input_ids.shape[1]
@@ -264,10 +270,14 @@ def encoder_forward(sd, cfg, input_ids, image_features, attention_mask=None, tra
     x = F.dropout(x, p=cfg.dropout, training=training)
     for i in range(cfg.encoder_layers):
         p = f"model.encoder.layers.{i}."
+        if hidden is not None:
+            hidden.append(x)
         a = attention(sd, p + "self_attn", cfg, cfg.encoder_attention_heads, x, x, key_padding_mask=pad,
-                      p_attn_drop=cfg.attention_dropout, training=training)
+                      p_attn_drop=cfg.attention_dropout, training=training, probs_out=attn)
         x = _ln(x + F.dropout(a, p=cfg.dropout, training=training), sd, p + "self_attn_layer_norm")
         x = _ffn_block(sd, p, cfg, x, cfg.dropout, training)
+    if hidden is not None:
+        hidden.append(x)
     return x
 
 
@@ -284,7 +294,7 @@ def prepare_decoder_masks(cfg, decoder_input_ids, decoder_attention_mask):
 
 
 def decoder_forward(sd, cfg, decoder_input_ids, enc_out, enc_attention_mask, dec_pad_mask, causal_mask,
-                    cache=None, use_cache=False, training=False):
+                    cache=None, use_cache=False, training=False, taps=None):
     """HF3.0.2 `BartDecoder.forward`.  With use_cache only the last token is embedded, at
     learned position (len-1)+2, and per-layer self K/V are appended; cross K/V are reused."""
     enc_pad = enc_attention_mask.eq(0) if enc_attention_mask is not None else None
@@ -302,13 +312,18 @@ def decoder_forward(sd, cfg, decoder_input_ids, enc_out, enc_attention_mask, dec
     x = F.dropout(x, p=cfg.dropout, training=training)
     if use_cache and cache is None:
         cache = [dict(self={}, encoder_decoder={}) for _ in range(cfg.decoder_layers)]
+    # taps (HF3.0.2 BartDecoder): 'hidden' = every layer's INPUT (no final entry), 'attn' = the SELF-attention weights
+    hidden = taps.setdefault("hidden", []) if taps is not None else None
+    attn = taps.setdefault("attn", []) if taps is not None else None
     for i in range(cfg.decoder_layers):
         p = f"model.decoder.layers.{i}."
         lc = cache[i] if use_cache else None
+        if hidden is not None:
+            hidden.append(x)
         a = attention(sd, p + "self_attn", cfg, cfg.decoder_attention_heads, x, x,
                       key_padding_mask=dec_pad_mask, causal_mask=causal_mask,
                       cache=lc["self"] if lc is not None else None,
-                      p_attn_drop=cfg.attention_dropout, training=training)
+                      p_attn_drop=cfg.attention_dropout, training=training, probs_out=attn)
         x = _ln(x + F.dropout(a, p=cfg.dropout, training=training), sd, p + "self_attn_layer_norm")
         a = attention(sd, p + "encoder_attn", cfg, cfg.decoder_attention_heads, x, enc_out,
                       key_padding_mask=enc_pad,
@@ -518,9 +533,70 @@ def top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=NEG_INF, min_
 
 
 @torch.no_grad()
+def calc_banned_ngram_tokens(prev_ids, no_repeat_ngram_size, cur_len):
+    """HF3.0.2 generation_utils.calc_banned_ngram_tokens: per row, the tokens that would complete an n-gram that already
+    occurs in the row."""
+    if cur_len + 1 < no_repeat_ngram_size:
+        return [[] for _ in prev_ids]
+    out = []
+    for row in prev_ids:
+        seen = {}
+        for ng in zip(*[row[i:] for i in range(no_repeat_ngram_size)]):
+            seen.setdefault(tuple(ng[:-1]), []).append(ng[-1])
+        out.append(seen.get(tuple(row[cur_len + 1 - no_repeat_ngram_size:cur_len]), []))
+    return out
+
+
+def calc_banned_bad_words_ids(prev_ids, bad_words_ids):
+    """HF3.0.2 generation_utils.calc_banned_bad_words_ids, including its length test against the NUMBER OF ROWS
+    (`len(tokens) > len(prev_input_ids)`, a quirk of that release)."""
+    n_rows = len(prev_ids)
+    out = []
+    for row in prev_ids:
+        banned = []
+        for seq in bad_words_ids:
+            assert len(seq) > 0, "Banned words token sequences {} cannot have an empty list".format(bad_words_ids)
+            head = list(seq[:-1])
+            if len(head) == 0:
+                match = True
+            elif len(head) > n_rows:
+                match = False
+            else:
+                match = row[-len(head):] == head
+            if match:
+                banned.append(seq[-1])
+        out.append(banned)
+    return out
+
+
+def postprocess_next_token_scores(scores, prev_ids, cur_len, min_length, eos, repetition_penalty=1.0,
+                                  no_repeat_ngram_size=0, bad_words_ids=None):
+    """HF3.0.2 GenerationMixin.postprocess_next_token_scores, in its order: repetition penalty (CTRL: a score < 0 is
+    multiplied by the penalty, a score >= 0 divided), EOS banned below min_length, no-repeat n-grams, bad words.
+    `scores` [rows, V] is modified in place (raw logits in the no-beam loop, log-probabilities in beam search);
+    prev_ids: list of the rows' token lists so far."""
+    if repetition_penalty != 1.0:
+        for i, row in enumerate(prev_ids):
+            for tok in set(row):
+                if scores[i, tok] < 0:
+                    scores[i, tok] *= repetition_penalty
+                else:
+                    scores[i, tok] /= repetition_penalty
+    if eos is not None and cur_len < min_length:
+        scores[:, eos] = NEG_INF
+    if no_repeat_ngram_size > 0:
+        for i, banned in enumerate(calc_banned_ngram_tokens(prev_ids, no_repeat_ngram_size, cur_len)):
+            scores[i, banned] = NEG_INF
+    if bad_words_ids is not None:
+        for i, banned in enumerate(calc_banned_bad_words_ids(prev_ids, bad_words_ids)):
+            scores[i, banned] = NEG_INF
+    return scores
+
+
 def generate(sd, cfg, input_ids, image_features, attention_mask=None, max_length=None, min_length=None,
              num_beams=None, num_return_sequences=None, early_stopping=None, length_penalty=None,
-             do_sample=False, top_k=0, top_p=1.0, temperature=1.0, return_scores=False, sampler=None, **unused):
+             do_sample=False, top_k=0, top_p=1.0, temperature=1.0, return_scores=False, sampler=None,
+             repetition_penalty=1.0, no_repeat_ngram_size=0, bad_words_ids=None, **unused):
     """Greedy / sampling without beams (num_beams==1) and beam search with or without multinomial sampling.
     mixins.py:150-384 -> HF3.0.2 _generate_no_beam_search / _generate_beam_search.  `sampler(probs, n)` replaces
     torch.multinomial (tests feed both implementations the same draws)."""
@@ -561,8 +637,8 @@ def generate(sd, cfg, input_ids, image_features, attention_mask=None, max_length
         unfinished = torch.ones(B, dtype=torch.long)
         while cur_len < max_length:
             logits, cache = _decode_logits(sd, cfg, ids, enc_out, attention_mask, cache)
-            if eos is not None and cur_len < min_length:
-                logits[:, eos] = NEG_INF
+            postprocess_next_token_scores(logits, ids.tolist(), cur_len, min_length, eos, repetition_penalty,
+                                          no_repeat_ngram_size, bad_words_ids)
             if do_sample:
                 lg = logits / temperature if temperature != 1.0 else logits
                 lg = top_k_top_p_filtering(lg, top_k=top_k, top_p=top_p)
@@ -599,8 +675,8 @@ def generate(sd, cfg, input_ids, image_features, attention_mask=None, max_length
             logits.fill_(NEG_INF)
             logits[:, eos] = keep
         scores = F.log_softmax(logits, dim=-1)
-        if eos is not None and cur_len < min_length:   # postprocess_next_token_scores: on the log-probabilities
-            scores[:, eos] = NEG_INF
+        postprocess_next_token_scores(scores, ids.tolist(), cur_len, min_length, eos, repetition_penalty,
+                                      no_repeat_ngram_size, bad_words_ids)   # on the log-probabilities
         if do_sample:
             _scores = scores + beam_scores[:, None]
             if temperature != 1.0:

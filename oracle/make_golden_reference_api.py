@@ -139,7 +139,70 @@ def dump_generate_text():
     return out
 
 
+def processors_batch():
+    """copy-task inputs whose event text REPEATS tokens and bigrams (the model reverses the text, so the plain search
+    repeats them too and the repetition penalty / n-gram ban have something to act on)"""
+    b = copy_task_batch(21, 4)
+    mask = b["input_ids"] == G.TINY["img_feat_id"]
+    for i in range(4):
+        r = int(mask[i].sum())
+        ev = b["input_ids"][i, 4 + r:]
+        e = int((ev < G.TINY_SPECIAL_BASE).long().cumprod(0).sum())     # event tokens up to </event>
+        if e >= 4:
+            ev[2] = ev[0]
+            ev[3] = ev[1]            # a b a b ...
+        if e >= 6:
+            ev[5] = ev[0]
+    return b
+
+
+def dump_generate_processors():
+    """Score post-processing of generate (repetition_penalty / no_repeat_ngram_size / bad_words_ids; reference
+    src/model/mixins.py:150-235 validates them, transformers 3.0.2 postprocess_next_token_scores applies them): the oracle's
+    restatement on the trained tiny fixture, cross-checked against transformers 5.15 `generate()` (same processors, the
+    bad-words length quirk of 3.0.2 does not trigger in these cases) -> tests/golden/tiny_generate_processors.json."""
+    from transformers.modeling_outputs import BaseModelOutput
+    from .make_golden import hf_model
+    cfg, sd = G.tiny_config(), G.trained_state_dict()
+    b = processors_batch()
+    hf = hf_model(cfg, sd)
+    with torch.no_grad():
+        enc = O.encoder_forward(sd, cfg, b["input_ids"], b["image_features"], b["attention_mask"])
+    plain = O.generate(sd, cfg, b["input_ids"], b["image_features"], b["attention_mask"], num_beams=3, max_length=12, early_stopping=True)
+    bad = [[int(plain[0, 2])], [int(plain[1, 2]), int(plain[1, 3])]]     # a token and a bigram the plain search produces
+    cases = [dict(num_beams=3, max_length=12, early_stopping=True, repetition_penalty=200.0),
+             dict(num_beams=3, max_length=12, early_stopping=True, no_repeat_ngram_size=2),
+             dict(num_beams=3, max_length=12, early_stopping=True, bad_words_ids=bad),
+             dict(num_beams=4, num_return_sequences=2, max_length=12, early_stopping=True, repetition_penalty=50.0,
+                  no_repeat_ngram_size=3, bad_words_ids=bad),
+             dict(num_beams=1, max_length=12, repetition_penalty=1.3, no_repeat_ngram_size=2, bad_words_ids=bad)]
+    out = {"generated_by": "oracle/make_golden_reference_api.py::dump_generate_processors", "seed": 21, "batch": 4,
+           "plain_ids": plain.tolist(), "cases": []}
+    for kw in cases:
+        beams = kw.get("num_beams", 1)
+        r = O.generate(sd, cfg, b["input_ids"], b["image_features"], b["attention_mask"], return_scores=beams > 1, **kw)
+        ids = r[0] if beams > 1 else r
+        h = hf.generate(encoder_outputs=BaseModelOutput(last_hidden_state=enc.clone()), attention_mask=b["attention_mask"],
+                        forced_bos_token_id=0 if beams > 1 else None, forced_eos_token_id=2 if beams > 1 else None,
+                        decoder_start_token_id=0, do_sample=False, **kw)
+        L = max(h.shape[1], ids.shape[1])
+        same = bool((torch.nn.functional.pad(h, (0, L - h.shape[1]), value=1) ==
+                     torch.nn.functional.pad(ids, (0, L - ids.shape[1]), value=1)).all())
+        changed = (ids.shape != plain.shape or not bool((ids == plain).all())) if beams > 1 and kw.get("num_return_sequences", 1) == 1 else None
+        if changed is not None:
+            assert changed, ("the option does not change this search: the case would test nothing", kw)
+        print("[processors]", kw, "== transformers 5.15" if same else "!= transformers 5.15", "| differs from the plain search:", changed)
+        assert same, kw
+        rec = {"kwargs": kw, "ids": ids.tolist(), "identical_to_transformers_5_15": same}
+        if beams > 1:
+            rec["scores"] = [float(x) for x in r[1]]
+        out["cases"].append(rec)
+    json.dump(out, open(os.path.join(GOLD, "tiny_generate_processors.json"), "w"))
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     dump_config()
     dump_generate_text()
+    dump_generate_processors()

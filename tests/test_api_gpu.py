@@ -328,3 +328,65 @@ def test_embedding_accessors_and_resize():
     ref = O.forward(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], b["decoder_input_ids"],
                     b["decoder_attention_mask"], b["labels"])[0]
     assert abs(float(loss) - float(ref)) / float(ref) < 1e-3
+
+
+def test_generate_score_processors_follow_the_fixture(gold_dir):
+    """repetition_penalty / no_repeat_ngram_size / bad_words_ids in generate (reference src/model/mixins.py:150-235;
+    transformers 3.0.2 postprocess_next_token_scores): token ids equal to the fixture the oracle wrote (each case identical
+    to transformers 5.15 generate() there), beam search and greedy, and the argument checks of the reference."""
+    import json
+    import os
+    from oracle.make_golden_reference_api import processors_batch
+    fx = json.load(open(os.path.join(gold_dir, "tiny_generate_processors.json")))
+    ocfg = G.tiny_config()
+    model = build(ocfg, G.trained_state_dict()).eval()
+    b = processors_batch()
+    kwb = dev_batch(b)
+    plain = model.generate(num_beams=3, max_length=12, early_stopping=True, **kwb)
+    assert plain.cpu().tolist() == fx["plain_ids"]
+    for case in fx["cases"]:
+        kw = case["kwargs"]
+        out = model.generate(return_scores=kw.get("num_beams", 1) > 1, **kw, **kwb)
+        ids = out[0] if isinstance(out, tuple) else out
+        assert ids.cpu().tolist() == case["ids"], (kw, ids.cpu().tolist(), case["ids"])
+        if isinstance(out, tuple):
+            assert torch.allclose(out[1].float(), torch.tensor(case["scores"]), atol=3e-2), kw
+    with pytest.raises(AssertionError):
+        model.generate(repetition_penalty=0.5, **kwb)
+    with pytest.raises(AssertionError):
+        model.generate(bad_words_ids=[1, 2], **kwb)
+
+
+def test_output_hidden_states_and_attentions_follow_the_oracle():
+    """forward(output_hidden_states=True, output_attentions=True) (reference src/model/modules.py:143-165, transformers
+    3.0.2 BartDecoder): (logits, decoder layer inputs, decoder self-attention weights, encoder states, encoder hidden
+    states, encoder attention weights) against the oracle's taps; the probabilities are recomputed from the saved q | k
+    and log-sum-exp by kmb_attention_probs."""
+    ocfg = G.tiny_config()
+    sd = G.golden_state_dict(ocfg, seed=17)
+    b = tiny_batch(seed=23)                       # ragged: encoder and decoder padding masks
+    model = build(ocfg, sd).eval()
+    with torch.no_grad():
+        out = model(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
+                    attention_mask=b["attention_mask"].to(DEV), decoder_input_ids=b["decoder_input_ids"].to(DEV),
+                    decoder_attention_mask=b["decoder_attention_mask"].to(DEV), output_hidden_states=True, output_attentions=True)
+    logits, dec_hidden, dec_attn, enc, enc_hidden, enc_attn = out
+    et, dt = {}, {}
+    enc_ref = O.encoder_forward(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], taps=et)
+    pm, causal = O.prepare_decoder_masks(ocfg, b["decoder_input_ids"], b["decoder_attention_mask"])
+    O.decoder_forward(sd, ocfg, b["decoder_input_ids"], enc_ref, b["attention_mask"], pm, causal, taps=dt)
+    assert len(enc_hidden) == ocfg.encoder_layers + 1 and len(enc_attn) == ocfg.encoder_layers
+    assert len(dec_hidden) == ocfg.decoder_layers and len(dec_attn) == ocfg.decoder_layers
+    am, dm = b["attention_mask"].bool(), b["decoder_attention_mask"].bool()
+    for got, ref in zip(enc_hidden, et["hidden"]):
+        assert rel(got.cpu()[am], ref[am]) < ACT_TOL
+    for got, ref in zip(dec_hidden, dt["hidden"]):
+        assert rel(got.cpu()[dm], ref[dm]) < ACT_TOL
+    for got, ref in zip(enc_attn, et["attn"]):        # rows of padded queries are unspecified in both; compare valid queries
+        g_, r_ = got.cpu().permute(0, 2, 1, 3)[am], ref.permute(0, 2, 1, 3)[am]
+        assert float((g_ - r_).abs().max()) < 2e-2 and float((g_.sum(-1) - 1).abs().max()) < 2e-2
+    for got, ref in zip(dec_attn, dt["attn"]):
+        g_, r_ = got.cpu().permute(0, 2, 1, 3)[dm], ref.permute(0, 2, 1, 3)[dm]
+        assert float((g_ - r_).abs().max()) < 2e-2 and float((g_.sum(-1) - 1).abs().max()) < 2e-2
+        assert float(torch.triu(got.cpu(), 1).abs().max()) == 0.0      # causal: nothing above the diagonal
+    assert rel(enc.cpu()[am], enc_ref[am]) < ACT_TOL

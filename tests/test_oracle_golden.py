@@ -131,3 +131,21 @@ def test_beam_sampling_bookkeeping():
     a2 = O.generate(sd, cfg, b["input_ids"], b["image_features"], b["attention_mask"], sampler=sampler_for(1), **kw)
     assert a.shape[0] == 6 and torch.equal(a, a2)
     assert (a[:, 0] == cfg.decoder_start_token_id).all() and not (a[:, 1:4] == cfg.eos_token_id).any()
+
+
+def test_generate_score_processors_fixture(gold_dir):
+    """repetition_penalty / no_repeat_ngram_size / bad_words_ids (transformers 3.0.2 postprocess_next_token_scores as
+    restated in the oracle): the committed fixture (written by oracle/make_golden_reference_api.py, where every case was
+    identical to transformers 5.15 generate()) is reproduced, and every option changes its search."""
+    import json
+    import os
+    from oracle.make_golden_reference_api import processors_batch
+    fx = json.load(open(os.path.join(gold_dir, "tiny_generate_processors.json")))
+    cfg, sd = G.tiny_config(), G.trained_state_dict()
+    b = processors_batch()
+    for case in fx["cases"]:
+        kw = case["kwargs"]
+        ids = O.generate(sd, cfg, b["input_ids"], b["image_features"], b["attention_mask"], **kw)
+        assert ids.tolist() == case["ids"], kw
+        assert case["identical_to_transformers_5_15"]
+    assert fx["cases"][0]["ids"] != fx["plain_ids"] and fx["cases"][1]["ids"] != fx["plain_ids"]
