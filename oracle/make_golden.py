@@ -2,9 +2,10 @@
 
     python -m oracle.make_golden            # from /root/repo
 
-It needs `/root/reference` (for the reference's own `src.training.fine_tune`, `src.generation`
-and `src.model.config`) and the installed transformers 5.15 BART (independent cross-check).
-Neither travels to the GPU box; only the small vectors written here do.
+It needs `/root/reference` (it imports the reference's own `src.training` -- `fine_tune` -- and reads
+`config/vcg_base.json`; the reference's `src.model.config` and `src.generation` are imported by the sibling script
+`oracle/make_golden_reference_api.py`, which pins rows a1 and a15 on them) and the installed transformers 5.15 BART
+(independent cross-check).  Neither travels to the GPU box; only the small vectors written here do.
 
 Steps
  1. cross-check `oracle.kmbart_oracle.forward` (+ autograd) against transformers 5.15
