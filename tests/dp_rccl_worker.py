@@ -29,6 +29,8 @@ def main():
     from test_model_gpu import build
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    if os.environ.get("KMB_TEST_ONE_DEVICE") == "1":   # probe: several ranks on ONE device (RCCL normally refuses duplicate devices)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
