@@ -96,6 +96,27 @@ def test_unbound_handle_refuses_to_run(lib):
         lib.kmb_destroy(h)
 
 
+def test_exchange_without_a_communicator_fails_loudly(lib):
+    """kmb_allreduce_grads / kmb_comm_wait / kmb_comm_broadcast_params before kmb_comm_init: an error, not a silent no-op
+    (a data-parallel job whose gradients are not exchanged would train N different models)."""
+    h = C.c_void_p()
+    check(lib.kmb_create(C.byref(KmbConfig(**VCG_BASE)), C.byref(h)))
+    try:
+        rank, world = C.c_int32(-1), C.c_int32(-1)
+        check(lib.kmb_comm_info(h, C.byref(rank), C.byref(world)))
+        assert world.value == 0
+        assert lib.kmb_allreduce_grads(h, None, None) != 0 and b"communicator" in lib.kmb_last_error()
+        assert lib.kmb_comm_wait(h, None) != 0
+        assert lib.kmb_comm_broadcast_params(h, 0, None) != 0
+        assert lib.kmb_comm_gather_moments(h, None) != 0
+        assert lib.kmb_comm_pieces(h, 0) >= lib.kmb_bucket_count(h)       # every bucket is at least one piece
+        assert lib.kmb_comm_pieces(h, 1 << 20) > lib.kmb_comm_pieces(h, 0)  # 4 MB pieces: more of them
+        assert lib.kmb_comm_destroy(h) == 0                                # idempotent
+        assert lib.kmb_gen_encoder_states(h, None, None) != 0 and lib.kmb_hidden_state(h, 0, 0, None, None) != 0
+    finally:
+        lib.kmb_destroy(h)
+
+
 def test_no_cpu_fallback():
     import torch
     from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration
