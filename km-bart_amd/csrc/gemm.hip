@@ -1195,24 +1195,36 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
   if (ACT == 2) { side = p.aux + (size_t)(row0w + lr) * p.ld_aux + gcol; ld_side = (size_t)p.ld_aux; }
   constexpr bool SIDE = RES || ACT == 2;
   static_assert(!(RES && ACT == 2), "one side stream");
-  // side loads run two chunks ahead of their use (a chunk is ~0.3 us, an HBM miss longer)
-  u32x4 s0[NIT], s1[NIT], s2[NIT];
+  // Side loads run two chunks ahead of their use (a chunk is ~0.3 us, an HBM miss longer).  The chunks are walked in pairs:
+  // even chunks keep their side values in sE / hE, odd ones in sO / hO; a chunk first consumes its registers (unpacks them)
+  // and then requests chunk i + 2 into the SAME registers, so the loop-carried value is defined by the load itself.  (Rounds
+  // 1-3 rotated three register sets, s0 <- s1 <- s2, at the bottom of a one-chunk loop: the copy s1 <- s2 is a USE of the load
+  // issued in that same iteration, so hipcc put `s_waitcnt vmcnt(0)` into every chunk -- the prefetch distance was zero and
+  // each chunk also waited for its own stores: 10 us of the fc2 data-gradient tile's epilogue, tools/epilogue_burst.py.)
+  // The eight-wave kernels (NIT = 2: 128 registers in all; with the pair loop they spilled, and a scratch access in the K
+  // loop breaks its counted vmcnt waits) use ONE register set and a one-chunk distance: consume, request chunk i + 1, compute
+  // chunk i -- their second wave per SIMD covers the rest.
+  constexpr bool PAIRS = NIT == 4;
+  constexpr int AHEAD = PAIRS ? 2 : 1;
+  u32x4 sE[NIT];
+  [[maybe_unused]] u32x4 sO[NIT];
   if (SIDE) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      s0[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(RPI * it) * ld_side);
-      s1[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 + RPI * it) * ld_side);
+      sE[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(RPI * it) * ld_side);
+      if constexpr (PAIRS) sO[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 + RPI * it) * ld_side);
     }
   }
   // act 5: the rows' shifts, loaded like the side operand two chunks ahead of their use (a load at the point of use exposed
   // its latency in every row-iteration: the head's forward GEMM 2.24 -> 3.19 ms)
-  float h0[NIT], h1[NIT], h2[NIT];
+  float hE[NIT];
+  [[maybe_unused]] float hO[NIT];
   const float* shift_base = ACT == 5 ? p.row_shift + row0w + lr : nullptr;
   if constexpr (ACT == 5) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      h0[it] = shift_base[RPI * it];
-      h1[it] = shift_base[16 + RPI * it];
+      hE[it] = shift_base[RPI * it];
+      if constexpr (PAIRS) hO[it] = shift_base[16 + RPI * it];
     }
   }
   auto stage_chunk = [&](int i) {
@@ -1227,9 +1239,29 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
       default: stage(acc[7]); break;
     }
   };
-  stage_chunk(0);
-#pragma unroll 1
-  for (int i = 0; i < WROWS / 16; ++i) {
+  static_assert((WROWS / 16) % 2 == 0, "chunks are walked in pairs");
+  auto chunk = [&](const int i, u32x4 (&sv)[NIT], float (&hv)[NIT]) {
+    // this chunk's side values out of their registers, then chunk i + 2's requested into them (the last two chunks re-read
+    // rows that are in cache; never used)
+    [[maybe_unused]] float su[SIDE ? NIT : 1][8];
+    [[maybe_unused]] float hc[ACT == 5 ? NIT : 1];
+    const int ahead = i + AHEAD < WROWS / 16 ? i + AHEAD : WROWS / 16 - 1;
+    if (SIDE) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) unpack8(sv[it], su[it]);
+      __builtin_amdgcn_sched_barrier(0);   // the unpacks stay in front of the reload of their source registers
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) sv[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 * ahead + RPI * it) * ld_side);
+    }
+    if constexpr (ACT == 5) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) hc[it] = hv[it];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(hc[it]));   // a value of its own, not an alias of the register being reloaded
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) hv[it] = shift_base[16 * ahead + RPI * it];
+    }
     // this chunk's rows out of LDS first, then the next chunk's accumulators into the same image: the LDS executes
     // a wave's accesses in order, so the writes queue behind the reads and their latency hides under this chunk's math
     f32x4 lo4[NIT], hi4[NIT];
@@ -1240,16 +1272,6 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
     }
     asm volatile("" ::: "memory");
     if (i + 1 < WROWS / 16) stage_chunk(i + 1);
-    if (SIDE) {
-      const int ahead = i + 2 < WROWS / 16 ? i + 2 : WROWS / 16 - 1;   // the last two chunks re-read rows that are in cache (never used)
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) s2[it] = *reinterpret_cast<const u32x4*>(side + (size_t)(16 * ahead + RPI * it) * ld_side);
-    }
-    if constexpr (ACT == 5) {
-      const int ahead = i + 2 < WROWS / 16 ? i + 2 : WROWS / 16 - 1;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) h2[it] = shift_base[16 * ahead + RPI * it];
-    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const f32x4 lo = lo4[it];
@@ -1266,7 +1288,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
         // shifted value at the label's column go to the side buffers (see KmbGemm)
         static_assert(ACT != 5 || WCOLS == 64 || WCOLS == 128, "act 5: 64- or 128-column wave blocks");
         const int grow = row0w + lr + 16 * i + RPI * it;
-        const float c = h0[it];
+        const float c = hc[it];
         const kmb_f32x2 c2 = {c, c};
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] - c2;
@@ -1313,10 +1335,8 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
           for (int e = 0; e < 4; ++e) v[e] = gelu2(v[e]);
         }
       } else if (ACT == 2) {
-        float u[8];
-        unpack8(s0[it], u);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * kmb_f32x2{u[2 * e], u[2 * e + 1]};
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * kmb_f32x2{su[it][2 * e], su[it][2 * e + 1]};
       }
       if (DROP) {
         const uint32_t grow = (uint32_t)(row0w + lr + 16 * i + RPI * it);
@@ -1328,10 +1348,8 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
         }
       }
       if (RES) {
-        float rr[8];
-        unpack8(s0[it], rr);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] + kmb_f32x2{rr[2 * e], rr[2 * e + 1]};
+        for (int e = 0; e < 4; ++e) v[e] = v[e] + kmb_f32x2{su[it][2 * e], su[it][2 * e + 1]};
       }
       if (CS) {
 #pragma unroll
@@ -1351,14 +1369,17 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 #endif
       }
     }
-    if (SIDE) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) { s0[it] = s1[it]; s1[it] = s2[it]; }
+  };
+  stage_chunk(0);
+  if constexpr (PAIRS) {
+#pragma unroll 1
+    for (int i = 0; i < WROWS / 16; i += 2) {
+      chunk(i, sE, hE);
+      chunk(i + 1, sO, hO);
     }
-    if constexpr (ACT == 5) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) { h0[it] = h1[it]; h1[it] = h2[it]; }
-    }
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < WROWS / 16; ++i) chunk(i, sE, hE);
   }
   if (CS) {
     float csum[8];
@@ -1473,6 +1494,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     __syncthreads();
   }
   if (first_tile >= range1) { retire(); return; }
+#ifdef KMB_DIAG
+  // (tools/epilogue_burst.py) KMB_GEMM_STAGGER = s: the workgroups start in four groups, s half-microseconds apart, so that
+  // their epilogues -- a burst of 64 MB of stores when all 256 workgroups reach them together -- are spread over a tile time
+  if (const int stg = (p.tile_order >> 16) & 255) {
+    const int q = ((int)blockIdx.x >> 3) & 3;
+    for (int i = 0; i < q * stg; ++i) __builtin_amdgcn_s_sleep(18);
+  }
+#endif
   const int nt = p.K / BK;   // >= 2 (launcher)
   constexpr int A_BYTES = BM4 * BK * 2;
   const size_t stepA = A_KC ? (size_t)BK * 2 : (size_t)BK * p.lda * 2;
@@ -2143,7 +2172,12 @@ namespace {
 // one workgroup per CU; fewer when there are fewer tiles (a multiple of 8: the per-XCD tile ranges)
 unsigned v11_grid(const KmbGemm& p, int bn) {
   const long tiles = (long)((p.M + BM4 - 1) / BM4) * ((p.N + bn - 1) / bn);
-  return tiles >= 256 ? 256u : (unsigned)(tiles & ~7L);
+  unsigned g = tiles >= 256 ? 256u : (unsigned)(tiles & ~7L);
+  if (const char* e = KMB_DIAG_ENV("KMB_GEMM_GRID")) {   // diagnostic build (tools/epilogue_burst.py): fewer persistent workgroups, read per launch
+    const unsigned v = (unsigned)atoi(e) & ~7u;
+    if (v >= 8u && v < g) g = v;
+  }
+  return g;
 }
 
 // Tile counters of the persistent variants: 16 words per launch, zeroed once; the last workgroup of a launch leaves its
@@ -2315,6 +2349,8 @@ hipError_t launch_config(const KmbGemm& p, int cfg, hipStream_t stream) {
     if (so == 0) q.tile_order &= ~4;
     else if (so == 1) q.tile_order |= 5;
   }
+  if (const char* e = KMB_DIAG_ENV("KMB_GEMM_STAGGER"))   // diagnostic build: start delay of a persistent workgroup, bits 16-23 (see gemm_kernel_v11)
+    q.tile_order |= (atoi(e) & 255) << 16;
   if (p.act == 5) q.tile_order &= ~256;   // (diagnostic build) the store ablation has no exp / row-sum form: act 5 always takes its lean epilogue
   return launch_variant(variant, q, stream);
 }
