@@ -14,6 +14,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream);
 const char* kmb_gemm_allrows_check(const KmbGemm& p);
 hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream);
 void kmb_gemm_set_shared_device(int on);   // persistent variants: hand out every tile dynamically
+// variant 9 (gemm_pair.hip): two persistent 256 x 128 workgroups per CU, 32-deep stages (forward layout)
+bool kmb_gemm_pair_ok(const KmbGemm& p);
+hipError_t kmb_gemm_pair_launch(const KmbGemm& p, hipStream_t stream);
 // variant 10 (gemm_rolesplit.hip): role-split persistent kernel, epilogue of tile t under the MFMAs of tile t + 1
 bool kmb_gemm_rs_ok(const KmbGemm& p);
 hipError_t kmb_gemm_rs_launch(const KmbGemm& p, hipStream_t stream);
