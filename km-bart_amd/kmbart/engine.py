@@ -411,6 +411,13 @@ class Engine:
         self.comm_world = world
         return rank, world
 
+    def comm_destroy(self):
+        """Drops the library's communicator (the data-parallel wrapper's fallback to torch.distributed when the native
+        bootstrap failed on another rank)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_comm_destroy(self.h))
+        self.comm_world = 0
+
     def comm_broadcast_params(self, root=0):
         with torch.cuda.device(self.device):
             check(self.lib.kmb_comm_broadcast_params(self.h, int(root), _stream()))

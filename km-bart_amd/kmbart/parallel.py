@@ -144,13 +144,34 @@ class DistributedDataParallel(torch.nn.Module):
             algo = os.environ.get("KMB_DP_ALGO", "allreduce")
         if algo not in ("allreduce", "rsag"):
             raise ValueError("algo must be 'allreduce' or 'rsag'")
-        if active and native and grad_dtype is None and dist.get_backend(process_group) == "nccl":
+        self.native_error = None
+        use_native = bool(active and native and grad_dtype is None and dist.get_backend(process_group) == "nccl")
+        if use_native:
+            # The library's communicator is created here, by a collective call (ncclCommInitRank).  If that -- or the
+            # parameter broadcast over it -- raises on any rank, EVERY rank takes the torch.distributed path below instead
+            # (same RCCL, torch's communicator): the ranks agree on the outcome through the bootstrap group, the reason is
+            # printed and kept for comm_report().  A failure is never silent and never a CPU path.
+            ok = 1
+            try:
+                eng.comm_init(process_group)
+                eng.comm_broadcast_params(0)      # C2: parameters and the logits-bias buffer start identical on every rank
+            except Exception as e:                # noqa: BLE001 -- any failure of the native bootstrap takes the fallback
+                ok, self.native_error = 0, "%s: %s" % (type(e).__name__, e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+            if int(flag.item()) != 1:
+                if ok:
+                    self.native_error = "the native RCCL bootstrap failed on another rank"
+                    eng.comm_destroy()
+                import sys
+                print("[kmbart] native RCCL exchange unavailable (%s): using the torch.distributed path" % self.native_error,
+                      file=sys.stderr, flush=True)
+                use_native = False
+        if use_native:
             # native exchange: the library's own communicator and communication stream (module docstring)
             self.native = True
             self.algo = 1 if (algo == "rsag" and 8 % self.world == 0) else 0
             self.max_piece_elems = max_bucket_mb * (1 << 20) // 4
-            eng.comm_init(process_group)
-            eng.comm_broadcast_params(0)      # C2: parameters and the logits-bias buffer start identical on every rank
             self._opt = None
             module._post_backward = self._reduce_native
             from . import _lib
@@ -218,7 +239,8 @@ class DistributedDataParallel(torch.nn.Module):
         if self._tail_events:
             torch.cuda.synchronize(self.engine.device)
             tails = sorted(a.elapsed_time(b) for a, b in self._tail_events)
-        return {"rccl_ranks": self.world, "backend": r.backend, "buckets": len(self.engine.buckets()),
+        return {"rccl_ranks": self.world, "backend": r.backend, "native_fallback": self.native_error,
+                "buckets": len(self.engine.buckets()),
                 "pieces": len(r.pieces), "bytes_reduced_per_step": int(sum(c for _, _, c in r.pieces) * esz),
                 "wire_dtype": "bf16" if esz == 2 else "fp32", "fused_optimizer": self._opt is not None,
                 "exposed_tail_ms": round(tails[len(tails) // 2], 3) if tails else None,

@@ -90,6 +90,41 @@ def test_single_rank_rccl_reducer_matches_plain_step(mode):
         dist.destroy_process_group()
 
 
+def test_native_bootstrap_failure_takes_the_torch_path(monkeypatch, capfd):
+    """If creating the library's communicator raises, every rank agrees (all-reduce of the outcome over the bootstrap group) to use
+    the torch.distributed exchange instead -- loudly, and still on RCCL: the step runs, the report names the reason."""
+    from oracle import goldenlib as G
+    from oracle.make_golden import tiny_batch
+    from kmbart import engine as E
+    from kmbart.parallel import DistributedDataParallel
+    from test_model_gpu import build
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29536"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        def boom(self, process_group=None):
+            raise RuntimeError("simulated ncclCommInitRank failure")
+        monkeypatch.setattr(E.Engine, "comm_init", boom)
+        ocfg = G.tiny_config(dropout=0.0)
+        model = build(ocfg, G.golden_state_dict(ocfg, seed=7)).train()
+        ddp = DistributedDataParallel(model, device_ids=[0], reduce_single_rank=True, native=True)
+        assert not ddp.native and ddp.reducer is not None and "simulated" in ddp.native_error
+        assert "native RCCL exchange unavailable" in capfd.readouterr().err
+        b = tiny_batch()
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+        batch["image_features"] = [f.to(dev) for f in b["image_features"]]
+        loss = float(ddp.train_step_fwd_bwd(batch))
+        torch.cuda.synchronize()
+        assert loss == loss
+        rep = ddp.comm_report()
+        assert rep["backend"] == "nccl" and "simulated" in rep["native_fallback"]
+    finally:
+        dist.destroy_process_group()
+
+
 def _n_gpus():
     return torch.cuda.device_count()   # counting devices does not initialise the GPU
 
