@@ -193,7 +193,9 @@ typedef struct kmb_forward_opts {
   kmb_bf16* decoder_states_out;     /* [B*T, d_model] or NULL: copy of the last decoder hidden states (model.py:87-103) */
   int32_t skip_head;                /* 1: stop after the decoder (no logits, no loss): MultiModalBartModel.forward */
 } kmb_forward_opts;
-/* kmb_forward with those options; need_grad must be 0 when encoder_states is given.  In the fp32 validation mode the
+/* kmb_forward with those options.  With encoder_states AND need_grad the following kmb_backward stops at the given states:
+ * the encoder's parameter gradients are zero, dL / d states comes from kmb_encoder_states_grad (the reference's
+ * `forward(encoder_outputs=...)` with a tensor that requires grad, src/model/model.py:76-83).  In the fp32 validation mode the
  * kmb_bf16 pointers of kmb_forward / kmb_forward_ex carry floats (kmb_act_bytes() == 4). */
 int kmb_forward_ex(kmb_handle* h, const kmb_batch* batch, const kmb_forward_opts* opts, int train, int need_grad,
                    float* loss_out, float* logits_out, kmb_bf16* enc_out, void* stream);
@@ -207,6 +209,8 @@ int kmb_last_logits(kmb_handle* h, float* logits_out, void* stream);
  * log-sum-exp (the fused attention kernels never store them).  bf16 product mode only. */
 int kmb_hidden_state(kmb_handle* h, int which, int index, kmb_bf16* out, void* stream);
 int kmb_attention_probs(kmb_handle* h, int which, int layer, float* out, void* stream);
+/* dL / d(encoder output) of the last kmb_backward as bf16 [B*S, d_model] (what autograd hands to `encoder_outputs[0].grad`) */
+int kmb_encoder_states_grad(kmb_handle* h, kmb_bf16* out, void* stream);
 /* fp32 VALIDATION mode (1) / bf16 product mode (0, default).  Mode 1 keeps every activation in float and runs the
  * eval-mode forward on exact-fp32 kernels (csrc/fp32_validate.hip) against the fp32 master weights: parity evidence for
  * north_star's "logits within 1e-3 of the fp32 reference path", never the measured path.  Training, backward and

@@ -116,6 +116,7 @@ struct kmb_handle {
   HeadP head[3];                    // mrm, attribute, relation (src/model/model.py:133-158)
   size_t heads_begin = 0, heads_end = 0; int head_rows_cap = 0;
   std::vector<Bucket> buckets;      // in backward completion order
+  bool enc_given = false;           // the last forward started from the caller's encoder states (kmb_forward_opts)
   std::vector<hipEvent_t> events;
   // bound memory
   float *P = nullptr, *G = nullptr, *M1 = nullptr, *M2 = nullptr, *flb = nullptr;
@@ -127,7 +128,7 @@ struct kmb_handle {
   bool have_hdec = false;   // xd[Ld] of the last forward is still in the workspace (kmb_last_logits)
   int lm_chunk = 8192;  // rows of fp32 logits per LM-head launch (bounds the logits buffer at 1.65 GB for V = 50320)
   // ---- state of the last forward (consumed by backward)
-  kmb_batch bt{}; bool have_fwd = false; bool fwd_train = false;
+  kmb_batch bt{}; bool have_fwd = false; bool fwd_train = false; bool have_bwd = false;
   int Me = 0, Md = 0, Ntot = 0;
   std::vector<EncAct> ea; std::vector<DecAct> da;
   std::vector<bf16_t*> xe, xd;
@@ -1078,7 +1079,8 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   if (h->fp32 && (train || need_grad || extra))
     return fail("kmb_forward: the fp32 validation mode (kmb_set_precision) is an eval-mode forward only");
   const bf16_t* enc_in = opts ? opts->encoder_states : nullptr;
-  if (enc_in && need_grad) return fail("kmb_forward_ex: a forward from given encoder states cannot be differentiated");
+  // need_grad with given encoder states: backward stops at them (kmb_encoder_states_grad hands out dL/d states, the encoder's
+  // parameter gradients are zero) -- src/model/model.py:76-83 run with a tensor that requires grad
   if (!batch || !batch->input_ids || !batch->decoder_input_ids || !batch->feat_offsets)
     return fail("kmb_forward: input_ids, decoder_input_ids and feat_offsets are required");
   const kmb_batch& bt = *batch;
@@ -1094,7 +1096,8 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   h->gen.active = false;
   const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = B * S, Md = B * T;
   h->bt = bt; h->Me = Me; h->Md = Md; h->Ntot = bt.n_features;
-  h->fwd_train = train != 0; h->have_fwd = false; h->have_hdec = false;
+  h->fwd_train = train != 0; h->have_fwd = false; h->have_hdec = false; h->have_bwd = false;
+  h->enc_given = enc_in != nullptr;
   if (train) h->step += 1;
   const bool tr = train != 0;
   const float eps = h->cfg.layer_norm_eps;
@@ -1308,6 +1311,15 @@ int kmb_hidden_state(kmb_handle* h, int which, int index, kmb_bf16* out, void* s
   return 0;
 }
 
+// dL / d(encoder states) of the last kmb_backward as bf16 [B * S, d_model]: the sum of every decoder layer's cross-attention key /
+// value data gradients, i.e. what the encoder's backward starts from (and all there is when the forward was given its states)
+int kmb_encoder_states_grad(kmb_handle* h, kmb_bf16* out, void* stream) {
+  if (!h || !out) return fail("kmb_encoder_states_grad: handle and out are required");
+  if (!h->have_bwd) return fail("kmb_encoder_states_grad: run kmb_backward first");
+  HIPCHK(hipMemcpyAsync(out, h->denc, (size_t)h->Me * h->d * sizeof(bf16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
 int kmb_attention_probs(kmb_handle* h, int which, int layer, float* out, void* stream) {
   if (!h->have_hdec) return fail("kmb_attention_probs: no forward whose activations are still in the workspace");
   if (h->fp32) return fail("kmb_attention_probs: not available in the fp32 validation mode");
@@ -1373,6 +1385,7 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
   if (h->small_floats > 1024) { g_small_slab = h->small_slab; g_small_floats = h->small_floats; }
   if (!h->have_fwd) return fail("kmb_backward: no forward with need_grad=1 to differentiate");
   h->have_fwd = false;
+  h->have_bwd = true;
   const kmb_batch& bt = h->bt;
   const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = h->Me, Md = h->Md;
   const bool tr = h->fwd_train;
@@ -1518,6 +1531,24 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
   }
   // ---- encoder layers
   if (!denc_init) HIPCHK(hipMemsetAsync(h->denc, 0, (size_t)Me * d * sizeof(bf16_t), s));
+  if (h->enc_given) {
+    // The forward started from the caller's encoder states: the gradient stops at them (h->denc, kmb_encoder_states_grad).
+    // The encoder's parameters took no part: their buckets are zero, complete here (the tied matrix keeps the decoder side's
+    // contributions: the head's weight gradient and the decoder embedding's scatter-add above).
+    for (int l = Le - 1; l >= 0; --l, ++ev) {
+      HIPCHK(hipMemsetAsync(h->gf(h->buckets[ev].off), 0, h->buckets[ev].count * sizeof(float), s));
+      HIPCHK(hipEventRecord(h->events[ev], s));
+    }
+    HIPCHK(hipMemsetAsync(h->gf(h->buckets[ev].off), 0, h->buckets[ev].count * sizeof(float), s));
+    if (side) {
+      hipEvent_t e = h->next_event();
+      HIPCHK(hipEventRecord(e, h->side));
+      HIPCHK(hipStreamWaitEvent(s, e, 0));
+    }
+    HIPCHK(hipEventRecord(h->events[ev++], s));
+    HIPCHK(hipEventRecord(h->events[ev++], s));
+    return 0;
+  }
   dy = h->denc;
   cur = 0;
   for (int l = Le - 1; l >= 0; --l, ++c) {

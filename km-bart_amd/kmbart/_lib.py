@@ -133,6 +133,7 @@ PROTOTYPES = {
     "kmb_comm_unique_id": (C.c_int, [c_p]),
     "kmb_comm_init": (C.c_int, [c_p, C.c_int, C.c_int, c_p]),
     "kmb_comm_destroy": (C.c_int, [c_p]),
+    "kmb_encoder_states_grad": (C.c_int, [c_p, c_p, c_p]),
     "kmb_comm_info": (C.c_int, [c_p, C.POINTER(i32), C.POINTER(i32)]),
     "kmb_comm_broadcast_params": (C.c_int, [c_p, C.c_int, c_p]),
     "kmb_allreduce_grads": (C.c_int, [c_p, C.POINTER(KmbAllreduceOpts), c_p]),

@@ -223,6 +223,15 @@ class Engine:
                 out.append(t)
         return tuple(out)
 
+    def encoder_states_grad(self):
+        """dL / d(encoder output) of the backward that just ran, bf16 [B, S, d]: what autograd hands to a tensor passed as
+        `encoder_outputs` (src/model/model.py:76-83)."""
+        B, _ = self._last_bt
+        t = torch.empty((B, self._last_S, int(self.config.d_model)), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_encoder_states_grad(self.h, ptr(t), _stream()))
+        return t
+
     def attention_probs(self, which):
         """`output_attentions`: tuple over layers of fp32 [B, H, T, T] self-attention probabilities."""
         B, T = self._last_bt

@@ -84,15 +84,22 @@ class _LossFn(torch.autograd.Function):
     (reference src/training.py:137-142) run kmb_backward."""
 
     @staticmethod
-    def forward(ctx, anchor, model, loss):
+    def forward(ctx, anchor, model, loss, enc_states=None):
         ctx.model = model
+        ctx.enc_meta = None if enc_states is None else (enc_states.dtype, enc_states.device, tuple(enc_states.shape))
         return loss.reshape(()).clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         # the upstream gradient (ones, or the GradScaler's scale) stays on the device: no host synchronisation
         ctx.model._backward(grad_out if grad_out.is_cuda else float(grad_out))
-        return None, None, None
+        g_enc = None
+        if ctx.enc_meta is not None and ctx.needs_input_grad[3]:
+            # forward(encoder_outputs=...) with a tensor that requires grad (src/model/model.py:76-83): the engine's backward
+            # stopped at the given states; their gradient is the cross-attention key / value data gradient, summed over layers
+            dtype, device, shape = ctx.enc_meta
+            g_enc = ctx.model._engine.encoder_states_grad().to(device=device, dtype=dtype).reshape(shape)
+        return None, None, None, g_enc
 
 
 class LazyLogits:
@@ -354,7 +361,7 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             decoder_input_ids = prev
         if decoder_attention_mask is None and bool((decoder_input_ids == self.config.pad_token_id).any()):
             decoder_attention_mask = decoder_input_ids.ne(self.config.pad_token_id).long()
-        need_grad = labels is not None and torch.is_grad_enabled() and enc_states is None
+        need_grad = labels is not None and torch.is_grad_enabled()
         want_logits = (labels is None) if return_logits is None else bool(return_logits)
         loss, logits, enc = eng.forward(input_ids, image_features, attention_mask, decoder_input_ids,
                                         decoder_attention_mask, labels, train=self.training, need_grad=need_grad,
@@ -378,7 +385,9 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         if labels is None:
             return (logits,) + dec_extra + (enc,) + enc_extra
         if need_grad:
-            loss = _LossFn.apply(self._anchor, self, loss)
+            # given encoder states take part in autograd: backward stops at them and hands their gradient on (the encoder's
+            # own parameters get zero gradients from this loss, as in the reference where they are not in the graph)
+            loss = _LossFn.apply(self._anchor, self, loss, enc_states if torch.is_tensor(enc_states) else None)
         else:
             loss = loss.view(())
         if logits is None:

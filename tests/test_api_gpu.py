@@ -59,9 +59,54 @@ def test_forward_with_encoder_outputs_scores_like_the_full_forward():
         loss, logits, enc = run_fwd(model, b, return_logits=True)
         loss2, logits2, enc2 = run_fwd(model, b, return_logits=True, encoder_outputs=(enc, [], []))
     assert torch.equal(logits, logits2) and float(loss) == float(loss2) and torch.equal(enc, enc2)
-    # grads enabled + encoder_outputs: a plain scoring loss (nothing to differentiate into the given states)
-    out = run_fwd(model.train(), b, encoder_outputs=(enc,))
-    assert not out[0].requires_grad
+
+
+def test_forward_with_encoder_outputs_is_differentiable():
+    """Reference src/model/model.py:76-83 with a tensor that requires grad: backward stops at the given states and hands their
+    gradient on; the decoder's parameter gradients are those of the oracle at the same states, the encoder's are zero."""
+    from oracle import kmbart_oracle as O
+    ocfg = G.tiny_config(dropout=0.0)
+    sd = G.golden_state_dict(ocfg, seed=29)
+    b = tiny_batch(seed=67)
+    model = build(ocfg, sd).train()
+    with torch.no_grad():
+        enc = run_fwd(model.eval(), b, return_logits=True)[2]
+    model.train()
+    enc_in = enc.detach().clone().requires_grad_(True)
+    out = run_fwd(model, b, encoder_outputs=(enc_in,))
+    assert out[0].requires_grad
+    model.zero_grad()
+    out[0].backward()
+    torch.cuda.synchronize()
+    got_enc = enc_in.grad.float().cpu()
+    got = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()}
+    # the oracle at the same (bf16-rounded) encoder states
+    osd = {k: v.clone().float().requires_grad_(k != "final_logits_bias") for k, v in sd.items()}
+    e0 = enc.float().cpu().clone().requires_grad_(True)
+    loss, _, _ = O.forward(osd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], b["decoder_input_ids"],
+                           b["decoder_attention_mask"], b["labels"], training=False, encoder_out=e0)
+    loss.backward()
+    assert abs(float(out[0].detach()) - float(loss.detach())) <= 2e-3 * abs(float(loss.detach()))
+    am = b["attention_mask"].bool()
+    assert rel(got_enc[am], e0.grad[am]) < 3e-2, rel(got_enc[am], e0.grad[am])
+    worst = 0.0
+    for n, g in got.items():
+        ref = osd[n].grad
+        if n.startswith("model.encoder."):
+            assert float(g.abs().max()) == 0.0, n            # the encoder took no part in this loss
+            assert ref is None or float(ref.abs().max()) == 0.0
+        elif n.startswith("model.decoder.") or n == "model.shared.weight":
+            if float(ref.norm()) < 1e-6:       # k_proj.bias: zero by the softmax's shift invariance
+                assert float(g.norm()) < 1e-2, n
+                continue
+            worst = max(worst, rel(g, ref))
+            assert rel(g, ref) < 3e-2, (n, rel(g, ref))
+    assert worst > 0.0
+    # a second, ordinary step afterwards differentiates the encoder again
+    model.zero_grad()
+    run_fwd(model, b)[0].backward()
+    torch.cuda.synchronize()
+    assert float(dict(model.named_parameters())["model.encoder.layers.0.fc1.weight"].grad.abs().max()) > 0.0
 
 
 def test_lazy_logits_are_the_training_logits_and_expire():
