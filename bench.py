@@ -125,14 +125,16 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
             a[0] += n.value
             a[1] += ms.value
             a[2] += fl.value
-        if i == n_prof - 1:   # minimal bytes of the same launches: A and B read once, C written once
+        if i == n_prof - 1:   # minimal bytes of the same launches: A and B (and a fused side operand) read once, C written once
             dump = os.path.join(tempfile.gettempdir(), "kmb_gemm_launches_%d.txt" % os.getpid())
             _lib.check(lib.kmb_profile_dump(dump.encode()))
             for line in open(dump):
-                v, M, N, K, sp, act, us = line.split()
+                v, M, N, K, sp, act, us, *rest = line.split()
                 v, M, N, K, act = int(v), int(M), int(N), int(K), int(act)
                 out_b = 4 if v == 0 else 2                               # weight gradients are fp32, everything else bf16
                 extra = M * N * 2 if act in (1, 2) else 0                # GeLU' written / read beside the output
+                if rest and int(rest[0]):
+                    extra += M * N * 2                                   # the residual / other gradient term the epilogue adds
                 alg_bytes += 2.0 * (M * K + N * K) + out_b * M * N + extra
                 alg_n += 1
                 last_us += float(us)

@@ -247,7 +247,7 @@ void add_ffn(kmb_handle* h, const std::string& p, int F, LayerP& L) {
 struct GemmProfiler {
   bool on = false;
   std::vector<hipEvent_t> ev;        // pairs
-  struct Rec { int variant; double flops; int M, N, K, split, act; };
+  struct Rec { int variant; double flops; int M, N, K, split, act, res; };
   std::vector<Rec> recs;
   size_t used = 0;
 } g_prof;
@@ -299,7 +299,7 @@ int run_gemm(const KmbGemm& g, hipStream_t s) {
     HIPCHK(kmb_gemm_launch(g, s));
     HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
     g_prof.used += 2;
-    g_prof.recs.push_back({g.a_kc * 2 + g.b_kc, 2.0 * g.M * g.N * (double)g.K, g.M, g.N, g.K, g.split_k, g.act});
+    g_prof.recs.push_back({g.a_kc * 2 + g.b_kc, 2.0 * g.M * g.N * (double)g.K, g.M, g.N, g.K, g.split_k, g.act, g.residual != nullptr ? 1 : 0});
     return 0;
   }
   HIPCHK(kmb_gemm_launch(g, s));
@@ -1639,7 +1639,7 @@ int kmb_profile_dump(const char* path) {
     HIPCHK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
     HIPCHK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
     const auto& r = g_prof.recs[i];
-    fprintf(f, "%d %d %d %d %d %d %.3f\n", r.variant, r.M, r.N, r.K, r.split, r.act, t * 1e3);
+    fprintf(f, "%d %d %d %d %d %d %.3f %d\n", r.variant, r.M, r.N, r.K, r.split, r.act, t * 1e3, r.res);   // res: the epilogue reads a residual operand
   }
   fclose(f);
   return 0;

@@ -534,6 +534,13 @@ __device__ __forceinline__ void dma_piece(const char* gbase, uint32_t off, char*
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off),
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (aux bit 1 = nt on gfx950): the line is allocated in L2 as the first to leave.  For
+// the STREAMED operand of a persistent launch (the activation panel: read by the column tiles of one round, never again) so
+// that it does not push the REUSED one (the weight panels, re-read every round) out of a 4 MB L2.  Experiment: -DKMB_A_NT.
+__device__ __forceinline__ void dma_piece_nt(const char* gbase, uint32_t off, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off),
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
+}
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
@@ -1596,8 +1603,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   auto dma_a = [&](int buf, int lo, int hi) {
     char* da = dstA + buf * STG;
 #pragma unroll
-    for (int i = 0; i < NPA; ++i)
+    for (int i = 0; i < NPA; ++i) {
+#ifdef KMB_A_NT
+      if (i >= lo && i < hi) { if constexpr (A_KC) dma_piece_nt(gA_d, offA[i], da + i * 1024); else dma_piece(gA_d, offA[i], da + i * 1024); }
+#else
       if (i >= lo && i < hi) dma_piece(gA_d, offA[i], da + i * 1024);
+#endif
+    }
     if (hi == NPA && lo < hi) gA_d = uniform_ptr(gA_d + stepA);
   };
   auto dma_b = [&](int buf, int lo, int hi) {

@@ -46,7 +46,7 @@ def table(tag):
         _lib.check(lib.kmb_profile_dump(path.encode()))
         lib.kmb_profile_gemm(0)
         for line in open(path):
-            v, M, N, K, sp, act, us = line.split()
+            v, M, N, K, sp, act, us, *_ = line.split()
             a = tot.setdefault((int(v), int(M), int(N), int(K), int(sp), int(act)), [0, 0.0])
             a[0] += 1
             a[1] += float(us)

@@ -39,7 +39,7 @@ _lib.check(lib.kmb_profile_dump(path.encode()))
 lib.kmb_profile_gemm(0)
 agg = collections.OrderedDict()
 for line in open(path):
-    v, M, N, K, sp, act, us = line.split()
+    v, M, N, K, sp, act, us, *_ = line.split()
     key = (int(v), int(M), int(N), int(K), int(sp), int(act))
     a = agg.setdefault(key, [0, 0.0])
     a[0] += 1
