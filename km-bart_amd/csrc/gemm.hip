@@ -1182,16 +1182,23 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
   const kmb_f32x2 scale2 = {p.col_scale, p.col_scale};
   const kmb_f32x2 dscale2 = {p.drop_scale, p.drop_scale};
   // staging write (transposed accumulators: lane (r, g) holds C[16 i + r][16 j + 4 g .. +3]) and read addresses
+  // Swizzle of a staged row: its 16-byte groups XORed with the row's low three bits.  Writes: the 8 lanes of a ds_write_b128
+  // group (8 rows, one column group) spread over all 32 banks.  Reads: a lane of the row-major pass reads its eight floats as
+  // two ds_read_b128, and the 16 lanes of a read group (two rows of different parity) then cover all 64 banks.  (Rounds 1-3
+  // XORed at 32-byte granularity: every read asked for the even 16-byte groups only and the writes for every other one --
+  // two-way conflicts on both, 15-25 % of the LDS cycles of the forward kernels: tools/pmc_stalls.sh.)
   float* const wbase = ef + r * LDE;
-  const int sw = (r & 7) << 3;
+  const int sw = (r & 7) << 2;
   auto stage = [&](const f32x4 (&a)[NJ]) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(wbase + ((j * 16 + g * 4) ^ sw)) = a[j];
     asm volatile("" ::: "memory");
   };
-  const float* rd[NIT];
+  const float* rd[NIT];   // this lane's floats 0-3 of row-iteration it; floats 4-7 are rd_hi floats further (RPI is even: the row parity is lr's)
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) rd[it] = ef + (lr + RPI * it) * LDE + (c8 ^ (((lr + RPI * it) & 7) << 3));
+  for (int it = 0; it < NIT; ++it)
+    rd[it] = ef + (lr + RPI * it) * LDE + (c8 ^ (((lr + RPI * it) & 7) << 2));
+  const int rd_hi = (lr & 1) ? -4 : 4;
   // row pointers of this lane's first row; a row-iteration is 4 rows further, a chunk 16
   bf16_t* out = F32 ? nullptr : p.out_bf16 + (size_t)(row0w + lr) * p.ld_out_bf16 + gcol;
   float* out32 = F32 ? p.out_f32 + (size_t)(row0w + lr) * p.ld_out_f32 + gcol : nullptr;   // fp32 logits (ld % 4 == 0)
@@ -1275,7 +1282,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       lo4[it] = *reinterpret_cast<const f32x4*>(rd[it]);
-      hi4[it] = *reinterpret_cast<const f32x4*>(rd[it] + 4);
+      hi4[it] = *reinterpret_cast<const f32x4*>(rd[it] + rd_hi);
     }
     asm volatile("" ::: "memory");
     if (i + 1 < WROWS / 16) stage_chunk(i + 1);
