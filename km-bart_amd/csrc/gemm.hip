@@ -2225,7 +2225,12 @@ uint32_t* v11_sched_slot(hipStream_t stream) {
 // 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192 (four waves); 14 / 15: persistent 256x256 / 256x192, eight waves
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  if (variant == 9) return kmb_gemm_pair_launch(p, stream);   // two workgroups per CU (gemm_pair.hip)
+  if (variant == 9) {   // two workgroups per CU (gemm_pair.hip)
+    // its tiles are dealt statically: while another kernel (RCCL, kmb_gemm_shared_device) holds CUs, the persistent 256 x 128
+    // kernel with dynamic hand-out takes the launch instead (same tile shape: every launch variant 9 admits, it admits)
+    if (!g_shared_device) return kmb_gemm_pair_launch(p, stream);
+    variant = 12;
+  }
   if (variant == 10) return kmb_gemm_rs_launch(p, stream);   // role-split persistent kernel (gemm_rolesplit.hip)
   if (variant == 11) {
     dim3 grid(v11_grid(p, BN4)), block(256);
