@@ -30,19 +30,22 @@
 // per-workgroup s_memrealtime stamps (100 MHz) + HW_ID / XCC_ID, to read prologue / loop / epilogue / dispatch-gap
 // times off the real kernel.  The product library has none of this.
 #ifdef KMB_GEMM_STAMP
-__device__ unsigned long long* g_kmb_stamps = nullptr;  // [grid][8]
+#ifndef KMB_STAMP_SLOTS
+#define KMB_STAMP_SLOTS 8   // tools/gemm_clock.py builds with 12: slots 8 / 9 = the persistent kernel's s_memtime / s_memrealtime spans
+#endif
+__device__ unsigned long long* g_kmb_stamps = nullptr;  // [grid][KMB_STAMP_SLOTS]
 extern "C" int kmb_debug_set_stamps(void* p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_kmb_stamps), &p, sizeof(p));
 }
 #define KMB_STAMP(i)                                                                                   \
   do {                                                                                                 \
     if (g_kmb_stamps != nullptr && threadIdx.x == 0)                                                   \
-      g_kmb_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                   \
+      g_kmb_stamps[(size_t)blockIdx.x * KMB_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime();                   \
   } while (0)
 #define KMB_STAMP_ID()                                                                                 \
   do {                                                                                                 \
     if (g_kmb_stamps != nullptr && threadIdx.x == 0)                                                   \
-      g_kmb_stamps[(size_t)blockIdx.x * 8 + 7] =                                                       \
+      g_kmb_stamps[(size_t)blockIdx.x * KMB_STAMP_SLOTS + 7] =                                                       \
           (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |                                      \
           ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);                               \
   } while (0)
@@ -51,7 +54,7 @@ extern "C" int kmb_debug_set_stamps(void* p) {
 #define KMB_WAIT_END(acc) (acc) += __builtin_amdgcn_s_memrealtime() - kmb_w0
 #define KMB_STAMP_VALUE(i, v)                                                                          \
   do {                                                                                                 \
-    if (g_kmb_stamps != nullptr && threadIdx.x == 0) g_kmb_stamps[(size_t)blockIdx.x * 8 + (i)] = (v); \
+    if (g_kmb_stamps != nullptr && threadIdx.x == 0) g_kmb_stamps[(size_t)blockIdx.x * KMB_STAMP_SLOTS + (i)] = (v); \
   } while (0)
 #else
 #define KMB_STAMP(i)
@@ -1508,6 +1511,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     __syncthreads();
   }
   if (first_tile >= range1) { retire(); return; }
+#if defined(KMB_GEMM_STAMP) && KMB_STAMP_SLOTS >= 12
+  // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader-clock ticks over 100 MHz real-time ticks
+  const uint64_t kmb_c0 = __builtin_amdgcn_s_memtime(), kmb_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef KMB_DIAG
   // (tools/epilogue_burst.py) KMB_GEMM_STAGGER = s: the workgroups start in four groups, s half-microseconds apart, so that
   // their epilogues -- a burst of 64 MB of stores when all 256 workgroups reach them together -- are spread over a tile time
@@ -1609,6 +1616,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   constexpr int P3 = (NA3 + NB3) / 2, P0 = (NPA - NA3 + NB0) / 2, P1 = NB1 / 2;   // pairs of pieces per sub-phase
   auto dma_a = [&](int buf, int lo, int hi) {
     char* da = dstA + buf * STG;
+#ifndef KMB_V11_NODMA   // (timing experiment only: the K loop without its LDS-DMA -- results are garbage)
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
 #ifdef KMB_A_NT
@@ -1617,13 +1625,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       if (i >= lo && i < hi) dma_piece(gA_d, offA[i], da + i * 1024);
 #endif
     }
+#endif
     if (hi == NPA && lo < hi) gA_d = uniform_ptr(gA_d + stepA);
   };
   auto dma_b = [&](int buf, int lo, int hi) {
     char* db = dstB + buf * STG;
+#ifndef KMB_V11_NODMA
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
       if (i >= lo && i < hi) dma_piece(gB_d, offB[i], db + i * 1024);
+#endif
     if (hi == NPB && lo < hi) {
       gB_d = uniform_ptr(gB_d + stepB);
       ++td;
@@ -1978,6 +1989,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   KMB_STAMP_VALUE(5, kmb_wait_ticks);
   KMB_STAMP_VALUE(6, kmb_drain_ticks);
   KMB_STAMP(4);
+#if defined(KMB_GEMM_STAMP) && KMB_STAMP_SLOTS >= 12
+  KMB_STAMP_VALUE(8, __builtin_amdgcn_s_memtime() - kmb_c0);
+  KMB_STAMP_VALUE(9, __builtin_amdgcn_s_memrealtime() - kmb_r0);
+#endif
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the two look-ahead fetches past the last tile target this LDS
   retire();
 }

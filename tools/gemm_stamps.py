@@ -23,7 +23,7 @@ def build():
     o = os.path.join(objdir, "gemm_stamp.o")
     subprocess.check_call(["hipcc", "-x", "hip"] + b.FLAGS + ["-DKMB_GEMM_STAMP", "-c", os.path.join(b.CSRC, "gemm.hip"), "-o", o])
     objs = [o] + [os.path.join(objdir, s + ".o") for s in b.SOURCES if s != "gemm.hip"]
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STAMP_LIB] + objs)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STAMP_LIB] + objs + b.RCCL_LINK)
     print("built", STAMP_LIB)
 
 
