@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libkmbart_hip.so")
-SOURCES = ["gemm.hip", "gemm_rolesplit.hip", "gemm_pair.hip", "attention.hip", "norm.hip", "embed.hip", "loss.hip", "optim.hip", "heads.hip", "fp32_validate.hip", "decode.hip", "engine.cpp", "capi_ops.cpp"]
+SOURCES = ["gemm.hip", "gemm_rolesplit.hip", "gemm_pair.hip", "gemm_lean.hip", "attention.hip", "norm.hip", "embed.hip", "loss.hip", "optim.hip", "heads.hip", "fp32_validate.hip", "decode.hip", "engine.cpp", "capi_ops.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 # -fno-slp-vectorize: with SLP-packed fp32 math (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers on register pairs
 # assembled by v_mov) hipcc 7.2 produced an ln_bwd_kernel whose dz output is wrong in a few elements per launch (lanes 48-63,
@@ -41,7 +41,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src + ".o")
-        deps = [s] + headers + ([os.path.join(CSRC, "gemm.hip")] if src in ("gemm_rolesplit.hip", "gemm_pair.hip") else [])   # they #include gemm.hip
+        deps = [s] + headers + ([os.path.join(CSRC, "gemm.hip")] if src in ("gemm_rolesplit.hip", "gemm_pair.hip", "gemm_lean.hip") else [])   # they #include gemm.hip
         if force or _stale(o, deps):
             jobs.append((s, o))
 

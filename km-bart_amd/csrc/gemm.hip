@@ -2240,6 +2240,10 @@ uint32_t* v11_sched_slot(hipStream_t stream) {
 // 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192 (four waves); 14 / 15: persistent 256x256 / 256x192, eight waves
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
+  if (variant == 6) {   // eight-wave persistent kernel around the bare K loop (gemm_lean.hip); static tiles: see variant 9 below
+    if (!g_shared_device) return kmb_gemm_lean_launch(p, stream);
+    variant = 14;
+  }
   if (variant == 9) {   // two workgroups per CU (gemm_pair.hip)
     // its tiles are dealt statically: while another kernel (RCCL, kmb_gemm_shared_device) holds CUs, the persistent 256 x 128
     // kernel with dynamic hand-out takes the launch instead (same tile shape: every launch variant 9 admits, it admits)
@@ -2354,7 +2358,7 @@ hipError_t launch_config(const KmbGemm& p, int cfg, hipStream_t stream) {
   if (cfg & 0x100) pf = false;
   if (cfg & 0x200) pf = p.a_kc != 0;
   q.tile_order = ((cfg >> 4) & 7) | (pf ? 2 : 0);
-  if ((variant == 9 || variant == 10) && p.a_kc && p.b_kc && p.N >= 32 * 256) q.tile_order |= 8;   // role-split: per-XCD ranges always; column blocks for wide outputs
+  if ((variant == 6 || variant == 9 || variant == 10) && p.a_kc && p.b_kc && p.N >= 32 * 256) q.tile_order |= 8;   // role-split: per-XCD ranges always; column blocks for wide outputs
   if (variant >= 11) {
     // Persistent variants: per-XCD contiguous tile ranges ALWAYS (bit 0), column blocks for wide outputs (bit 3).  The
     // tuner's back-to-back timing cannot see the difference (operands sit in the Infinity Cache there); inside a step
@@ -2524,6 +2528,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   }
   if (forced) {
     int v = forced;
+    if (v == 6 && !kmb_gemm_lean_ok(p)) v = 11;
     if (v == 9 && !kmb_gemm_pair_ok(p)) v = 11;
     if (v == 10 && !kmb_gemm_rs_ok(p)) v = 11;
     if (v == 11 && !v11_ok(p)) v = 8;
@@ -2532,8 +2537,8 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (v == 14 && !v11_ok(p)) v = 8;
     if (v == 15 && !v11_ok(p, 192)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
-    if (v != 1 && v != 7 && v != 8 && v != 9 && v != 10 && (v < 11 || v > 15)) v = 7;
-    if (p.act == 5 && v != 9 && v != 10 && (v < 11 || v == 13 || v == 15)) v = 11;
+    if (v != 1 && v != 6 && v != 7 && v != 8 && v != 9 && v != 10 && (v < 11 || v > 15)) v = 7;
+    if (p.act == 5 && v != 6 && v != 9 && v != 10 && (v < 11 || v == 13 || v == 15)) v = 11;
     KmbGemm q = p;
     q.tile_order = p.tile_order | (prefetch_a(p) ? 2 : 0);
     return launch_variant(v, q, stream);
@@ -2545,10 +2550,11 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (!autotune || writes_an_input(p)) return p.act == 5 ? launch_config(p, 11, stream) : launch_variant(7, p, stream);
     // (variant 10, the role-split kernel of gemm_rolesplit.hip, is NOT a candidate: bit-identical and tested, but slower than
     //  the persistent variants on every benchmark-batch shape but two -- DESIGN.md section 4 "Round 4"; KMB_GEMM_VARIANT=10 forces it)
-    const int cands[17] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
+    const int cands[18] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
                            14, 14 + 16, 15, 15 + 16,
                            7 + 16 * 5, 8 + 16 * 5,                                        // split-K only: slice-major
-                           9};                                                            // two workgroups per CU (gemm_pair.hip)
+                           9,                                                             // two workgroups per CU (gemm_pair.hip)
+                           6};                                                            // eight waves around the bare K loop (gemm_lean.hip)
     float best_ms = 1e30f;
     int best = p.act == 5 ? 11 : 7;
     std::vector<std::pair<float, int>> timed;   // (ms, candidate) of every eligible candidate
@@ -2567,6 +2573,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     }
     for (int c : cands) {
       if (exclude & (1u << (c & 15))) continue;
+      if ((c & 15) == 6 && !kmb_gemm_lean_ok(p)) continue;
       if ((c & 15) == 9 && !kmb_gemm_pair_ok(p)) continue;
       if ((c & 15) == 10 && !kmb_gemm_rs_ok(p)) continue;
       if ((c & 15) == 11 && !v11_ok(p)) continue;
@@ -2574,7 +2581,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;
       if ((c & 15) == 14 && !v11_ok(p)) continue;
       if ((c & 15) == 15 && !v11_ok(p, 192)) continue;
-      if (p.act == 5 && (c & 15) != 9 && (c & 15) != 10 && ((c & 15) < 11 || (c & 15) == 13 || (c & 15) == 15)) continue;   // lean epilogue of the 256- / 128-column persistent variants (and the role-split one) only
+      if (p.act == 5 && (c & 15) != 6 && (c & 15) != 9 && (c & 15) != 10 && ((c & 15) < 11 || (c & 15) == 13 || (c & 15) == 15)) continue;   // lean epilogue of the 256- / 128-column persistent variants (and the role-split one) only
       if (((c >> 4) & 4) && p.split_k <= 1) continue;
       KmbGemm q = p;
       q.tile_order = c >> 4;

@@ -1,0 +1,257 @@
+// Variant 6: the persistent 256 x 256 eight-wave GEMM REBUILT AROUND ITS K LOOP (forward X W^T and data-gradient dY W layouts).
+//
+// Why.  tools/mfma_loop.hip times the K step of the 256 x 256 tile with nothing around it: eight waves (128 x 64 blocks, two
+// per SIMD), 24 fragment reads and 64 MFMAs per wave, one barrier, the next-but-one stage fetched by LDS-DMA in one burst
+// behind the barrier -- 1.42 us per step, 1.5 PFLOP/s, 77 % of the peak at the clock the chip holds (1.2 us / 1.8 PFLOP/s
+// without the fetch).  The same step inside gemm_kernel_v11<.., 8> (variant 14) takes 1.64 us WITHOUT its LDS-DMA and
+// ~2 us with it (profiles/r04_gemm_in_kernel_clock_and_bare_loop.txt): what it carries besides the step -- per-use address
+// rebuilding, the tile-decode / cursor / L2-touch arithmetic and its branches inside the scheduled region (13 branches and 32
+// spilled-scalar reloads per step in the ISA), the dynamic tile hand-out -- costs more than any of it buys.  This kernel is the
+// microbenchmark's loop with the minimum around it:
+//   * static tile assignment (per-XCD contiguous ranges), every tile interior (M % 256 == N % 256 == 0, K % 64 == 0);
+//   * per-lane LDS-DMA offsets are kernel constants, the tile bases scalar; the cursor's tile switch is the only branch in a step;
+//   * a tile's steps run in one branch-free loop; the last step leaves out the next fragments' reads, the lean epilogue
+//     (v11_epilogue_lean, one class per kernel instance) follows, then the reads;
+//   * no L2 touch, no role split, no second accumulator set.
+// Same LDS images, swizzles, MFMA operand order and k order per accumulator as every other variant: bit-identical results
+// (tools/gemm_v11_check.py).
+#define KMB_GEMM_DEVICE_ONLY
+#include "gemm.hip"
+
+namespace {
+
+constexpr int LN_STG = (256 + 256) * BK * 2;          // 64 KB
+constexpr int LN_A = 256 * BK * 2;                    // 32 KB
+constexpr int LN_EPW = 16 * 64 * 4;                   // fp32 staging image of a wave (16 rows x 64 columns)
+constexpr int LN_LDS = 2 * LN_STG + 8 * LN_EPW;       // 160 KB
+
+enum { LN_BIAS = 0, LN_BIAS_RES = 1, LN_PLAIN = 2, LN_GELU = 3, LN_DGELU_CS = 4, LN_CE = 5 };
+
+__device__ __forceinline__ const char* ln_uniform(const char* ptr) {
+  const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+template <bool B_KC, int EC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel_lean(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves of 128 x 64
+  const int r = lane & 15, g = lane >> 4;
+  constexpr int NJ = 4;
+  const int tiles_n = p.N / 256, tiles_m = p.M / 256;
+  const int ntiles = tiles_m * tiles_n;
+  constexpr int CB = 8;   // column blocks for wide outputs, as in gemm_kernel_v11
+  const bool col_blocks = (p.tile_order & 8) != 0 && tiles_n > CB;
+  const int cb_full = tiles_n / CB;
+  auto decode_tile = [&](int t, int& tm, int& tn) {
+    if (!col_blocks) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
+    const int blk = t / (CB * tiles_m);
+    if (blk < cb_full) {
+      const int rem = t - blk * (CB * tiles_m);
+      tm = rem / CB; tn = blk * CB + (rem - tm * CB);
+    } else {
+      const int wl = tiles_n - cb_full * CB;
+      const int rem = t - cb_full * (CB * tiles_m);
+      tm = rem / wl; tn = cb_full * CB + (rem - tm * wl);
+    }
+  };
+  const int per = (int)gridDim.x >> 3;
+  const int xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
+  const int tq = ntiles >> 3, trem = ntiles & 7;
+  const int range0 = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
+  const int range1 = range0 + tq + (xcd < trem ? 1 : 0);
+  const int first_tile = range0 + loc;
+  if (first_tile >= range1) return;
+  const int nt = p.K / BK;   // >= 4 (launcher)
+
+  // ---- LDS-DMA: kernel-constant lane offsets (interior tiles), scalar tile bases; the cursor runs two steps ahead ----
+  uint32_t offA[4], offB[4];
+  dma_offsets256w4<true, 4>(offA, p.lda, 0, 1 << 30, wave, lane);
+  dma_offsets256w4<B_KC, 4>(offB, p.ldb, 0, 1 << 30, wave, lane);
+  const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
+  const char *gA_d, *gB_d;
+  int tile_d = first_tile, td = 0;
+  auto set_dma_tile = [&](int tile) {
+    int tm, tn;
+    decode_tile(tile, tm, tn);
+    gA_d = ln_uniform(reinterpret_cast<const char*>(p.A) + (size_t)tm * 256 * p.lda * 2);
+    gB_d = ln_uniform(reinterpret_cast<const char*>(p.B) + (B_KC ? (size_t)tn * 256 * p.ldb * 2 : (size_t)tn * 256 * 2));
+  };
+  auto dma_stage = [&](char* stage) {   // the cursor's stage -> `stage`; past the last tile the last tile is fetched again (never read)
+    char* da = stage + wave * 4096;
+    char* db = stage + LN_A + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(gA_d, offA[i], da + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(gB_d, offB[i], db + i * 1024);
+    gA_d = ln_uniform(gA_d + BK * 2);
+    gB_d = ln_uniform(gB_d + stepB);
+    if (++td == nt) {
+      td = 0;
+      if (tile_d + per < range1) tile_d += per;
+      set_dma_tile(tile_d);
+    }
+  };
+
+  bf16x8 fa[2][4], fb[2][NJ];
+  f32x4 acc[8][NJ];
+  auto read_a = [&](const char* st, int kk, int half, bf16x8 (&d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = read_frag3<true, 256>(st, wm * 8 + half * 4 + i, kk, r, g);
+  };
+  auto read_b = [&](const char* st, int kk, bf16x8 (&d)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) d[j] = read_frag3<B_KC, 256>(st + LN_A, wn * NJ + j, kk, r, g);
+  };
+  auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);   // C^T tile
+  };
+  constexpr int NDA = 4, NDB = B_KC ? NJ : 2 * NJ;   // ds_read instructions per 4 A / NJ B fragments
+  // One 64-deep K step on stage `cur` (tools/mfma_loop.hip, variant 7):
+  //   0: A(k0, rows 0-63) x B(k0)    || read A(k0, rows 64-127)
+  //   1: A(k0, rows 64-127) x B(k0)  || read B(k1), A(k1, rows 0-63)
+  //   2: A(k1, rows 0-63) x B(k1)    || read A(k1, rows 64-127); every piece of this wave has landed (vmcnt 0); barrier
+  //   3: A(k1, rows 64-127) x B(k1)  || read k0 of stage `nxt` (not in a tile's LAST step), fetch the cursor's stage into `cur`
+  auto kstep = [&](char* cur, const char* nxt, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
+    read_a(cur, 0, 1, fa[1]);
+    mma(0, fa[0], fb[0]);
+#pragma unroll
+    for (int q = 0; q < NDA; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(cur, 1, fb[1]);
+    read_a(cur, 1, 0, fa[0]);
+    mma(1, fa[1], fb[0]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, (NDB + NDA + 7) / 8, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(cur, 1, 1, fa[1]);
+    mma(0, fa[0], fb[1]);
+#pragma unroll
+    for (int q = 0; q < NDA; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); __builtin_amdgcn_sched_group_barrier(0x100, 1, 2); __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) {
+      read_b(nxt, 0, fb[0]);
+      read_a(nxt, 0, 0, fa[0]);
+    }
+    dma_stage(cur);
+    mma(1, fa[1], fb[1]);
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 3); __builtin_amdgcn_sched_group_barrier(0x100, (NDB + NDA + 7) / 8, 3); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+
+  // ---- prologue: stages 0 and 1 of the first tile ----
+  set_dma_tile(tile_d);
+  dma_stage(smem);
+  dma_stage(smem + LN_STG);
+  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 has landed
+  __builtin_amdgcn_s_barrier();
+  read_b(smem, 0, fb[0]);
+  read_a(smem, 0, 0, fa[0]);
+
+  float* const ef = reinterpret_cast<float*>(smem + 2 * LN_STG + wave * LN_EPW);
+  int it = 0;   // linear K-step counter: stage buffer = it & 1
+  for (int tile = first_tile; tile < range1; tile += per) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t + 1 < nt; ++t, ++it) kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, No{});
+    kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, Yes{});
+    ++it;
+    {
+      int tm, tn;
+      decode_tile(tile, tm, tn);
+      const int row0w = tm * 256 + wm * 128, col0w = tn * 256 + wn * 64;
+      const bool hs = col0w < p.col_scale_n, hd = p.drop_thr16 != 0u, hr = p.residual != nullptr;
+#define KMB_LN_LEAN(B, S, A, R, D, C) v11_epilogue_lean<B, S, A, R, D, C, 128, false, NJ>(p, acc, ef, lane, r, g, row0w, col0w)
+      if constexpr (EC == LN_BIAS) { if (hs) KMB_LN_LEAN(true, true, 0, false, false, false); else KMB_LN_LEAN(true, false, 0, false, false, false); }
+      if constexpr (EC == LN_BIAS_RES) { if (hd) KMB_LN_LEAN(true, false, 0, true, true, false); else KMB_LN_LEAN(true, false, 0, true, false, false); }
+      if constexpr (EC == LN_PLAIN) { if (hr) KMB_LN_LEAN(false, false, 0, true, false, false); else KMB_LN_LEAN(false, false, 0, false, false, false); }
+      if constexpr (EC == LN_GELU) KMB_LN_LEAN(true, false, 1, false, false, false);
+      if constexpr (EC == LN_DGELU_CS) KMB_LN_LEAN(false, false, 2, false, false, true);
+      if constexpr (EC == LN_CE) KMB_LN_LEAN(true, false, 5, false, false, false);
+#undef KMB_LN_LEAN
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile's first fragments (its stage 0 landed before the last step's barrier)
+    read_b(smem + (it & 1) * LN_STG, 0, fb[0]);
+    read_a(smem + (it & 1) * LN_STG, 0, 0, fa[0]);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this workgroup is in flight when it ends
+}
+
+int ln_class(const KmbGemm& p) {
+  const bool hb = p.bias != nullptr, hr = p.residual != nullptr, hd = p.drop_thr16 != 0u, hc = p.colsum != nullptr;
+  const bool hs = p.col_scale_n > 0;
+  if (p.act == 0 && hb && !hr && !hd && !hc) return LN_BIAS;
+  if (p.act == 0 && hb && hr && !hc && !hs) return LN_BIAS_RES;
+  if (p.act == 0 && !hb && !hd && !hc && !hs) return LN_PLAIN;
+  if (p.act == 1 && hb && !hr && !hd && !hc && !hs) return LN_GELU;
+  if (p.act == 2 && !hb && !hr && !hd && hc && !hs) return LN_DGELU_CS;
+  if (p.act == 5 && hb && !hr && !hd && !hc && !hs) return LN_CE;
+  return -1;
+}
+
+template <bool B_KC>
+hipError_t ln_launch_layout(int ec, const KmbGemm& p, dim3 grid, hipStream_t stream) {
+#define KMB_LN_CASE(E)                                                                                                          \
+  case E: {                                                                                                                     \
+    static bool attr = false;                                                                                                   \
+    if (!attr) {                                                                                                                \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_lean<B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS); \
+      if (e != hipSuccess) return e;                                                                                            \
+      attr = true;                                                                                                              \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((gemm_kernel_lean<B_KC, E>), grid, dim3(512), LN_LDS, stream, p);                                         \
+    break;                                                                                                                      \
+  }
+  switch (ec) {
+    KMB_LN_CASE(LN_BIAS)
+    KMB_LN_CASE(LN_BIAS_RES)
+    KMB_LN_CASE(LN_PLAIN)
+    KMB_LN_CASE(LN_GELU)
+    KMB_LN_CASE(LN_DGELU_CS)
+    KMB_LN_CASE(LN_CE)
+    default: return hipErrorInvalidValue;
+  }
+#undef KMB_LN_CASE
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool kmb_gemm_lean_ok(const KmbGemm& p) {
+  if (!p.a_kc || p.split_k > 1 || (p.K % BK) != 0 || p.K / BK < 4) return false;
+  if ((p.M % 256) != 0 || (p.N % 256) != 0) return false;
+  if ((long)(p.M / 256) * (p.N / 256) < 128) return false;
+  if (p.out_bf16 == nullptr || p.out_f32 != nullptr || p.beta != 0.f) return false;
+  if (p.col_scale_n > 0 && (p.col_scale_n % 64) != 0) return false;
+  if (p.act == 5 && (p.row_shift == nullptr || p.row_sums == nullptr)) return false;
+  if ((long)p.lda * 2 * 256 >= (1L << 31) || (long)p.ldb * 2 * 256 >= (1L << 31)) return false;   // 32-bit piece offsets
+  return ln_class(p) >= 0;
+}
+
+hipError_t kmb_gemm_lean_launch(const KmbGemm& p, hipStream_t stream) {
+  if (!kmb_gemm_lean_ok(p)) return hipErrorInvalidValue;
+  const long tiles = (long)(p.M / 256) * (p.N / 256);
+  const dim3 grid(tiles >= 256 ? 256u : (unsigned)(tiles & ~7L));
+  const int ec = ln_class(p);
+  return p.b_kc ? ln_launch_layout<true>(ec, p, grid, stream) : ln_launch_layout<false>(ec, p, grid, stream);
+}

@@ -1,0 +1,221 @@
+// What the K loop of the persistent 256 x 256 GEMM can issue when NOTHING moves (measurement only; not part of the library).
+//
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_loop tools/mfma_loop.hip && /tmp/mfma_loop
+//
+// One 4-wave workgroup per CU, wave block 128 x 128 (64 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 256 registers), a
+// 64-deep "K step" = 128 MFMAs per wave; the operands are random bf16 in a two-stage LDS image with the library's K-contiguous
+// layout (128-byte rows, chunk XOR swizzle), filled once.  Variants, each timed over thousands of steps:
+//   0  MFMAs only (fragments stay in registers)
+//   1  + the step's 32 fragment reads (ds_read_b128), interleaved one per four MFMAs, software-pipelined one sub-phase ahead
+//   2  + one workgroup barrier per step
+//   3  + lgkmcnt(0) at the top of every step (what the library's loop does so that the compiler can count its waits)
+//   4  variant 2 with the reads bunched at the start of each 32-MFMA sub-phase
+//   5  variant 2 with EIGHT waves (128 x 64 blocks, 128 accumulator registers, two waves per SIMD)
+// Printed: TFLOP/s and the in-kernel clock (s_memtime / s_memrealtime), so that cycles and wall time can be told apart.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 as raw bits... the builtin wants __bf16 vectors
+typedef __attribute__((ext_vector_type(8))) __bf16 bfrag;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int STG = 64 * 1024;   // (256 + 256) rows x 128 bytes
+
+__device__ __forceinline__ bfrag read_frag(const char* img, int rowtile, int kk, int r, int g) {
+  const int row = rowtile * 16 + r;
+  return *reinterpret_cast<const bfrag*>(img + row * 128 + ((((kk * 4 + g) ^ ((row >> 1) & 7))) << 4));
+}
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+void loop_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsigned long long* clk, const char* __restrict__ gA,
+                 const char* __restrict__ gB) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < 2 * STG / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem)[i] = rnd[i];
+  __syncthreads();
+  constexpr int WN = NW == 8 ? 4 : 2, NJ = NW == 8 ? 4 : 8;
+  const int wm = wave / WN, wn = wave % WN;
+  f32x4 acc[8][NJ];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bfrag fa[2][4], fb[2][NJ];
+  auto read_a = [&](const char* st, int kk, int half, bfrag (&d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = read_frag(st, wm * 8 + half * 4 + i, kk, r, g);
+  };
+  auto read_b = [&](const char* st, int kk, bfrag (&d)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) d[j] = read_frag(st + 32768, wn * NJ + j, kk, r, g);
+  };
+  auto mma = [&](int half, const bfrag (&a)[4], const bfrag (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);
+  };
+  constexpr int NM = 4 * NJ;   // MFMAs per sub-phase
+  // MODE 6 / 7: the stage two steps ahead is fetched by LDS-DMA as the library does it (64 pieces of 1 KiB per step and CU: 8 rows x
+  // 128 bytes each, rows 1536 bytes apart -- a [65536, 768] activation matrix walked in 256-row panels, 12 steps per panel, and a
+  // [3072, 768] weight matrix), vmcnt(0) in front of the step's barrier
+  constexpr bool DMA = MODE >= 6;
+  constexpr int NP = 32 / NW;                       // pieces per wave, operand and step
+  uint32_t off[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) off[i] = (uint32_t)(((wave * NP + i) * 8 + (lane >> 3)) * 1536 + (((lane & 7) ^ ((((wave * NP + i) * 8 + (lane >> 3)) >> 1) & 7)) << 4));
+  int panel = (int)blockIdx.x, kstep = 0;
+  auto dma = [&](char* stage) {
+    const char* pa = gA + (size_t)panel * (256 * 1536) + kstep * 128;
+    const char* pb = gB + (size_t)(panel % 12) * (256 * 1536) + kstep * 128;
+    const uint64_t ua = (uint64_t)pa, ub = (uint64_t)pb;
+    pa = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ua >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ua));
+    pb = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub));
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + off[i]),
+                                       (__attribute__((address_space(3))) void*)(stage + (wave * NP + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + off[i]),
+                                       (__attribute__((address_space(3))) void*)(stage + 32768 + (wave * NP + i) * 1024), 16, 0, 0);
+    if (++kstep == 12) { kstep = 0; panel = (panel + 37) & 255; }
+  };
+  read_b(smem, 0, fb[0]);
+  read_a(smem, 0, 0, fa[0]);
+  read_a(smem, 0, 1, fa[1]);
+  read_b(smem, 1, fb[1]);
+  const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < steps; ++it) {
+    const char* cur = smem + (it & 1) * STG;
+    const char* nxt = smem + ((it + 1) & 1) * STG;
+    if constexpr (MODE == 0) {
+      mma(0, fa[0], fb[0]); mma(1, fa[1], fb[0]); mma(0, fa[0], fb[1]); mma(1, fa[1], fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if constexpr (MODE == 3) __builtin_amdgcn_s_waitcnt(0xC07F);
+      // sub-phase 0: A(k0, rows 0-63) x B(k0)  ||  read A(k0, rows 64-127)
+      read_a(cur, 0, 1, fa[1]);
+      mma(0, fa[0], fb[0]);
+      if constexpr (MODE == 4) { __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, NM, 0); }
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 0); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // sub-phase 1: A(k0, rows 64-127) x B(k0)  ||  read B(k1), A(k1, rows 0-63)
+      read_b(cur, 1, fb[1]);
+      read_a(cur, 1, 0, fa[0]);
+      mma(1, fa[1], fb[0]);
+      if constexpr (MODE == 4) { __builtin_amdgcn_sched_group_barrier(0x100, NJ + 4, 1); __builtin_amdgcn_sched_group_barrier(0x008, NM, 1); }
+      else {
+#pragma unroll
+        for (int q = 0; q < NJ + 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, NM / (NJ + 4), 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - (NJ + 4) * (NM / (NJ + 4)), 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // sub-phase 2: A(k1, rows 0-63) x B(k1)  ||  read A(k1, rows 64-127); barrier
+      read_a(cur, 1, 1, fa[1]);
+      mma(0, fa[0], fb[1]);
+      if constexpr (MODE == 4) { __builtin_amdgcn_sched_group_barrier(0x100, 4, 2); __builtin_amdgcn_sched_group_barrier(0x008, NM, 2); }
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 2); __builtin_amdgcn_sched_group_barrier(0x100, 1, 2); __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 2); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DMA) { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+      else if constexpr (MODE >= 2) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+      // sub-phase 3: A(k1, rows 64-127) x B(k1)  ||  read k0 of the next stage
+      read_b(nxt, 0, fb[0]);
+      read_a(nxt, 0, 0, fa[0]);
+      if constexpr (DMA) dma(const_cast<char*>(cur));
+      mma(1, fa[1], fb[1]);
+      if constexpr (MODE == 4) { __builtin_amdgcn_sched_group_barrier(0x100, NJ + 4, 3); __builtin_amdgcn_sched_group_barrier(0x008, NM, 3); }
+      else {
+#pragma unroll
+        for (int q = 0; q < NJ + 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, NM / (NJ + 4), 3); __builtin_amdgcn_sched_group_barrier(0x100, 1, 3); }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - (NJ + 4) * (NM / (NJ + 4)), 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (s == 12345.678f) sink[0] = s;
+  if (tid == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+template <int MODE, int NW>
+void run(const char* name, const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA, const char* gB) {
+  auto fn = loop_kernel<MODE, NW>;
+  CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STG));
+  const int steps = 4000;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; ++rep) {   // ~1 s in all: the clock has settled for the later repetitions
+    CK(hipEventRecord(e0));
+    for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(fn, dim3(256), dim3(NW * 64), 2 * STG, 0, rnd, steps, sink, clk, gA, gB);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep >= 3 && ms < best) best = ms;
+  }
+  std::vector<unsigned long long> h(512);
+  CK(hipMemcpy(h.data(), clk, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double cs = 0, rs = 0;
+  for (int i = 0; i < 256; ++i) { cs += (double)h[2 * i]; rs += (double)h[2 * i + 1]; }
+  const double ghz = cs / rs * 0.1;
+  const double flops = 10.0 * steps * 128.0 * 16384.0 * 4.0 * 256.0;   // 128 MFMAs x 4 waves' worth per step and CU (NW = 8: 64 x 8)
+  const double tf = flops / (best * 1e-3) * 1e-12;
+  printf("%-78s %7.1f TFLOP/s  clock %.2f GHz  = %4.1f %% of the peak at that clock  (%.2f us per step)\n", name, tf, ghz,
+         100.0 * tf / (256 * 4 * 1024 * ghz * 1e-3), best * 1e3 / 10.0 / steps);
+}
+
+int main() {
+  std::vector<uint32_t> h(2 * STG / 4);
+  uint32_t x = 12345u;
+  for (auto& v : h) {   // two random bf16 per word, |value| < 2: sign, exponent 0x3D..0x3F, random mantissa
+    x = x * 1664525u + 1013904223u;
+    const uint32_t a = ((x >> 3) & 0x807Fu) | (0x3D80u + (((x >> 20) & 3u) << 7));
+    x = x * 1664525u + 1013904223u;
+    const uint32_t b = ((x >> 3) & 0x807Fu) | (0x3D80u + (((x >> 20) & 3u) << 7));
+    v = a | (b << 16);
+  }
+  uint32_t* rnd;
+  float* sink;
+  unsigned long long* clk;
+  CK(hipMalloc(&rnd, 2 * STG));
+  CK(hipMemcpy(rnd, h.data(), 2 * STG, hipMemcpyHostToDevice));
+  CK(hipMalloc(&sink, 16));
+  CK(hipMalloc(&clk, 512 * sizeof(unsigned long long)));
+  char *gA, *gB;
+  CK(hipMalloc(&gA, (size_t)65536 * 1536 + 4096));
+  CK(hipMalloc(&gB, (size_t)3072 * 1536 + 4096));
+  for (size_t o = 0; o < (size_t)65536 * 1536; o += 2 * STG) CK(hipMemcpy(gA + o, h.data(), 2 * STG, hipMemcpyHostToDevice));
+  for (size_t o = 0; o < (size_t)3072 * 1536; o += 2 * STG) CK(hipMemcpy(gB + o, h.data(), 2 * STG, hipMemcpyHostToDevice));
+  printf("# bare K loop of the persistent 256 x 256 bf16 GEMM: 128 v_mfma_f32_16x16x32_bf16 per wave and 64-deep step, random operands in LDS, no global memory\n");
+  run<0, 4>("0  MFMAs only (operands in registers), 4 waves", rnd, sink, clk, gA, gB);
+  run<1, 4>("1  + 32 ds_read_b128 per wave and step, one per four MFMAs", rnd, sink, clk, gA, gB);
+  run<2, 4>("2  + one workgroup barrier per step", rnd, sink, clk, gA, gB);
+  run<3, 4>("3  + lgkmcnt(0) at the top of the step (the library's loop)", rnd, sink, clk, gA, gB);
+  run<4, 4>("4  as 2, the reads bunched at the start of each sub-phase", rnd, sink, clk, gA, gB);
+  run<0, 8>("0' MFMAs only, 8 waves (128 x 64 blocks, two waves per SIMD)", rnd, sink, clk, gA, gB);
+  run<2, 8>("5  8 waves: 24 ds_read_b128 per wave and step + barrier", rnd, sink, clk, gA, gB);
+  run<6, 4>("6  4 waves: reads + barrier + LDS-DMA of the stage two steps ahead (vmcnt(0) before the barrier)", rnd, sink, clk, gA, gB);
+  run<6, 8>("7  8 waves: the same", rnd, sink, clk, gA, gB);
+  return 0;
+}
