@@ -12,7 +12,7 @@
 //   * per-lane LDS-DMA offsets are kernel constants, the tile bases scalar; the cursor's tile switch is the only branch in a step;
 //   * a tile's steps run in one branch-free loop; the last step leaves out the next fragments' reads, the lean epilogue
 //     (v11_epilogue_lean, one class per kernel instance) follows, then the reads;
-//   * no L2 touch, no role split, no second accumulator set.
+//   * the L2 touch of the activation panel as one load per wave behind a stage's pieces; no role split, no second accumulator set.
 // Same LDS images, swizzles, MFMA operand order and k order per accumulator as every other variant: bit-identical results
 // (tools/gemm_v11_check.py).
 #define KMB_GEMM_DEVICE_ONLY
@@ -75,11 +75,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
   const char *gA_d, *gB_d;
   int tile_d = first_tile, td = 0;
+  // ---- L2 touch of the activation panel (gemm_kernel_v11, "L2 prefetch of the activation operand"): one stage in flight covers
+  // an L2 round trip, not a memory one, and inside a step A was just streamed out by the previous kernel.  The workgroups that
+  // share a row panel (the tiles of one tm: consecutive tiles, side by side on one XCD) each touch THEIR share of its rows
+  // LN_PFD steps ahead of the DMA cursor, one load instruction per wave right behind a stage's pieces; the step's wait leaves it
+  // outstanding (vmcnt 1), so it has a whole step to land.  Its result is never used; its destination is one register web for
+  // the whole kernel (see gemm_kernel_v11).  Not for the data-gradient layout's B (the weights: L2 / Infinity Cache residents).
+  constexpr int LN_PFD = 2;
+  const int sharers = col_blocks ? CB : tiles_n;
+  const int pf_share = (256 + sharers - 1) / sharers;
+  const int pf_gs = (pf_share + 7) >> 3;                 // rows per wave
+  const char *gA_tile, *gA_nx;
+  int pf_rows = 0, pf_rows_nx = 0;
+  uint32_t pf_sink = 0u;
   auto set_dma_tile = [&](int tile) {
     int tm, tn;
     decode_tile(tile, tm, tn);
     gA_d = ln_uniform(reinterpret_cast<const char*>(p.A) + (size_t)tm * 256 * p.lda * 2);
     gB_d = ln_uniform(reinterpret_cast<const char*>(p.B) + (B_KC ? (size_t)tn * 256 * p.ldb * 2 : (size_t)tn * 256 * 2));
+    gA_tile = gA_d;
+    pf_rows = (col_blocks ? tn % CB : tn) * pf_share;
+    const int tx = tile + per < range1 ? tile + per : tile;
+    decode_tile(tx, tm, tn);
+    gA_nx = ln_uniform(reinterpret_cast<const char*>(p.A) + (size_t)tm * 256 * p.lda * 2);
+    pf_rows_nx = (col_blocks ? tn % CB : tn) * pf_share;
   };
   auto dma_stage = [&](char* stage) {   // the cursor's stage -> `stage`; past the last tile the last tile is fetched again (never read)
     char* da = stage + wave * 4096;
@@ -88,6 +107,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 4; ++i) dma_piece(gA_d, offA[i], da + i * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_piece(gB_d, offB[i], db + i * 1024);
+    {
+      const int ps = td + LN_PFD;
+      const bool nx = ps >= nt;
+      const char* sbase = ln_uniform((nx ? gA_nx : gA_tile) + (size_t)(nx ? ps - nt : ps) * (BK * 2));
+      int row = wave * pf_gs + (lane < pf_gs ? lane : pf_gs - 1);
+      row = row < pf_share ? row : pf_share - 1;
+      row += nx ? pf_rows_nx : pf_rows;
+      row = row < 256 ? row : 255;
+      const uint32_t voff = (uint32_t)row * (uint32_t)p.lda * 2u;
+      asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(voff), "s"(sbase) : "memory");
+    }
     gA_d = ln_uniform(gA_d + BK * 2);
     gB_d = ln_uniform(gB_d + stepB);
     if (++td == nt) {
@@ -118,7 +148,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // One 64-deep K step on stage `cur` (tools/mfma_loop.hip, variant 7):
   //   0: A(k0, rows 0-63) x B(k0)    || read A(k0, rows 64-127)
   //   1: A(k0, rows 64-127) x B(k0)  || read B(k1), A(k1, rows 0-63)
-  //   2: A(k1, rows 0-63) x B(k1)    || read A(k1, rows 64-127); every piece of this wave has landed (vmcnt 0); barrier
+  //   2: A(k1, rows 0-63) x B(k1)    || read A(k1, rows 64-127); every piece of this wave has landed (vmcnt 1: the touch); barrier
   //   3: A(k1, rows 64-127) x B(k1)  || read k0 of stage `nxt` (not in a tile's LAST step), fetch the cursor's stage into `cur`
   auto kstep = [&](char* cur, const char* nxt, auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
@@ -138,7 +168,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int q = 0; q < NDA; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); __builtin_amdgcn_sched_group_barrier(0x100, 1, 2); __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0071);   // vmcnt(1) lgkmcnt(0): the pieces have landed, the touch behind them may still be out
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!LAST) {
@@ -160,7 +190,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   set_dma_tile(tile_d);
   dma_stage(smem);
   dma_stage(smem + LN_STG);
-  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 has landed
+  __builtin_amdgcn_s_waitcnt(0x0F7A);   // vmcnt(10) = touch, stage 1, touch: stage 0 has landed
   __builtin_amdgcn_s_barrier();
   read_b(smem, 0, fb[0]);
   read_a(smem, 0, 0, fa[0]);
@@ -195,6 +225,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     read_a(smem + (it & 1) * LN_STG, 0, 0, fa[0]);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this workgroup is in flight when it ends
+  asm volatile("" ::"v"(pf_sink));      // the touch's destination stays reserved for the whole kernel
 }
 
 int ln_class(const KmbGemm& p) {
