@@ -95,7 +95,7 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         defs = sys.argv[i + 2:]
         # KMB_DIAG (csrc/diag.h) switches the A/B environment knobs and ablation bits on in every file that has them
-        srcs = ("gemm.hip", "engine.cpp", "attention.hip") if "KMB_DIAG" in defs else ("gemm.hip",)
+        srcs = ("gemm.hip", "gemm_lean.hip", "engine.cpp", "attention.hip") if "KMB_DIAG" in defs else ("gemm.hip",)
         if any(d.startswith("KMB_RS_") for d in defs):   # experiment builds of the role-split kernel
             srcs = ("gemm_rolesplit.hip",)
         if any(d.startswith("KMB_PR_") for d in defs):   # ... of the two-workgroups-per-CU kernel

@@ -205,7 +205,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = 0; t + 1 < nt; ++t, ++it) kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, No{});
     kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, Yes{});
     ++it;
-    {
+    if (KMB_DIAG_BIT(p.tile_order, 512)) {   // epilogue ablation (diagnostic build only, tools/kloop_time.py): keep the accumulators alive
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
       int tm, tn;
       decode_tile(tile, tm, tn);
       const int row0w = tm * 256 + wm * 128, col0w = tn * 256 + wn * 64;

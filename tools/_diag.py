@@ -17,6 +17,6 @@ def use_diag_lib():
     lib = os.path.join(mod.LIBDIR, "libkmbart_hip_diag.so")
     srcs = [os.path.join(mod.CSRC, f) for f in os.listdir(mod.CSRC)]
     if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
-        lib = mod.build_variant("diag", ["KMB_DIAG"], ("gemm.hip", "engine.cpp", "attention.hip"))
+        lib = mod.build_variant("diag", ["KMB_DIAG"], ("gemm.hip", "gemm_lean.hip", "engine.cpp", "attention.hip"))
     os.environ["KMB_LIB_PATH"] = lib
     return lib

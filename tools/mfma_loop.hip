@@ -34,7 +34,7 @@ __device__ __forceinline__ bfrag read_frag(const char* img, int rowtile, int kk,
 template <int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void loop_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsigned long long* clk, const char* __restrict__ gA,
-                 const char* __restrict__ gB) {
+                 const char* __restrict__ gB, int apanels) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -67,11 +67,14 @@ void loop_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsig
   // 128 bytes each, rows 1536 bytes apart -- a [65536, 768] activation matrix walked in 256-row panels, 12 steps per panel, and a
   // [3072, 768] weight matrix), vmcnt(0) in front of the step's barrier
   constexpr bool DMA = MODE >= 6;
+  constexpr bool TOUCH = MODE == 10;   // + an L2 touch of the activation panel two steps ahead of the fetch (one load per wave), vmcnt(1)
+  uint32_t pf_sink = 0u;
   constexpr int NP = 32 / NW;                       // pieces per wave, operand and step
   uint32_t off[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) off[i] = (uint32_t)(((wave * NP + i) * 8 + (lane >> 3)) * 1536 + (((lane & 7) ^ ((((wave * NP + i) * 8 + (lane >> 3)) >> 1) & 7)) << 4));
-  int panel = (int)blockIdx.x, kstep = 0;
+  int panel = apanels < 0 ? (int)blockIdx.x / -apanels : (int)blockIdx.x, kstep = 0;
+  const int npan = apanels < 0 ? 256 : apanels, pstep = apanels < 0 ? 22 : 293;
   auto dma = [&](char* stage) {
     const char* pa = gA + (size_t)panel * (256 * 1536) + kstep * 128;
     const char* pb = gB + (size_t)(panel % 12) * (256 * 1536) + kstep * 128;
@@ -86,7 +89,16 @@ void loop_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsig
     for (int i = 0; i < NP; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + off[i]),
                                        (__attribute__((address_space(3))) void*)(stage + 32768 + (wave * NP + i) * 1024), 16, 0, 0);
-    if (++kstep == 12) { kstep = 0; panel = (panel + 37) & 255; }
+    if constexpr (TOUCH) {
+      const int ps = kstep + 2;
+      const int pp = ps >= 12 ? (panel + pstep) % npan : panel;
+      const char* tb = gA + (size_t)pp * (256 * 1536) + (ps >= 12 ? ps - 12 : ps) * 128;
+      const uint64_t ut = (uint64_t)tb;
+      tb = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ut >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ut));
+      const uint32_t voff = (uint32_t)((wave * (256 / NW) + (lane & (256 / NW - 1))) * 1536);
+      asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(voff), "s"(tb) : "memory");
+    }
+    if (++kstep == 12) { kstep = 0; panel = (panel + pstep) % npan; }
   };
   read_b(smem, 0, fb[0]);
   read_a(smem, 0, 0, fa[0]);
@@ -130,7 +142,8 @@ void loop_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsig
         for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 2); __builtin_amdgcn_sched_group_barrier(0x100, 1, 2); __builtin_amdgcn_sched_group_barrier(0x008, NM / 8, 2); }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DMA) { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+      if constexpr (TOUCH) { __builtin_amdgcn_s_waitcnt(0x0071); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+      else if constexpr (DMA) { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
       else if constexpr (MODE >= 2) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
       // sub-phase 3: A(k1, rows 64-127) x B(k1)  ||  read k0 of the next stage
       read_b(nxt, 0, fb[0]);
@@ -153,11 +166,12 @@ void loop_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsig
 #pragma unroll
     for (int j = 0; j < NJ; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
   if (s == 12345.678f) sink[0] = s;
+  asm volatile("" ::"v"(pf_sink));
   if (tid == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 
 template <int MODE, int NW>
-void run(const char* name, const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA, const char* gB) {
+void run(const char* name, const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA, const char* gB, int apanels = 256) {
   auto fn = loop_kernel<MODE, NW>;
   CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STG));
   const int steps = 4000;
@@ -167,7 +181,7 @@ void run(const char* name, const uint32_t* rnd, float* sink, unsigned long long*
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {   // ~1 s in all: the clock has settled for the later repetitions
     CK(hipEventRecord(e0));
-    for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(fn, dim3(256), dim3(NW * 64), 2 * STG, 0, rnd, steps, sink, clk, gA, gB);
+    for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(fn, dim3(256), dim3(NW * 64), 2 * STG, 0, rnd, steps, sink, clk, gA, gB, apanels);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -184,6 +198,8 @@ void run(const char* name, const uint32_t* rnd, float* sink, unsigned long long*
   printf("%-78s %7.1f TFLOP/s  clock %.2f GHz  = %4.1f %% of the peak at that clock  (%.2f us per step)\n", name, tf, ghz,
          100.0 * tf / (256 * 4 * 1024 * ghz * 1e-3), best * 1e3 / 10.0 / steps);
 }
+
+int ring_main(const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA);
 
 int main() {
   std::vector<uint32_t> h(2 * STG / 4);
@@ -203,9 +219,9 @@ int main() {
   CK(hipMalloc(&sink, 16));
   CK(hipMalloc(&clk, 512 * sizeof(unsigned long long)));
   char *gA, *gB;
-  CK(hipMalloc(&gA, (size_t)65536 * 1536 + 4096));
+  CK(hipMalloc(&gA, (size_t)4 * 65536 * 1536 + 4096));   // 400 MB: 1024 panels (the Infinity Cache holds 256 MB)
   CK(hipMalloc(&gB, (size_t)3072 * 1536 + 4096));
-  for (size_t o = 0; o < (size_t)65536 * 1536; o += 2 * STG) CK(hipMemcpy(gA + o, h.data(), 2 * STG, hipMemcpyHostToDevice));
+  for (size_t o = 0; o < (size_t)4 * 65536 * 1536; o += 2 * STG) CK(hipMemcpy(gA + o, h.data(), 2 * STG, hipMemcpyHostToDevice));
   for (size_t o = 0; o < (size_t)3072 * 1536; o += 2 * STG) CK(hipMemcpy(gB + o, h.data(), 2 * STG, hipMemcpyHostToDevice));
   printf("# bare K loop of the persistent 256 x 256 bf16 GEMM: 128 v_mfma_f32_16x16x32_bf16 per wave and 64-deep step, random operands in LDS, no global memory\n");
   run<0, 4>("0  MFMAs only (operands in registers), 4 waves", rnd, sink, clk, gA, gB);
@@ -217,5 +233,145 @@ int main() {
   run<2, 8>("5  8 waves: 24 ds_read_b128 per wave and step + barrier", rnd, sink, clk, gA, gB);
   run<6, 4>("6  4 waves: reads + barrier + LDS-DMA of the stage two steps ahead (vmcnt(0) before the barrier)", rnd, sink, clk, gA, gB);
   run<6, 8>("7  8 waves: the same", rnd, sink, clk, gA, gB);
+  run<6, 8>("8  as 7, the activation matrix 400 MB (1024 panels: beyond the Infinity Cache)", rnd, sink, clk, gA, gB, 1024);
+  run<6, 8>("9  as 7, 21 panels shared by 12 workgroups each (the sharing of a 3072-column output)", rnd, sink, clk, gA, gB, -12);
+  ring_main(rnd, sink, clk, gA);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Deeper pipeline for operands that BOTH stream from the memory side (the weight-gradient layout: no sharing to speak of, no
+// weights): 32-deep stages (32 KB: 256 + 256 rows x 64 bytes), NSTG of them, the stage NSTG steps ahead fetched behind each
+// step's barrier into the buffer that step has just left -- NSTG - 1 stages (x 32 KB) in flight at the wait.  Eight waves, 32 MFMAs
+// and 12 fragment reads per wave and 32-deep step.  Compare at equal work: two of these steps = one 64-deep step above.
+__device__ __forceinline__ int swz64(int r) { return (0x78 >> (((r >> 2) & 3) * 2)) & 3; }
+
+template <int NSTG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void ring_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsigned long long* clk, const char* __restrict__ gA,
+                 const char* __restrict__ gB, int apanels) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SB = 32 * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < NSTG * SB / 4; i += 512) reinterpret_cast<uint32_t*>(smem)[i] = rnd[i & (2 * STG / 4 - 1)];
+  __syncthreads();
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fc = r * 64 + ((g ^ swz64(r)) << 4);
+  bfrag fa0[4], fa1[4], fbx[4], fby[4];
+  auto read_a = [&](const char* st, int half, bfrag (&d)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const bfrag*>(st + (wm * 8 + half * 4 + i) * 1024 + fc);
+  };
+  auto read_b = [&](const char* st, bfrag (&d)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = *reinterpret_cast<const bfrag*>(st + 16384 + (wn * 4 + j) * 1024 + fc);
+  };
+  auto mma = [&](int half, const bfrag (&a)[4], const bfrag (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);
+  };
+  // pieces: 16 per operand and step = 2 per wave; a piece = 16 rows x 64 bytes (rows 1536 bytes apart)
+  uint32_t off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) off[i] = (uint32_t)(((wave * 2 + i) * 16 + (lane >> 2)) * 1536 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
+  int pa = (int)blockIdx.x, pb = ((int)blockIdx.x * 7 + 3) % apanels, kstep = 0;
+  auto dma = [&](char* stage) {
+    const uint64_t ua = (uint64_t)(gA + (size_t)pa * (256 * 1536) + kstep * 64), ub = (uint64_t)(gB + (size_t)pb * (256 * 1536) + kstep * 64);
+    const char* sa = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ua >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ua));
+    const char* sb = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa + off[i]),
+                                       (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + off[i]),
+                                       (__attribute__((address_space(3))) void*)(stage + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
+    if (++kstep == 24) { kstep = 0; pa = (pa + 293) % apanels; pb = (pb + 311) % apanels; }
+  };
+  auto step = [&](char* cur, const char* nxt, bfrag (&fb)[4], bfrag (&fbn)[4]) {
+    read_a(cur, 1, fa1);
+    mma(0, fa0, fb);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (NSTG == 2) __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0)
+    else if (NSTG == 3) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4): one younger stage stays in flight
+    else __builtin_amdgcn_s_waitcnt(0x0078);                  // vmcnt(8): two
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(nxt, fbn);
+    read_a(nxt, 0, fa0);
+    dma(cur);
+    mma(1, fa1, fb);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 2, 1); __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int s = 0; s < NSTG - 1; ++s) dma(smem + (s + 1) * SB);   // stages 1 .. NSTG-1 in flight (stage 0 is the resident fill)
+  read_b(smem, fbx);
+  read_a(smem, 0, fa0);
+  const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  int b = 0;
+  for (int it = 0; it < steps; it += 2) {
+    const int b1 = b + 1 == NSTG ? 0 : b + 1;
+    step(smem + b * SB, smem + b1 * SB, fbx, fby);
+    const int b2 = b1 + 1 == NSTG ? 0 : b1 + 1;
+    step(smem + b1 * SB, smem + b2 * SB, fby, fbx);
+    b = b2;
+  }
+  const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (s == 12345.678f) sink[0] = s;
+  if (tid == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+template <int NSTG>
+void run_ring(const char* name, const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA, const char* gB, int apanels) {
+  auto fn = ring_kernel<NSTG>;
+  CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * 32 * 1024));
+  const int steps = 8000;   // 32-deep steps = 4000 64-deep ones
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; ++rep) {
+    CK(hipEventRecord(e0));
+    for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(fn, dim3(256), dim3(512), NSTG * 32 * 1024, 0, rnd, steps, sink, clk, gA, gB, apanels);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep >= 3 && ms < best) best = ms;
+  }
+  std::vector<unsigned long long> h(512);
+  CK(hipMemcpy(h.data(), clk, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double cs = 0, rs = 0;
+  for (int i = 0; i < 256; ++i) { cs += (double)h[2 * i]; rs += (double)h[2 * i + 1]; }
+  const double ghz = cs / rs * 0.1;
+  const double flops = 10.0 * steps * 32.0 * 16384.0 * 8.0 * 256.0;
+  const double tf = flops / (best * 1e-3) * 1e-12;
+  printf("%-78s %7.1f TFLOP/s  clock %.2f GHz  = %4.1f %% of the peak at that clock  (%.2f us per 64-deep step)\n", name, tf, ghz,
+         100.0 * tf / (256 * 4 * 1024 * ghz * 1e-3), best * 1e3 / 10.0 / steps * 2.0);
+}
+
+int ring_main(const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA) {
+  printf("# both operands streamed from a 400 MB buffer (the weight-gradient case), 32-deep stages, eight waves\n");
+  run_ring<2>("R2 two 32-deep stages (one in flight at the wait)", rnd, sink, clk, gA, gA, 1024);
+  run_ring<3>("R3 three stages (two in flight)", rnd, sink, clk, gA, gA, 1024);
+  run_ring<4>("R4 four stages (three in flight: 96 KB per CU)", rnd, sink, clk, gA, gA, 1024);
   return 0;
 }
