@@ -2240,10 +2240,8 @@ uint32_t* v11_sched_slot(hipStream_t stream) {
 // 11 / 12 / 13: persistent 256x256 / 256x128 / 256x192 (four waves); 14 / 15: persistent 256x256 / 256x192, eight waves
 hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  if (variant == 6) {   // eight-wave persistent kernel around the bare K loop (gemm_lean.hip); static tiles: see variant 9 below
-    if (!g_shared_device) return kmb_gemm_lean_launch(p, stream);
-    variant = 14;
-  }
+  if (variant == 6)   // eight-wave persistent kernel around the bare K loop (gemm_lean.hip); tiles from a counter while the device is shared
+    return kmb_gemm_lean_launch(p, stream, g_shared_device ? v11_sched_slot(stream) : nullptr, g_shared_device);
   if (variant == 9) {   // two workgroups per CU (gemm_pair.hip)
     // its tiles are dealt statically: while another kernel (RCCL, kmb_gemm_shared_device) holds CUs, the persistent 256 x 128
     // kernel with dynamic hand-out takes the launch instead (same tile shape: every launch variant 9 admits, it admits)

@@ -8,7 +8,8 @@
 // rebuilding, the tile-decode / cursor / L2-touch arithmetic and its branches inside the scheduled region (13 branches and 32
 // spilled-scalar reloads per step in the ISA), the dynamic tile hand-out -- costs more than any of it buys.  This kernel is the
 // microbenchmark's loop with the minimum around it:
-//   * static tile assignment (per-XCD contiguous ranges), every tile interior (M % 256 == N % 256 == 0, K % 64 == 0);
+//   * per-XCD contiguous tile ranges, dealt statically -- or from an atomic counter while another kernel shares the device --,
+//     every tile interior (M % 256 == N % 256 == 0, K % 64 == 0);
 //   * per-lane LDS-DMA offsets are kernel constants, the tile bases scalar; the cursor's tile switch is the only branch in a step;
 //   * a tile's steps run in one branch-free loop; the last step leaves out the next fragments' reads, the lean epilogue
 //     (v11_epilogue_lean, one class per kernel instance) follows, then the reads;
@@ -35,7 +36,7 @@ __device__ __forceinline__ const char* ln_uniform(const char* ptr) {
 }
 
 template <bool B_KC, int EC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel_lean(const KmbGemm p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel_lean(const KmbGemm p, uint32_t* sched, int dyn_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,9 +65,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tq = ntiles >> 3, trem = ntiles & 7;
   const int range0 = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
   const int range1 = range0 + tq + (xcd < trem ? 1 : 0);
-  const int first_tile = range0 + loc;
-  if (first_tile >= range1) return;
-  const int nt = p.K / BK;   // >= 4 (launcher)
+  const int nt = p.K / BK;   // >= 4 (launcher; >= 6 when tiles are handed out dynamically)
+  // Tiles after the first (with dyn_first: all of them) come from an atomic counter per XCD range when another kernel shares the
+  // device (sched != nullptr: kmb_gemm_shared_device, an RCCL exchange on the communication stream): a workgroup that gets its CU
+  // late takes fewer tiles instead of leaving a fixed share to a straggling round.  As in gemm_kernel_v11: sched[0..7] tile counters,
+  // sched[8] finished workgroups, the last one zeroes them; the next tile is published through one LDS word.
+  const bool dyn = sched != nullptr;
+  uint32_t* const my_ctr = sched + xcd;
+  auto retire = [&]() {
+    if (dyn && tid == 0) {
+      if (atomicAdd(sched + 8, 1u) == gridDim.x - 1u) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sched[i] = 0u;
+      }
+    }
+  };
+  int* const next_slot = reinterpret_cast<int*>(smem + 2 * LN_STG);   // word 0 of wave 0's staging image (idle in the K loop)
+  const int dyn_base = (dyn && dyn_first) ? range0 : range0 + per;
+  int first_tile = range0 + loc;
+  if (dyn && dyn_first) {
+    if (tid == 0) *next_slot = range0 + (int)atomicAdd(my_ctr, 1u);
+    __syncthreads();
+    first_tile = __builtin_amdgcn_readfirstlane(*next_slot);
+    __syncthreads();
+  }
+  if (first_tile >= range1) { retire(); return; }
 
   // ---- LDS-DMA: kernel-constant lane offsets (interior tiles), scalar tile bases; the cursor runs two steps ahead ----
   uint32_t offA[4], offB[4];
@@ -75,6 +98,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
   const char *gA_d, *gB_d;
   int tile_d = first_tile, td = 0;
+  int tile_next = first_tile;   // the tile after the one being multiplied: known once the cursor has left that one
   // ---- L2 touch of the activation panel (gemm_kernel_v11, "L2 prefetch of the activation operand"): one stage in flight covers
   // an L2 round trip, not a memory one, and inside a step A was just streamed out by the previous kernel.  The workgroups that
   // share a row panel (the tiles of one tm: consecutive tiles, side by side on one XCD) each touch THEIR share of its rows
@@ -95,7 +119,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     gB_d = ln_uniform(reinterpret_cast<const char*>(p.B) + (B_KC ? (size_t)tn * 256 * p.ldb * 2 : (size_t)tn * 256 * 2));
     gA_tile = gA_d;
     pf_rows = (col_blocks ? tn % CB : tn) * pf_share;
-    const int tx = tile + per < range1 ? tile + per : tile;
+    const int tx = (!dyn && tile + per < range1) ? tile + per : tile;   // (dynamic hand-out: the tile after this one is not known yet)
     decode_tile(tx, tm, tn);
     gA_nx = ln_uniform(reinterpret_cast<const char*>(p.A) + (size_t)tm * 256 * p.lda * 2);
     pf_rows_nx = (col_blocks ? tn % CB : tn) * pf_share;
@@ -122,7 +146,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     gB_d = ln_uniform(gB_d + stepB);
     if (++td == nt) {
       td = 0;
-      if (tile_d + per < range1) tile_d += per;
+      tile_next = dyn ? __builtin_amdgcn_readfirstlane(*next_slot) : tile_d + per;
+      if (tile_next < range1) tile_d = tile_next;
       set_dma_tile(tile_d);
     }
   };
@@ -197,12 +222,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   float* const ef = reinterpret_cast<float*>(smem + 2 * LN_STG + wave * LN_EPW);
   int it = 0;   // linear K-step counter: stage buffer = it & 1
-  for (int tile = first_tile; tile < range1; tile += per) {
+  uint32_t fetched = 0u;
+  for (int tile = first_tile; tile < range1; tile = tile_next) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t + 1 < nt; ++t, ++it) kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, No{});
+    for (int t = 0; t + 1 < nt; ++t, ++it) {
+      // dynamic hand-out: the counter is read at the top of step 1 (behind step 0's touch, so the step waits stay exact: it is the
+      // youngest operation at step 1's wait and older than everything step 2's wait leaves out), published at the top of step 3,
+      // and read by the cursor behind the barrier of step nt - 3 >= 3
+      if (dyn && t == 1 && tid == 0) fetched = atomicAdd(my_ctr, 1u);
+      if (dyn && t == 3 && tid == 0) *next_slot = dyn_base + (int)fetched;
+      kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, No{});
+    }
     kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, Yes{});
     ++it;
     if (KMB_DIAG_BIT(p.tile_order, 512)) {   // epilogue ablation (diagnostic build only, tools/kloop_time.py): keep the accumulators alive
@@ -231,6 +264,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this workgroup is in flight when it ends
   asm volatile("" ::"v"(pf_sink));      // the touch's destination stays reserved for the whole kernel
+  retire();
 }
 
 int ln_class(const KmbGemm& p) {
@@ -246,7 +280,7 @@ int ln_class(const KmbGemm& p) {
 }
 
 template <bool B_KC>
-hipError_t ln_launch_layout(int ec, const KmbGemm& p, dim3 grid, hipStream_t stream) {
+hipError_t ln_launch_layout(int ec, const KmbGemm& p, dim3 grid, hipStream_t stream, uint32_t* sched, int dyn_first) {
 #define KMB_LN_CASE(E)                                                                                                          \
   case E: {                                                                                                                     \
     static bool attr = false;                                                                                                   \
@@ -255,7 +289,7 @@ hipError_t ln_launch_layout(int ec, const KmbGemm& p, dim3 grid, hipStream_t str
       if (e != hipSuccess) return e;                                                                                            \
       attr = true;                                                                                                              \
     }                                                                                                                           \
-    hipLaunchKernelGGL((gemm_kernel_lean<B_KC, E>), grid, dim3(512), LN_LDS, stream, p);                                         \
+    hipLaunchKernelGGL((gemm_kernel_lean<B_KC, E>), grid, dim3(512), LN_LDS, stream, p, sched, dyn_first);                                         \
     break;                                                                                                                      \
   }
   switch (ec) {
@@ -284,10 +318,13 @@ bool kmb_gemm_lean_ok(const KmbGemm& p) {
   return ln_class(p) >= 0;
 }
 
-hipError_t kmb_gemm_lean_launch(const KmbGemm& p, hipStream_t stream) {
+// sched: the launch's tile counters (16 zeroed words of the caller's ring, gemm.hip v11_sched_slot) or nullptr for static tiles;
+// dynamic hand-out needs K >= 6 * 64 (the counter's round trip runs under the first steps of a tile)
+hipError_t kmb_gemm_lean_launch(const KmbGemm& p, hipStream_t stream, uint32_t* sched, int dyn_first) {
   if (!kmb_gemm_lean_ok(p)) return hipErrorInvalidValue;
+  if (p.K / BK < 6) sched = nullptr;
   const long tiles = (long)(p.M / 256) * (p.N / 256);
   const dim3 grid(tiles >= 256 ? 256u : (unsigned)(tiles & ~7L));
   const int ec = ln_class(p);
-  return p.b_kc ? ln_launch_layout<true>(ec, p, grid, stream) : ln_launch_layout<false>(ec, p, grid, stream);
+  return p.b_kc ? ln_launch_layout<true>(ec, p, grid, stream, sched, dyn_first) : ln_launch_layout<false>(ec, p, grid, stream, sched, dyn_first);
 }

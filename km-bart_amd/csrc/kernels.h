@@ -16,7 +16,7 @@ hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream);
 void kmb_gemm_set_shared_device(int on);   // persistent variants: hand out every tile dynamically
 // variant 6 (gemm_lean.hip): the eight-wave persistent 256 x 256 kernel rebuilt around the bare K loop of tools/mfma_loop.hip
 bool kmb_gemm_lean_ok(const KmbGemm& p);
-hipError_t kmb_gemm_lean_launch(const KmbGemm& p, hipStream_t stream);
+hipError_t kmb_gemm_lean_launch(const KmbGemm& p, hipStream_t stream, uint32_t* sched, int dyn_first);
 // variant 9 (gemm_pair.hip): two persistent 256 x 128 workgroups per CU, 32-deep stages (forward layout)
 bool kmb_gemm_pair_ok(const KmbGemm& p);
 hipError_t kmb_gemm_pair_launch(const KmbGemm& p, hipStream_t stream);
