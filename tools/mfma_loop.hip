@@ -73,8 +73,8 @@ void loop_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsig
   uint32_t off[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) off[i] = (uint32_t)(((wave * NP + i) * 8 + (lane >> 3)) * 1536 + (((lane & 7) ^ ((((wave * NP + i) * 8 + (lane >> 3)) >> 1) & 7)) << 4));
-  int panel = apanels < 0 ? (int)blockIdx.x / -apanels : (int)blockIdx.x, kstep = 0;
-  const int npan = apanels < 0 ? 256 : apanels, pstep = apanels < 0 ? 22 : 293;
+  int panel = apanels < 0 ? (int)blockIdx.x / 12 : (int)blockIdx.x, kstep = 0;
+  const int npan = apanels < -100 ? 1024 : apanels < 0 ? 256 : apanels, pstep = apanels < 0 ? 22 : 293;
   auto dma = [&](char* stage) {
     const char* pa = gA + (size_t)panel * (256 * 1536) + kstep * 128;
     const char* pb = gB + (size_t)(panel % 12) * (256 * 1536) + kstep * 128;
@@ -200,6 +200,7 @@ void run(const char* name, const uint32_t* rnd, float* sink, unsigned long long*
 }
 
 int ring_main(const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA);
+int ring_shared(const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA, const char* gB);
 
 int main() {
   std::vector<uint32_t> h(2 * STG / 4);
@@ -235,7 +236,9 @@ int main() {
   run<6, 8>("7  8 waves: the same", rnd, sink, clk, gA, gB);
   run<6, 8>("8  as 7, the activation matrix 400 MB (1024 panels: beyond the Infinity Cache)", rnd, sink, clk, gA, gB, 1024);
   run<6, 8>("9  as 7, 21 panels shared by 12 workgroups each (the sharing of a 3072-column output)", rnd, sink, clk, gA, gB, -12);
+  run<6, 8>("9b as 9 over the 400 MB matrix (1024 panels)", rnd, sink, clk, gA, gB, -1024);
   ring_main(rnd, sink, clk, gA);
+  ring_shared(rnd, sink, clk, gA, gB);
   return 0;
 }
 
@@ -282,7 +285,9 @@ void ring_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsig
   uint32_t off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) off[i] = (uint32_t)(((wave * 2 + i) * 16 + (lane >> 2)) * 1536 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
-  int pa = (int)blockIdx.x, pb = ((int)blockIdx.x * 7 + 3) % apanels, kstep = 0;
+  const bool shared = apanels < 0;   // the forward / data-gradient case: A panel shared by 12 workgroups, B = 12 resident weight panels
+  const int npa = shared ? 1024 : apanels;
+  int pa = shared ? (int)blockIdx.x / 12 : (int)blockIdx.x, pb = shared ? (int)blockIdx.x % 12 : ((int)blockIdx.x * 7 + 3) % npa, kstep = 0;
   auto dma = [&](char* stage) {
     const uint64_t ua = (uint64_t)(gA + (size_t)pa * (256 * 1536) + kstep * 64), ub = (uint64_t)(gB + (size_t)pb * (256 * 1536) + kstep * 64);
     const char* sa = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ua >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ua));
@@ -295,7 +300,7 @@ void ring_kernel(const uint32_t* __restrict__ rnd, int steps, float* sink, unsig
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + off[i]),
                                        (__attribute__((address_space(3))) void*)(stage + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
-    if (++kstep == 24) { kstep = 0; pa = (pa + 293) % apanels; pb = (pb + 311) % apanels; }
+    if (++kstep == 24) { kstep = 0; pa = (pa + (shared ? 22 : 293)) % npa; if (!shared) pb = (pb + 311) % npa; }
   };
   auto step = [&](char* cur, const char* nxt, bfrag (&fb)[4], bfrag (&fbn)[4]) {
     read_a(cur, 1, fa1);
@@ -373,5 +378,13 @@ int ring_main(const uint32_t* rnd, float* sink, unsigned long long* clk, const c
   run_ring<2>("R2 two 32-deep stages (one in flight at the wait)", rnd, sink, clk, gA, gA, 1024);
   run_ring<3>("R3 three stages (two in flight)", rnd, sink, clk, gA, gA, 1024);
   run_ring<4>("R4 four stages (three in flight: 96 KB per CU)", rnd, sink, clk, gA, gA, 1024);
+  return 0;
+}
+
+int ring_shared(const uint32_t* rnd, float* sink, unsigned long long* clk, const char* gA, const char* gB) {
+  printf("# activation panels (400 MB matrix) shared by 12 workgroups each, weights resident (the forward / data-gradient case), 32-deep stages\n");
+  run_ring<2>("S2 two 32-deep stages", rnd, sink, clk, gA, gB, -1);
+  run_ring<3>("S3 three stages", rnd, sink, clk, gA, gB, -1);
+  run_ring<4>("S4 four stages (three in flight)", rnd, sink, clk, gA, gB, -1);
   return 0;
 }
