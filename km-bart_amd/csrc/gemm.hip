@@ -73,6 +73,10 @@ extern "C" int kmb_debug_set_stamps(void* p) {
 #define KMB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
 
+// The L2 touch of the persistent kernels: a load whose result nobody reads, into v255 -- a register their kernels are compiled
+// not to allocate (__attribute__((amdgpu_num_vgpr(255)))), so no value can ever live where a touch in flight will land.
+#define KMB_L2_TOUCH(voff, sbase) asm volatile("global_load_dword v255, %0, %1" ::"v"(voff), "s"(sbase) : "memory", "v255")
+
 namespace {
 
 int g_shared_device = 0;   // kmb_gemm_shared_device(): other kernels (RCCL) hold CUs while the GEMMs run
@@ -1428,7 +1432,8 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 // an 18.8 us K loop -- and the second wave halves exactly that part.  The K loop is v8's (same fragments, same
 // accumulation order: bit-identical), MFMA-paced either way.
 template <bool A_KC, bool B_KC, int BNT, int NW = 4>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) __attribute__((amdgpu_num_vgpr(255)))
+void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   static_assert(NW == 4 || (NW == 8 && (BNT == 256 || BNT == 192)), "eight waves: 256 x 256 and 256 x 192 tiles only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KMB_STAMP(0);
@@ -1559,7 +1564,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   // The first KMB_PFD steps of a tile have no earlier step of the same tile to be prefetched from: they are touched
   // from the tile `per` places earlier in the range -- the tile whose workgroup is one round ahead of the one that will
   // take this tile (tiles are handed out in range order, so the workgroups of one round run the sharers of a panel).
-  uint32_t pf_off = 0u, pfn_off = 0u, pf_sink = 0u;
+  uint32_t pf_off = 0u, pfn_off = 0u;
   const char* pfn_base = reinterpret_cast<const char*>(p.A);
   bool pf_pending = false, pfn_ok = false;
   auto pf_row_offset = [&](int tn, int row0) {
@@ -1745,7 +1750,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     for (int i = 2; i < 2 + KMB_PFD; ++i) {
       if (i < nt) {
         const char* pbase = uniform_ptr(gA_d + (size_t)i * stepA);
-        asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_off), "s"(pbase) : "memory");
+        KMB_L2_TOUCH(pf_off, pbase);
       }
     }
   }
@@ -1844,10 +1849,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
         // that wait is vmcnt(1) for wave 0 and the touch -- an HBM miss by design -- has until the NEXT step's wait to
         // land.  (Issued as the oldest operation of the window behind a plain vmcnt(0) it sat in front of the stage's
         // pieces in the in-order return queue and the whole gain was gone: 42.2 vs 39.5 ms of in-step GEMM time.)
-        // Its destination is ONE register web for the whole kernel ("+v": every touch reads and writes pf_sink, the last
-        // use is at the end of the kernel), so the allocator cannot hand the register to another value while a load is
-        // still going to write it.  Round 2's form ("=v": a fresh value per touch, dead at once) allowed exactly that:
-        // invisible with 256 free registers, wrong bits in the eight-wave kernel (tools/gemm_v11_check.py, 14o1p).
+        // Its destination is v255, which the kernel is compiled NOT to allocate (amdgpu_num_vgpr(255), KMB_L2_TOUCH): a touch
+        // still in flight can never land in a register that has been handed to another value.  (Round 2's form -- "=v", a fresh
+        // value per touch -- allowed exactly that: wrong bits in the eight-wave kernel; round 3's -- one "+v" register web for the
+        // whole kernel -- held in the product builds but not under more register pressure: a memory fault in the stamp build, wrong
+        // results in an experimental build of gemm_lean.hip in round 4.)
         // No touch in a tile's last K step: that step's wait is vmcnt(0), nothing is in flight across the epilogue,
         // where the register may be spilled and reused.
         const int ps = td + KMB_PFD;   // td: the step the next fetch of this workgroup asks for
@@ -1856,7 +1862,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
         if (pf_pending) {
           const char* pbase = uniform_ptr(in_tile ? gA_d + (size_t)KMB_PFD * stepA : pfn_base + (size_t)(ps - nt) * stepA);
           const uint32_t poff = in_tile ? pf_off : pfn_off;
-          asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(poff), "s"(pbase) : "memory");
+          KMB_L2_TOUCH(poff, pbase);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1983,7 +1989,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     }
 #endif
   }
-  if (PF_ON) asm volatile("" ::"v"(pf_sink));   // the prefetch destination stays reserved for the whole kernel
   KMB_STAMP_VALUE(2, kmb_loop_ticks);
   KMB_STAMP_VALUE(3, kmb_epi_ticks);
   KMB_STAMP_VALUE(5, kmb_wait_ticks);

@@ -36,7 +36,7 @@ __device__ __forceinline__ const char* ln_uniform(const char* ptr) {
 }
 
 template <bool B_KC, int EC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel_lean(const KmbGemm p, uint32_t* sched, int dyn_first) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) __attribute__((amdgpu_num_vgpr(255))) void gemm_kernel_lean(const KmbGemm p, uint32_t* sched, int dyn_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (first_tile >= range1) { retire(); return; }
 
   // ---- LDS-DMA: kernel-constant lane offsets (interior tiles), scalar tile bases; the cursor runs two steps ahead ----
-  uint32_t offA[4], offB[4];
+  constexpr int NPW = 4;
+  uint32_t offA[NPW], offB[NPW];
   dma_offsets256w4<true, 4>(offA, p.lda, 0, 1 << 30, wave, lane);
   dma_offsets256w4<B_KC, 4>(offB, p.ldb, 0, 1 << 30, wave, lane);
   const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
@@ -103,15 +104,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // an L2 round trip, not a memory one, and inside a step A was just streamed out by the previous kernel.  The workgroups that
   // share a row panel (the tiles of one tm: consecutive tiles, side by side on one XCD) each touch THEIR share of its rows
   // LN_PFD steps ahead of the DMA cursor, one load instruction per wave right behind a stage's pieces; the step's wait leaves it
-  // outstanding (vmcnt 1), so it has a whole step to land.  Its result is never used; its destination is one register web for
-  // the whole kernel (see gemm_kernel_v11).  Not for the data-gradient layout's B (the weights: L2 / Infinity Cache residents).
+  // outstanding (vmcnt 1), so it has a whole step to land.  Its result is never used; its destination is v255, which the kernel
+  // does not allocate (KMB_L2_TOUCH, gemm.hip).  Not for the data-gradient layout's B (the weights: L2 / Infinity Cache residents).
   constexpr int LN_PFD = 2;
   const int sharers = col_blocks ? CB : tiles_n;
   const int pf_share = (256 + sharers - 1) / sharers;
   const int pf_gs = (pf_share + 7) >> 3;                 // rows per wave
   const char *gA_tile, *gA_nx;
   int pf_rows = 0, pf_rows_nx = 0;
-  uint32_t pf_sink = 0u;
   auto set_dma_tile = [&](int tile) {
     int tm, tn;
     decode_tile(tile, tm, tn);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       row += nx ? pf_rows_nx : pf_rows;
       row = row < 256 ? row : 255;
       const uint32_t voff = (uint32_t)row * (uint32_t)p.lda * 2u;
-      asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(voff), "s"(sbase) : "memory");
+      KMB_L2_TOUCH(voff, sbase);
     }
     gA_d = ln_uniform(gA_d + BK * 2);
     gB_d = ln_uniform(gB_d + stepB);
@@ -263,7 +263,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     read_a(smem + (it & 1) * LN_STG, 0, 0, fa[0]);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this workgroup is in flight when it ends
-  asm volatile("" ::"v"(pf_sink));      // the touch's destination stays reserved for the whole kernel
   retire();
 }
 

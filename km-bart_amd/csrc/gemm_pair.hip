@@ -50,7 +50,7 @@ __device__ __forceinline__ const char* pr_uniform(const char* ptr) {
 }
 
 template <int EC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel_pair(const KmbGemm p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) __attribute__((amdgpu_num_vgpr(255))) void gemm_kernel_pair(const KmbGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ahead of the DMA cursor -- one load instruction per wave behind every stage's pieces, a 128-byte line serves two steps, the
   // step's parity picks which half of the wave's rows it touches -- and the pieces of all sharers then hit L2.  The load's result
   // is never used; every wait leaves it outstanding (vmcnt 8 = the previous touch, a stage's six pieces, this touch) so that it
-  // has three steps to land; its destination is one register web for the whole kernel (see gemm_kernel_v11).
+  // has three steps to land; its destination is v255, which the kernel does not allocate (KMB_L2_TOUCH, gemm.hip).
   constexpr int PR_PFD = 4;
   const int sharers = col_blocks ? CB : tiles_n;
   int pf_share = (PR_BM + sharers - 1) / sharers;
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int pf_gs = (pf_share + 7) >> 3;                  // rows per (wave, parity) group; <= 32
   const char *gA_tile, *gA_nx;                            // panel bases of the cursor's tile and of the workgroup's tile after it
   int pf_rows = 0, pf_rows_nx = 0;                        // first row of this workgroup's share in those panels
-  uint32_t pf_sink = 0u;
   auto set_dma_tile = [&](int tile) {
     int tm, tn;
     decode_tile(tile, tm, tn);
@@ -136,9 +135,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     row = row < PR_BM ? row : PR_BM - 1;
     const uint32_t voff = (uint32_t)row * (uint32_t)p.lda * 2u;
 #if !defined(KMB_PR_NODMA) && !defined(KMB_PR_NOTOUCH)
-    asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(voff), "s"(sbase) : "memory");
+    KMB_L2_TOUCH(voff, sbase);
 #else
-    asm volatile("" : "+v"(pf_sink) : "v"(voff), "s"(sbase));
+    asm volatile("" ::"v"(voff), "s"(sbase));
 #endif
   };
   // the next stage of the DMA cursor into buffer `buf`; past the workgroup's last tile the last tile's steps are fetched
@@ -315,7 +314,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     read_a(smem, 0, fa0);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this workgroup is in flight when it ends
-  asm volatile("" ::"v"(pf_sink));      // the touch's destination stays reserved for the whole kernel
 }
 
 int pr_class(const KmbGemm& p) {

@@ -1,12 +1,10 @@
 """The clock the chip holds inside the persistent GEMM kernels (MI355X_MICROARCH.md 'DVFS give-back' item 6): shader-clock ticks
 (s_memtime) over real-time ticks (s_memrealtime, 100 MHz) stamped around each persistent workgroup's whole life, after >= 2 s of
 back-to-back launches of the same shape on random data.  Diagnostic build (-DKMB_GEMM_STAMP -DKMB_STAMP_SLOTS=12 -DKMB_V11_PREFETCH=0), never the
-product library.  (The L2 touch of the activation panel is compiled out: its asm load keeps one register reserved for the whole kernel,
-and with the stamp build's extra live values the allocator splits that web -- memory fault, the hazard DESIGN.md section 4 "Round 4"
-describes for inline-asm loads under register pressure.  The product kernel has 20 registers of headroom and the bitwise tests.)
-
-    python tools/gemm_clock.py --build       (no GPU needed)
-    KMB_GEMM_VARIANT=11 python tools/gemm_clock.py [zeros]
+product library.  (The L2 touch of the activation panel is compiled out: when this tool was written the touch's asm load kept one register
+"reserved" only by a "+v" constraint chain, and with the stamp build's extra live values the allocator split that web -- memory fault.
+Since then the touch writes v255 and the kernels are compiled not to allocate it (KMB_L2_TOUCH, csrc/gemm.hip); the flag stays so that
+the committed clock figures remain reproducible.)
 """
 import os
 import subprocess
