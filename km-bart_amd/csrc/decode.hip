@@ -219,6 +219,19 @@ __device__ __forceinline__ float group16_sum(float v) {
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
   return v;
 }
+// the same over rotations inside a row of 16 lanes (DPP row_ror: a register move, not a trip through the LDS crossbar)
+template <int CTRL>
+__device__ __forceinline__ float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, row_ror<0x128>(v)); v = fmaxf(v, row_ror<0x124>(v)); v = fmaxf(v, row_ror<0x122>(v)); v = fmaxf(v, row_ror<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += row_ror<0x128>(v); v += row_ror<0x124>(v); v += row_ror<0x122>(v); v += row_ror<0x121>(v);
+  return v;
+}
 
 // Which (weight slice, row tile) a workgroup takes.  The `tiles` row tiles that read the same weight slice are split
 // into RG groups; a (slice, group) unit runs on ONE XCD (workgroup b runs on XCD b % 8), so a slice crosses the fabric
@@ -337,9 +350,20 @@ __global__ __launch_bounds__(256, 2) void decode_proj_wide_kernel(const KmbDecod
 // bytes of this head) into LDS once -- whole 128-byte lines, requested right behind the weight fragments so they land
 // during the projection -- instead of every row fetching its own 32-byte pieces from L2 (16 x Tk x 256 bytes in
 // quarter-line requests: the request rate of the vector memory pipe made that 19 of the block's 26 us).
+// With the keys / values of the tile's items in LDS the attention itself runs on the matrix cores (round 4; on the vector
+// ALUs the 64-key cross-attention was 8.4 of the block's 18 us: 2 x 65 k multiply-adds per workgroup, each with a bf16 unpack):
+//   scores  S^T = K_staged q^T   : one 16-key tile x 16 rows per MFMA pair, EVERY staged key against every row (<= 4 items:
+//                                  the products of the other items' keys are computed and dropped -- 16 MFMAs per wave)
+//   softmax per row over its own item's keys (fp32, as before); e = exp(s - max) leaves as TWO bf16 matrices e_hi + e_lo
+//                                  (e_hi = bf16(e), e_lo = bf16(e - e_hi): 16 significant bits, so that the weights carry
+//                                  the precision the fp32 vector path gave them), zero at the other items' keys
+//   output  O^T = V_staged^T (e_hi + e_lo)^T : values read as transposed fragments (ds_read_b64_tr_b16), wave w owns
+//                                  head dimensions 16 w .. 16 w + 15; scaled by 1 / sum(e) at the store.
 constexpr int KV_ITEMS = 4;      // batch items a 16-row tile can touch when kv_group >= 4
 constexpr int NKV = 15;          // 16-byte chunks per thread and operand: KV_ITEMS * Tk * 8 <= NKV * 256  (Tk <= 120)
-constexpr int KS = 144;          // LDS row stride of a staged key row (128 + 16: spreads the 4-keys-per-step reads)
+constexpr int KS = 144;          // LDS row stride of a staged key row (128 + 16: conflict-free 16-row fragment reads)
+__host__ __device__ constexpr int kv_pad(int Tk) { return (KV_ITEMS * Tk + 31) & ~31; }     // staged keys, padded to MFMA K steps
+__host__ __device__ constexpr int pb_stride(int Tk) { return kv_pad(Tk) * 2 + 16; }          // bytes per row of e_hi / e_lo
 
 template <bool SELF, bool KVLDS>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p) {
@@ -384,14 +408,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
     const bf16_t* vc = p.Vc + (size_t)prow * p.Tmax * p.ldc + h * HD;
     const int tc = p.Tk - 1;
 #pragma unroll
-    for (int u = 0; u < KU; ++u) {
+    for (int u = 0; u < KU; ++u) {   // (positions past the cache: no request; their scores / weights are never used)
       const int t = (a_s >> 2) + 4 * u;
-      const bf16_t* kr = kc + (size_t)(t < tc ? t : 0) * p.ldc + (a_s & 3) * 16;
-      pk0[u] = *reinterpret_cast<const u32x4*>(kr);
-      pk1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+      pk0[u] = pk1[u] = u32x4{0u, 0u, 0u, 0u};
+      if (4 * u < tc) {   // wave-uniform
+        const bf16_t* kr = kc + (size_t)(t < tc ? t : 0) * p.ldc + (a_s & 3) * 16;
+        pk0[u] = *reinterpret_cast<const u32x4*>(kr);
+        pk1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < VU; ++u) pv[u] = *reinterpret_cast<const uint2*>(vc + (size_t)(u < tc ? u : 0) * p.ldc + a_s * 4);
+    for (int u = 0; u < VU; ++u) {
+      pv[u] = uint2{0u, 0u};
+      if (u < tc) pv[u] = *reinterpret_cast<const uint2*>(vc + (size_t)u * p.ldc + a_s * 4);
+    }
   }
   // KVLDS: this thread's chunks of the tile's keys / values (chunk c = tid + 256 i: staged row c / 8, 16-byte piece c % 8)
   [[maybe_unused]] u32x4 kreg[KVLDS ? NKV : 1], vreg[KVLDS ? NKV : 1];
@@ -409,10 +439,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
     const int seg = threadIdx.x & 7;
 #pragma unroll
     for (int i = 0; i < NKV; ++i) {
-      const bool ok = rowi < kv_rows;
-      const size_t off = ((size_t)(first_item + (ok ? li : 0)) * p.Tmax + (ok ? t : 0)) * p.ldc + h * HD + seg * 8;
-      kreg[i] = *reinterpret_cast<const u32x4*>(p.Kc + off);
-      vreg[i] = *reinterpret_cast<const u32x4*>(p.Vc + off);
+      if (rowi < kv_rows) {   // (no request at all past the staged rows: the block is bound by the requests a CU can issue)
+        const size_t off = ((size_t)(first_item + li) * p.Tmax + t) * p.ldc + h * HD + seg * 8;
+        kreg[i] = *reinterpret_cast<const u32x4*>(p.Kc + off);
+        vreg[i] = *reinterpret_cast<const u32x4*>(p.Vc + off);
+      }
       rowi += 32; t += 32;
       while (t >= p.Tk) { t -= p.Tk; ++li; }
     }
@@ -424,6 +455,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
       }
     }
   }
+  DSTAMP(stype, 7);   // every load of the block has been issued
   rows_finish<2>(rr, row0, p.R, p.K, p.gamma, p.beta, p.eps, h == 0 ? p.ln_out : nullptr, smem, a_stride, wave, lane);
   __syncthreads();
   DSTAMP(stype, 1);
@@ -471,6 +503,91 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   DSTAMP(stype, 2);
   __syncthreads();
   DSTAMP(stype, 3);
+  if constexpr (KVLDS) {
+    // ---- attention on the matrix cores (see the note above KV_ITEMS) ----
+    const int r = lane & 15, g = lane >> 4;
+    const int Tk = p.Tk, kpad = (kv_rows + 31) & ~31, PBS = pb_stride(Tk);
+    char* const pb_hi = smem;                                               // the activation rows are done with
+    char* const pb_lo = reinterpret_cast<char*>(lds_m + KV_ITEMS * Tk);
+    float* const inv_s = reinterpret_cast<float*>(pb_lo + RT * PBS);
+    const int t2 = 2 * Tk, t3 = 3 * Tk;
+    {   // scores: lane (r, g) of key tile kt ends up with keys kt * 16 + 4 g .. + 3 of row r
+      const int rrow = row0 + r < p.R ? row0 + r : p.R - 1;
+      const int item_r = rrow / p.kv_group - first_item;
+      const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(lds_q + r * QS + g * 16);
+      const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(lds_q + r * QS + 64 + g * 16);
+      for (int kt = wave; kt * 16 < kv_rows; kt += 4) {
+        const int key = kt * 16 + r < kv_rows ? kt * 16 + r : 0;
+        const char* kr = lds_k + (size_t)key * KS + g * 16;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr), q0, sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + 64), q1, sa, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kidx = kt * 16 + 4 * g + e;
+          const int it = (kidx >= Tk) + (kidx >= t2) + (kidx >= t3);
+          if (kidx < kv_rows && it == item_r) sc[(size_t)r * Tk + (kidx - it * Tk)] = sa[e] + lds_m[kidx];
+        }
+      }
+    }
+    __syncthreads();
+    DSTAMP(stype, 4);
+    {   // softmax: 16 lanes per row; e_hi / e_lo over the staged key index (eight keys = one 16-byte store per lane and
+        // matrix), zero outside the row's item
+      const int lr = threadIdx.x >> 4, s = threadIdx.x & 15;
+      const int rrow = row0 + lr < p.R ? row0 + lr : p.R - 1;
+      const int lo_k = (rrow / p.kv_group - first_item) * Tk, hi_k = lo_k + Tk;   // the item's staged keys
+      const float* my = sc + (size_t)lr * Tk;
+      float mx = -INFINITY;
+      for (int t = s; t < Tk; t += 16) mx = fmaxf(mx, my[t]);
+      mx = row16_max(mx);
+      float l = 0.f;
+      for (int c = s * 8; c < kpad; c += 128) {
+        float e[8], rem[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = 0.f;
+        if (c + 8 > lo_k && c < hi_k && mx != -INFINITY) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (c + i >= lo_k && c + i < hi_k) e[i] = __expf(my[c + i - lo_k] - mx);
+        }
+        const u32x4 hi = pack8(e);
+        float back[8];
+        unpack8(hi, back);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { l += e[i]; rem[i] = e[i] - back[i]; }
+        *reinterpret_cast<u32x4*>(pb_hi + lr * PBS + c * 2) = hi;
+        *reinterpret_cast<u32x4*>(pb_lo + lr * PBS + c * 2) = pack8(rem);
+      }
+      l = row16_sum(l);
+      if (s == 0) inv_s[lr] = l > 0.f ? 1.f / l : 0.f;
+    }
+    __syncthreads();
+    f32x4 oa = {0.f, 0.f, 0.f, 0.f};   // lane (r, g): head dimensions 16 wave + 4 g .. + 3 of row r
+    for (int k0 = 0; k0 < kpad; k0 += 32) {
+      bf16x8 vf;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        int krow = k0 + g * 8 + hh * 4 + (r >> 2);
+        krow = krow < kv_rows ? krow : kv_rows - 1;   // its weight is zero; the row has to be finite
+        const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(lds_v + (size_t)krow * 128 + wave * 32 + (r & 3) * 8));
+        vf[hh * 4 + 0] = t[0]; vf[hh * 4 + 1] = t[1]; vf[hh * 4 + 2] = t[2]; vf[hh * 4 + 3] = t[3];
+      }
+      const bf16x8 ph = *reinterpret_cast<const bf16x8*>(pb_hi + r * PBS + (k0 + g * 8) * 2);
+      const bf16x8 pl = *reinterpret_cast<const bf16x8*>(pb_lo + r * PBS + (k0 + g * 8) * 2);
+      oa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oa, 0, 0, 0);
+      oa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl, oa, 0, 0, 0);
+    }
+    DSTAMP(stype, 5);
+    if (row0 + r < p.R) {
+      const float inv = inv_s[r];
+      *reinterpret_cast<uint2*>(p.out + (size_t)(row0 + r) * p.ld_out + h * HD + wave * 16 + g * 4) =
+          uint2{pack2bf(oa[0] * inv, oa[1] * inv), pack2bf(oa[2] * inv, oa[3] * inv)};
+    }
+    DSTAMP(stype, 6);
+    return;
+  }
   // ---- attention ----
   const int lr = threadIdx.x >> 4, s = threadIdx.x & 15;
   const int row = row0 + lr;
@@ -647,7 +764,7 @@ hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream) 
   }
   const bool self = p.kind == 1;
   const size_t lds = a_bytes + (size_t)RT * ((self ? 3 * HD : HD) + 8) * 2 + (((size_t)RT * p.Tk * sizeof(float) + 15) & ~(size_t)15);
-  const size_t lds_kv = lds + (size_t)KV_ITEMS * p.Tk * (KS + 128 + sizeof(float));
+  const size_t lds_kv = lds + (size_t)KV_ITEMS * p.Tk * (KS + 128 + sizeof(float)) + (size_t)RT * pb_stride(p.Tk) + RT * sizeof(float);
   static size_t set_s = 0, set_c = 0, set_l = 0;
   if (self) {
     if (lds > set_s) { e = set_lds(decode_attn_kernel<true, false>, lds); if (e != hipSuccess) return e; set_s = lds; }

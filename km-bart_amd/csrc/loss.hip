@@ -565,28 +565,131 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// wave-wide maximum of a float, result in every lane (same DPP pattern as wave_max_u64)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_maxf_step(float v) {
+  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+  return fmaxf(v, o);
+}
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+  v = dpp_maxf_step<0x121, 0xf>(v);
+  v = dpp_maxf_step<0x122, 0xf>(v);
+  v = dpp_maxf_step<0x124, 0xf>(v);
+  v = dpp_maxf_step<0x128, 0xf>(v);
+  v = dpp_maxf_step<0x142, 0xa>(v);
+  v = dpp_maxf_step<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Selection inside a wave (64 lanes x 4 NV values, k best as 64-bit keys into cand[0 .. TOPK_KMAX), 0 = none), round 4:
+// the kernel is bound by its vector-ALU work (5 waves per SIMD x ~2500 instructions; the first form built a 64-bit key
+// per element and kept every thread's best two keys: 14 instructions per element, 220 registers, three rounds of
+// workgroups per launch), so the keys are not built at all for elements that cannot win:
+//   1. every lane's two largest VALUES (three instructions per element),
+//   2. at most k rounds of a wave-wide maximum over the lanes' current best, the winners popping to their second value,
+//      until k values have been counted: the last maximum T is a LOWER bound of the wave's k-th largest value (a lane
+//      holding three or more of the k best has contributed only two, the count was filled by smaller ones),
+//   3. one pass over the elements: the few with value >= T (k, plus ties and the third-bests of step 2) get their key
+//      and a slot of cand[] (ballot + prefix count).  The caller's merge of the waves orders by key as before.
+// Fewer than k finite values in the wave, or more than TOPK_KMAX elements >= T (rows of equal logits): the exact, slow
+// form below -- k rounds of "largest key below the previous winner" over all elements.  Same keys, same order of the
+// final result either way.
+template <int NV>
+__device__ __forceinline__ void wave_topk(const f32x4 (&x)[NV], int idx0, int chunks_left, int V, int ban, int k, int lane,
+                                          unsigned long long* cand) {
+  // idx0: index of x[0][0] of this thread; element (j, e) has index idx0 + 1024 j + e; valid iff j * 256 < chunks_left
+  // (chunks_left = chunks_per_part - tid), index < V and != ban.  Invalid elements hold -inf (the caller masked them).
+  float v1 = -INFINITY, v2 = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = fminf(v1, x[j][e]);
+      v1 = fmaxf(v1, x[j][e]);
+      v2 = fmaxf(v2, t);
+    }
+  int cnt = 0;
+  float T = -INFINITY;
+  bool exact = false;
+  for (int jr = 0; jr < k && cnt < k; ++jr) {
+    const float wm = wave_max_f32_dpp(v1);
+    if (wm == -INFINITY) { exact = true; break; }
+    const bool mine = v1 == wm;
+    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+    T = wm;
+    if (mine) { v1 = v2; v2 = -INFINITY; }
+  }
+  if (cnt < k) exact = true;
+  int n = 0;
+  if (!exact) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool hit = x[j][e] >= T;   // T > -inf: invalid elements never hit
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+        if (bal != 0ull) {
+          const int slot = n + __builtin_popcountll(bal & below);
+          if (hit && slot < TOPK_KMAX) cand[slot] = topk_key(x[j][e], idx0 + 1024 * j + e);
+          n += __builtin_popcountll(bal);
+        }
+      }
+    if (n > TOPK_KMAX) exact = true;
+  }
+  if (!exact) {
+    if (lane >= n && lane < TOPK_KMAX) cand[lane] = 0ull;
+    return;
+  }
+  unsigned long long last = ~0ull;
+  for (int jr = 0; jr < TOPK_KMAX; ++jr) {
+    unsigned long long best = 0ull;
+    if (jr < k && last != 0ull) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = idx0 + 1024 * j + e;
+          unsigned long long key = (j * 256 < chunks_left && i < V && i != ban) ? topk_key(x[j][e], i) : 0ull;
+          key = key < last ? key : 0ull;
+          best = key > best ? key : best;
+        }
+      best = wave_max_u64(best);
+      last = best;
+    }
+    if (lane == 0) cand[jr] = best;
+  }
+}
+
+#ifndef KMB_TOPK_OCC
+#define KMB_TOPK_OCC 4   // workgroups per CU the register budget is cut for (128 registers: no spills; 2, 4 and 5 measure alike)
+#endif
 template <int NV>   // float4 chunks per thread: chunks per part <= NV * 256
-__global__ __launch_bounds__(256) void topk_part_kernel(const float* __restrict__ logits, int ldv, int V, int ban, int k,
-                                                        int chunks_per_part, float* __restrict__ part) {
+__global__ __launch_bounds__(256, KMB_TOPK_OCC) void topk_part_kernel(const float* __restrict__ logits, int ldv, int V, int ban, int k,
+                                                                      int chunks_per_part, float* __restrict__ part) {
   __shared__ float sh[8];
   __shared__ unsigned long long cand[4][TOPK_KMAX];
   const int p = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* row = logits + (size_t)r * ldv;
   f32x4 x[NV];
   float m = -INFINITY;
+  // every load first, from a clamped address and with no branch around it: a load inside `if (in range) { load; mask; }` is
+  // followed by its own s_waitcnt vmcnt(0), i.e. NV dependent memory round trips per thread (rounds 2-3 shipped that)
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = tid + 256 * j;
     const int i = (p * chunks_per_part + c) * 4;
-    if (c < chunks_per_part && i < ldv) {
-      x[j] = *reinterpret_cast<const f32x4*>(row + i);
+    x[j] = *reinterpret_cast<const f32x4*>(row + ((c < chunks_per_part && i < ldv) ? i : 0));
+  }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (i + e >= V) x[j][e] = -INFINITY;
-        m = fmaxf(m, x[j][e]);
-      }
-    } else {
-      x[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int j = 0; j < NV; ++j) {
+    const int c = tid + 256 * j;
+    const int i = (p * chunks_per_part + c) * 4;
+    const bool in = c < chunks_per_part && i < ldv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!in || i + e >= V) x[j][e] = -INFINITY;
+      m = fmaxf(m, x[j][e]);
     }
   }
   m = wave_max(m);
@@ -602,46 +705,21 @@ __global__ __launch_bounds__(256) void topk_part_kernel(const float* __restrict_
   }
   sum = wave_sum(sum);
   if (lane == 0) sh[4 + wave] = sum;
-  // this thread's two best keys (0 = none); the banned token is excluded AFTER the normalisation above
-  unsigned long long b1 = 0ull, b2 = 0ull;
+  // the banned token is excluded AFTER the normalisation above
+  const int idx0 = (p * chunks_per_part + tid) * 4;
+  if (ban >= 0) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = (p * chunks_per_part + tid + 256 * j) * 4 + e;
-      const unsigned long long key = (tid + 256 * j < chunks_per_part && i < V && i != ban) ? topk_key(x[j][e], i) : 0ull;
-      const unsigned long long lo = key < b1 ? key : b1;
-      b1 = key > b1 ? key : b1;
-      b2 = lo > b2 ? lo : b2;
-    }
-  bool b2_known = true;
-  for (int jr = 0; jr < k; ++jr) {
-    const unsigned long long wk = wave_max_u64(b1);
-    if (lane == 0) cand[wave][jr] = wk;
-    if (wk == 0ull) continue;
-    const bool mine = b1 == wk;   // indices are unique: exactly one lane
-    if (__builtin_amdgcn_ballot_w64(mine && !b2_known) != 0ull) {   // wave-uniform: a second win of the same thread
-      unsigned long long nk = 0ull;
-#pragma unroll
-      for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = (p * chunks_per_part + tid + 256 * j) * 4 + e;
-          unsigned long long key = (tid + 256 * j < chunks_per_part && i < V && i != ban) ? topk_key(x[j][e], i) : 0ull;
-          key = key < wk ? key : 0ull;
-          nk = key > nk ? key : nk;
-        }
-      if (mine) b1 = nk;
-    } else if (mine) {
-      b1 = b2;
-      b2_known = false;
-    }
+      for (int e = 0; e < 4; ++e)
+        if (idx0 + 1024 * j + e == ban) x[j][e] = -INFINITY;
   }
+  wave_topk<NV>(x, idx0, chunks_per_part - tid, V, ban, k, lane, cand[wave]);
   __syncthreads();
   if (wave == 0) {
     float* out = part + ((size_t)r * TOPK_PARTS + p) * TOPK_PW;
     if (lane == 0) { out[0] = m; out[1] = (sh[4] + sh[5]) + (sh[6] + sh[7]); }
-    unsigned long long key = lane < 4 * k ? cand[lane / k][lane % k] : 0ull;   // 4 k <= 64
+    unsigned long long key = cand[lane >> 4][lane & 15];   // 4 x TOPK_KMAX = 64
     for (int jr = 0; jr < k; ++jr) {
       const unsigned long long wk = wave_max_u64(key);
       if (lane == 0) {

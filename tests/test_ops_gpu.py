@@ -436,6 +436,46 @@ class _TopkWithScratch:
         return self.lib.kmb_logsoftmax_topk_ws(*a[:-1], ptr(self.scr), self.scr.numel(), a[-1])
 
 
+@pytest.mark.parametrize("ws", [False, True])
+def test_logsoftmax_topk_degenerate_rows(ws):
+    """Rows on which the split form's threshold selection has to give up (csrc/loss.hip wave_topk: more than 16 elements at
+    or above the k-th value of a wave, or fewer than k finite values) -- the exact path; order = (value desc, index asc)."""
+    lib = _lib.load()
+    V, ld, k = 50320, 50432, 10
+    base = rnd(8, V, seed=66) * 2
+    rows_l = []
+    rows_l.append(torch.zeros(V, device=DEV))                                   # every logit equal
+    r = base[1].clone(); r[1000:1100] = 30.0; rows_l.append(r)                     # a hundred copies of the maximum
+    r = torch.full((V,), -float("inf"), device=DEV); r[[7, 20000, 49000]] = torch.tensor([1.0, 3.0, 2.0], device=DEV); rows_l.append(r)
+    r = base[3].clone(); r[12600:] = -float("inf"); rows_l.append(r)               # three of the four parts hold nothing finite
+    r = base[4].clone(); r[::2] = r[1::2]; rows_l.append(r)                        # every value twice
+    r = base[5].clone(); r[40000:40040] = r.max() + 1.0; rows_l.append(r)          # forty ties above everything, in one part
+    r = torch.full((V,), -float("inf"), device=DEV); rows_l.append(r)              # nothing finite at all
+    rows_l.append(base[7].clone())
+    logits = torch.zeros((len(rows_l), ld), device=DEV)
+    logits[:, :V] = torch.stack(rows_l)
+    rows = logits.shape[0]
+    if ws:
+        lib = _TopkWithScratch(lib, rows)
+    add = rnd(rows, seed=67)
+    val = torch.empty((rows, k), device=DEV)
+    idx = torch.empty((rows, k), dtype=torch.int32, device=DEV)
+    check(lib.kmb_logsoftmax_topk(ptr(logits), ld, V, rows, ptr(add), -1, -1, k, ptr(val), ptr(idx), stream()))
+    lp = torch.log_softmax(logits[:, :V], -1) + add[:, None]
+    order = torch.sort(lp, dim=1, descending=True, stable=True)[1][:, :k]
+    want = torch.gather(lp, 1, order)
+    for i in range(rows):
+        if i == 6:       # log_softmax of an all -inf row is NaN in torch; the kernel reports "no candidate" values
+            continue
+        finite = torch.isfinite(want[i])
+        assert torch.equal(idx[i].long()[finite], order[i][finite]), i
+        assert torch.allclose(val[i][finite], want[i][finite], atol=1e-4), i
+        if i != 2:
+            assert bool(finite.all()), i
+    # row 2 has three finite values: they come first, in value order
+    assert idx[2, :3].tolist() == [20000, 49000, 7]
+
+
 @pytest.mark.parametrize("V,ld,ws", [(50320, 50432, False), (60000, 60032, False), (50320, 50432, True)])
 def test_logsoftmax_topk(V, ld, ws):
     """one workgroup per row: register-resident kernel / 256-thread kernel; ws: rows split over four workgroups + combine"""

@@ -59,5 +59,8 @@ for t, (name, phases) in names.items():
     for i, ph in enumerate(phases):
         d = (v[:, i + 1] - v[:, i]) * 0.01
         print(f"   {ph:42s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f} us")
+    if t >= 2:
+        d = (v[:, 7] - v[:, 0]) * 0.01
+        print(f"   {'(of the first phase: until all loads issued)':42s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f} us")
     d = (v[:, last] - v[:, 0]) * 0.01
     print(f"   {'whole workgroup':42s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f} us")
