@@ -63,14 +63,25 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(
   const float* prow = P + (size_t)(pos_base + (row % S)) * D;
   float v[NCH][8];
   float s = 0.f;
+  // all loads first, from clamped addresses and outside any branch (see ln_fwd_kernel in norm.hip)
+  f32x4 ev[NCH][2], pv[NCH][2], gv[NCH][2], bv[NCH][2];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i < nch ? lane + 64 * i : 0;
+    ev[i][0] = *reinterpret_cast<const f32x4*>(erow + c * 8); ev[i][1] = *reinterpret_cast<const f32x4*>(erow + c * 8 + 4);
+    pv[i][0] = *reinterpret_cast<const f32x4*>(prow + c * 8); pv[i][1] = *reinterpret_cast<const f32x4*>(prow + c * 8 + 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i < nch ? lane + 64 * i : 0;
+    gv[i][0] = *reinterpret_cast<const f32x4*>(gamma + c * 8); gv[i][1] = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+    bv[i][0] = *reinterpret_cast<const f32x4*>(beta + c * 8); bv[i][1] = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(erow + c * 8);
-      const f32x4 e1 = *reinterpret_cast<const f32x4*>(erow + c * 8 + 4);
-      const f32x4 p0 = *reinterpret_cast<const f32x4*>(prow + c * 8);
-      const f32x4 p1 = *reinterpret_cast<const f32x4*>(prow + c * 8 + 4);
+      const f32x4 e0 = ev[i][0], e1 = ev[i][1], p0 = pv[i][0], p1 = pv[i][1];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[i][e] = e0[e] * scale + p0[e]; v[i][4 + e] = e1[e] * scale + p1[e]; }
       if (z != nullptr) *reinterpret_cast<u32x4*>(z + (size_t)row * D + c * 8) = pack8(v[i]);
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        o[e] = (v[i][e] - mu) * rs * gamma[c * 8 + e] + beta[c * 8 + e];
+        o[e] = (v[i][e] - mu) * rs * gv[i][e >> 2][e & 3] + bv[i][e >> 2][e & 3];
         if (drop.thr16 != 0u)
           o[e] = drop_keep(drop.seed, (uint32_t)row, (uint32_t)(c * 8 + e), drop.thr16) ? o[e] * drop.scale : 0.f;
       }
@@ -189,6 +200,8 @@ hipError_t kmb_embed_ln_fwd_launch(const int64_t* ids, const int32_t* img_src, c
                                    float eps, KmbDrop drop, hipStream_t stream) {
   if (M <= 0) return hipSuccess;
   if ((D & 7) || D > 2048) return hipErrorInvalidValue;
+  if (((uintptr_t)E & 15) || ((uintptr_t)P & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)img_emb & 15))
+    return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
   if (D <= 512)
     hipLaunchKernelGGL((embed_ln_fwd_kernel<1>), grid, block, 0, stream, ids, img_src, E, img_emb, P, pos_base, S, scale, gamma, beta, z, y, mean, rstd, M, D, eps, drop);

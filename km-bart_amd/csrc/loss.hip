@@ -787,36 +787,44 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
                                                         int nb, int k, int V, int32_t* __restrict__ out, int eos,
                                                         float* __restrict__ next_scores, int64_t* __restrict__ next_tokens,
                                                         int32_t* __restrict__ next_beam_idx) {
-  __shared__ float sv[256];
-  __shared__ unsigned char taken[256];
-  const int b = blockIdx.x, lane = threadIdx.x, n = nb * k;   // n <= 256
-  int n_sel = 0;   // lane 0
-  for (int i = lane; i < n; i += 64) { sv[i] = val[(size_t)b * n + i]; taken[i] = 0; }
-  __syncthreads();
-  for (int j = 0; j < k; ++j) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = lane; i < n; i += 64) {
-      const float x = sv[i];
-      if (!taken[i] && (bi == 0x7fffffff || x > bv)) { bv = x; bi = i; }   // ascending i: first of equal values wins
-    }
+  // one wave per batch item; lane l holds candidates l, l + 64, l + 128, l + 192 (n <= 256) as 64-bit keys
+  // (value bits in order | ~position): a selection round is one DPP wave maximum (round 4; the first form ran a shuffle
+  // tree over (value, position) pairs, a workgroup barrier and a global load of the winner's token per round: 1 us each)
+  const int b = blockIdx.x, lane = threadIdx.x, n = nb * k;
+  unsigned long long key[4];
+  int tokv[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float v2 = __shfl_xor(bv, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
+  for (int q = 0; q < 4; ++q) {
+    const int i = lane + 64 * q;
+    const bool in = i < n;
+    const float v = val[(size_t)b * n + (in ? i : 0)];
+    tokv[q] = idx[(size_t)b * n + (in ? i : 0)];
+    key[q] = in ? topk_key(v, i) : 0ull;     // topk_key: larger value first, then smaller position; never 0 for a real entry
+  }
+  int n_sel = 0;
+  for (int j = 0; j < k; ++j) {
+    unsigned long long best = key[0] > key[1] ? key[0] : key[1];
+    const unsigned long long b23 = key[2] > key[3] ? key[2] : key[3];
+    best = best > b23 ? best : b23;
+    const unsigned long long wk = wave_max_u64(best);   // k <= n: there is always a candidate left
+    const int bi = 0x7fffffff - (int)(uint32_t)wk;
+    const int q = bi >> 6;
+    int tok = 0;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      if (qq == q && lane == (bi & 63)) { tok = tokv[qq]; key[qq] = 0ull; }
     }
+    tok = __shfl(tok, bi & 63, 64);   // the owner's token to every lane
     if (lane == 0) {
-      const int beam = bi / k, tok = idx[(size_t)b * n + bi];
+      const float bv = topk_key_value(wk);
+      const int beam = bi / k;
       out[((size_t)b * k + j) * 2] = __float_as_int(bv);
       out[((size_t)b * k + j) * 2 + 1] = beam * V + tok;
-      taken[bi] = 1;
       if (next_scores != nullptr && n_sel < nb && tok != eos) {
         const size_t o = (size_t)b * nb + n_sel++;
         next_scores[o] = bv; next_tokens[o] = tok; next_beam_idx[o] = b * nb + beam;
       }
     }
-    __syncthreads();
   }
   if (lane == 0 && next_scores != nullptr) {
     for (; n_sel < nb; ++n_sel) {   // cannot happen with k >= 2 * nb (at most one EOS candidate per beam); keep the rows defined

@@ -15,13 +15,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   const int nch = D >> 3;
+  // every load of the row and of its parameters is issued before the first use, from clamped addresses and outside any
+  // branch (a load inside `if (c < nch) { load; use }` gets its own s_waitcnt vmcnt(0): NCH + 1 dependent round trips per
+  // row, which is what a 320-row decode launch is made of)
+  u32x4 raw[NCH];
+  f32x4 gv[NCH][2], bv[NCH][2];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i < nch ? lane + 64 * i : 0;
+    raw[i] = *reinterpret_cast<const u32x4*>(z + (size_t)row * D + c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i < nch ? lane + 64 * i : 0;
+    gv[i][0] = *reinterpret_cast<const f32x4*>(gamma + c * 8); gv[i][1] = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+    bv[i][0] = *reinterpret_cast<const f32x4*>(beta + c * 8); bv[i][1] = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+  }
   float v[NCH][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
-      unpack8(*reinterpret_cast<const u32x4*>(z + (size_t)row * D + c * 8), v[i]);
+    if (lane + 64 * i < nch) {
+      unpack8(raw[i], v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
     } else {
@@ -46,7 +61,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     if (c < nch) {
       float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * gamma[c * 8 + e] + beta[c * 8 + e];
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * gv[i][e >> 2][e & 3] + bv[i][e >> 2][e & 3];
       *reinterpret_cast<u32x4*>(y + (size_t)row * D + c * 8) = pack8(o);
     }
   }
@@ -386,6 +401,7 @@ hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* b
                              float* rstd, int M, int D, float eps, hipStream_t stream) {
   if (M <= 0) return hipSuccess;
   if ((D & 7) || D > 2048) return hipErrorInvalidValue;
+  if (((uintptr_t)z & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)y & 15)) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
   if (D <= 512) hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
   else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
