@@ -180,7 +180,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const KmbAttn p) {
 // to LDS after it.  Same arithmetic, operation for operation, as one key tile of attn_fwd_kernel (whose online-softmax
 // rescale is exp(-inf - m) = 0 on the first tile): identical bits.  Waves without query rows (Tq = 32: waves 2, 3) only
 // stage.
-struct FwdRegs { u32x4 q[2], k[2], v[2]; };
+// mk: the key-mask words of this lane's four keys (16 j + lane % 16).  They travel with the item's operands: read where they
+// are used -- after the next item's loads have been issued -- each of them queued behind those loads in the in-order return
+// path, and the compute of item i waited for the operands of item i + 1 (rounds 2-3: the software pipeline hid nothing
+// whenever a padding mask was given).
+struct FwdRegs { u32x4 q[2], k[2], v[2]; long long mk[4]; };
 
 __device__ __forceinline__ void fwd_load_item(const KmbAttn& p, int item, int tid, FwdRegs& x) {
   const int b = item / p.H, h = item % p.H;
@@ -194,6 +198,13 @@ __device__ __forceinline__ void fwd_load_item(const KmbAttn& p, int item, int ti
     if (i == 0 || p.Tk > 32) {
       x.k[i] = *reinterpret_cast<const u32x4*>(p.K + ((size_t)b * p.Tk + tk) * p.ldk + h * HD + c * 8);
       x.v[i] = *reinterpret_cast<const u32x4*>(p.V + ((size_t)b * p.Tk + tk) * p.ldv + h * HD + c * 8);
+    }
+  }
+  if (p.key_mask != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = j * 16 + (tid & 15);
+      x.mk[j] = p.key_mask[(size_t)b * p.Tk + (key < p.Tk ? key : p.Tk - 1)];
     }
   }
 }
@@ -216,6 +227,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
     const u32x4 z = {0u, 0u, 0u, 0u};
     x.q[i] = z; x.k[i] = z; x.v[i] = z;
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x.mk[j] = 1;
   fwd_load_item(p, item, tid, x);
   for (; item < nitems; item += gridDim.x) {
     const int b = item / p.H, h = item % p.H;
@@ -229,6 +242,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
       *reinterpret_cast<u32x4*>(Vs + tile_off(row, c)) = x.v[i];
     }
     __syncthreads();
+    bool key_on[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) key_on[j] = x.mk[j] != 0;
     const int nxt = item + (int)gridDim.x;   // the next item's loads go out now and land while this one is computed
     if (nxt < nitems) fwd_load_item(p, nxt, tid, x);
     if (q0 >= p.Tq) continue;   // wave-uniform: this wave has no query rows (both barriers are at the loop head)
@@ -245,8 +261,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = j * 16 + r;
-      bool kv = key < p.Tk;
-      if (kv && p.key_mask != nullptr) kv = p.key_mask[(size_t)b * p.Tk + key] != 0;
+      const bool kv = key < p.Tk && key_on[j];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int qi = q0 + g * 4 + q;
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
 // and its read-modify-write pass are gone -- dQ leaves from registers as transposed MFMA tiles (8-byte stores), like
 // dK / dV; delta = rowsum(dO * O) comes from the staged registers (no second global read of dO).
 // Same arithmetic as attn_bwd_kernel up to the summation order of delta and of the column sums (fp32, last bit).
-struct BwdRegs { u32x4 q[2], d[2], k[2], v[2], o[2]; };
+struct BwdRegs { u32x4 q[2], d[2], k[2], v[2], o[2]; float lse[2]; long long mk[4]; };   // lse, mk: see FwdRegs
 
 __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int tid, BwdRegs& x) {
   const int b = item / p.H, h = item % p.H;
@@ -498,6 +513,14 @@ __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int ti
     x.o[i] = *reinterpret_cast<const u32x4*>(p.O + rq * p.ldo + h * HD + c * 8);
     x.k[i] = *reinterpret_cast<const u32x4*>(p.K + rk * p.ldk + h * HD + c * 8);
     x.v[i] = *reinterpret_cast<const u32x4*>(p.V + rk * p.ldv + h * HD + c * 8);
+    x.lse[i] = p.lse[((size_t)b * p.H + h) * p.Tq + tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
+  }
+  if (p.key_mask != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = j * 16 + (tid & 15);
+      x.mk[j] = p.key_mask[(size_t)b * p.Tk + (key < p.Tk ? key : p.Tk - 1)];
+    }
   }
 }
 
@@ -528,6 +551,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
   int item = blockIdx.x;
   if (item >= nitems) return;
   BwdRegs x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x.mk[j] = 1;
   bwd_load_item(p, item, tid, x);
   for (; item < nitems; item += gridDim.x) {
     const int b = item / p.H, h = item % p.H;
@@ -552,11 +577,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
       acc += __shfl_xor(acc, 2, 64);
       if (c == 0) {
         del_s[row] = acc;
-        const int q = row < p.Tq ? row : p.Tq - 1;
-        lse_s[row] = p.lse[((size_t)b * p.H + h) * p.Tq + q];
+        lse_s[row] = x.lse[i];
       }
     }
     __syncthreads();
+    bool key_on[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) key_on[j] = x.mk[j] != 0;
     // ---- next item's loads go out now and land while this item is computed ----
     const int nxt = item + (int)gridDim.x;
     if (nxt < nitems) bwd_load_item(p, nxt, tid, x);
@@ -577,8 +604,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = j * 16 + r;
-      bool kv = key < p.Tk;
-      if (kv && p.key_mask != nullptr) kv = p.key_mask[(size_t)b * p.Tk + key] != 0;
+      const bool kv = key < p.Tk && key_on[j];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int lrow = wave * 16 + g * 4 + q;

@@ -23,7 +23,8 @@ for name, Tq, Tk, causal in (("enc self", 64, 64, 0), ("dec self", 32, 32, 1), (
     kv = (torch.randn(B * Tk, 3 * d, device=DEV, generator=g) * 0.5).bfloat16() if Tk != Tq else qkv
     O = torch.empty(B * Tq, d, dtype=torch.bfloat16, device=DEV)
     lse = torch.empty(B * H * Tq, dtype=torch.float32, device=DEV)
-    a = attn_struct(qkv[:, :d], kv[:, d:2 * d], kv[:, 2 * d:], B, H, Tq, Tk, None, causal, O, lse)
+    mask = torch.ones(B, Tk, dtype=torch.int64, device=DEV)   # the training step always passes a padding mask
+    a = attn_struct(qkv[:, :d], kv[:, d:2 * d], kv[:, 2 * d:], B, H, Tq, Tk, None if os.environ.get("NOMASK") else mask, causal, O, lse)
     check(lib.kmb_op_attn_fwd(C.byref(a), stream()))
     dO = (torch.randn(B * Tq, d, device=DEV, generator=g) * 0.1).bfloat16()
     dqkv = torch.empty(B * Tq, 3 * d, dtype=torch.bfloat16, device=DEV)
