@@ -146,6 +146,7 @@ hipError_t kmb_gather_rows_multi_launch(const void* const* src, void* const* dst
                                         int row_bytes, size_t stride_bytes, hipStream_t stream);
 // dst[i] = src[idx[i]]  (dst must not alias src)
 hipError_t kmb_gather_i32_launch(const int32_t* src, const int32_t* idx, int32_t* dst, int n, hipStream_t stream);
+hipError_t kmb_iota_div_launch(int32_t* out, int n, int div, hipStream_t stream);   // out[i] = i / div
 hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst, int rows, int row_bytes,
                                   size_t stride_bytes, hipStream_t stream);
 

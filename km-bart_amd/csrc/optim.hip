@@ -122,6 +122,12 @@ __global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t* __restri
   if (i < n) dst[i] = src[idx[i]];
 }
 
+// out[i] = i / div  (the beam row -> batch item table of a generation)
+__global__ __launch_bounds__(256) void iota_div_kernel(int32_t* __restrict__ out, int n, int div) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = i / div;
+}
+
 inline int grid_for(size_t work, int cap = 4096) {
   size_t b = (work + 255) / 256;
   if (b > (size_t)cap) b = cap;
@@ -178,6 +184,13 @@ hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst
   if ((row_bytes & 15) || (stride_bytes & 15)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)rows * (row_bytes >> 4))), dim3(256), 0, stream,
                      (const char*)src, idx, (char*)dst, rows, row_bytes, stride_bytes);
+  return hipGetLastError();
+}
+
+hipError_t kmb_iota_div_launch(int32_t* out, int n, int div, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (div <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(iota_div_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, div);
   return hipGetLastError();
 }
 
