@@ -114,6 +114,50 @@ __device__ __forceinline__ kmb_f32x2 gelu_grad2(kmb_f32x2 x) {
   return cdf + x * 0.39894228040143268f * e;
 }
 
+// ---- split-K slabs: a += slab[1] + slab[2] + ... (src points at this thread's element of slab 0), in slice order ----
+// U slabs' loads are in flight together: the plain `for (s) a += load(s)` loop is not unrolled by hipcc (runtime trip count)
+// and compiles to load, s_waitcnt vmcnt(0), add -- one dependent memory round trip per slab.  Same additions in the same
+// order: identical bits.
+template <int U>
+__device__ __forceinline__ void add_slabs(f32x4& a, const float* __restrict__ src, size_t stride, int nslabs) {
+  int s = 1;
+  for (; s + U <= nslabs; s += U) {
+    f32x4 b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * stride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { a[0] += b[u][0]; a[1] += b[u][1]; a[2] += b[u][2]; a[3] += b[u][3]; }
+  }
+  for (; s < nslabs; ++s) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
+    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+  }
+}
+// the same for two adjacent vectors (eight columns)
+template <int U>
+__device__ __forceinline__ void add_slabs2(f32x4& lo, f32x4& hi, const float* __restrict__ src, size_t stride, int nslabs) {
+  int s = 1;
+  for (; s + U <= nslabs; s += U) {
+    f32x4 bl[U], bh[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bl[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * stride);
+      bh[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * stride + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      lo[0] += bl[u][0]; lo[1] += bl[u][1]; lo[2] += bl[u][2]; lo[3] += bl[u][3];
+      hi[0] += bh[u][0]; hi[1] += bh[u][1]; hi[2] += bh[u][2]; hi[3] += bh[u][3];
+    }
+  }
+  for (; s < nslabs; ++s) {
+    const f32x4 l2 = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
+    const f32x4 h2 = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride + 4);
+    lo[0] += l2[0]; lo[1] += l2[1]; lo[2] += l2[2]; lo[3] += l2[3];
+    hi[0] += h2[0]; hi[1] += h2[1]; hi[2] += h2[2]; hi[3] += h2[3];
+  }
+}
+
 // ---- dropout: counter-based keep decision, identical in forward epilogues and backward ----
 // keep(row, col) depends only on (site_seed, row, col); site_seed = mix(seed, step, site) on host.
 __device__ __forceinline__ uint32_t kmb_hash32(uint32_t x) {

@@ -935,11 +935,10 @@ __global__ __launch_bounds__(256) void ce_dgrad_finish_kernel(const float* __res
   const float a = alpha[r];
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (a != 0.f) {
-    for (int s = 0; s < nslabs; ++s) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + s * stride + (size_t)r * d + c);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + s * stride + (size_t)r * d + c + 4);
-      v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3]; v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
-    }
+    const float* src = slab + (size_t)r * d + c;
+    f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+    add_slabs2<4>(lo, hi, src, stride, nslabs);
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= a;
   }

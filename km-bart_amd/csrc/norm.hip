@@ -88,12 +88,7 @@ __global__ __launch_bounds__(256) void ln_fwd_slabs_kernel(const float* __restri
     if (c < nch) {
       const float* src = slabs + (size_t)row * D + c * 8;
       f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-      for (int k = 1; k < nslabs; ++k) {
-        const f32x4 l2 = *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
-        const f32x4 h2 = *reinterpret_cast<const f32x4*>(src + (size_t)k * stride + 4);
-        lo[0] += l2[0]; lo[1] += l2[1]; lo[2] += l2[2]; lo[3] += l2[3];
-        hi[0] += h2[0]; hi[1] += h2[1]; hi[2] += h2[2]; hi[3] += h2[3];
-      }
+      add_slabs2<4>(lo, hi, src, stride, nslabs);
       float rr[8];
       unpack8(*reinterpret_cast<const u32x4*>(residual + (size_t)row * ld_res + c * 8), rr);
       float t[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -295,10 +290,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
                                                            float* __restrict__ out, size_t n4, float beta) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     f32x4 a = reinterpret_cast<const f32x4*>(slabs)[i];
-    for (int s = 1; s < nslabs; ++s) {
-      const f32x4 b = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride)[i];
-      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
-    }
+    add_slabs<8>(a, slabs + 4 * i, stride, nslabs);
     if (beta != 0.f) {
       const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
       a[0] += beta * o[0]; a[1] += beta * o[1]; a[2] += beta * o[2]; a[3] += beta * o[3];
@@ -312,12 +304,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __r
                                                                 bf16_t* __restrict__ out, size_t n8) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     f32x4 a = reinterpret_cast<const f32x4*>(slabs)[2 * i], b = reinterpret_cast<const f32x4*>(slabs)[2 * i + 1];
-    for (int s = 1; s < nslabs; ++s) {
-      const f32x4 a2 = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride)[2 * i];
-      const f32x4 b2 = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride)[2 * i + 1];
-      a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3];
-      b[0] += b2[0]; b[1] += b2[1]; b[2] += b2[2]; b[3] += b2[3];
-    }
+    add_slabs2<4>(a, b, slabs + 8 * i, stride, nslabs);
     const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     reinterpret_cast<u32x4*>(out)[i] = pack8(v);
   }
@@ -337,12 +324,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_epi_kernel(const float* __re
     const int row = (int)(i / nch), c = (int)(i % nch) * 8;
     const float* src = slabs + (size_t)row * N + c;
     f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
-    for (int s = 1; s < nslabs; ++s) {
-      const f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride + 4);
-      a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3];
-      b[0] += b2[0]; b[1] += b2[1]; b[2] += b2[2]; b[3] += b2[3];
-    }
+    add_slabs2<4>(a, b, src, stride, nslabs);
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

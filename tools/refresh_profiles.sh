@@ -18,6 +18,7 @@ cp $O/gemm_shapes.txt profiles/${R}_gemm_shape_table_b${B}.txt
 cp $O/yardstick.txt profiles/${R}_gemm_library_yardstick_b${B}.txt
 cp $O/attn_bwd.txt profiles/${R}_attn_bwd_time.txt
 [ -f $O/decode_stamps.txt ] && cp $O/decode_stamps.txt profiles/${R}_decode_stamps.txt
+[ -f $O/gen_host_wait.txt ] && cp $O/gen_host_wait.txt profiles/${R}_generation_host_wait.txt
 [ -f $O/traffic_by_shape.txt ] && cp $O/traffic_by_shape.txt profiles/${R}_gemm_traffic_by_shape_b${B}.txt
 cp $O/topk_time.txt profiles/${R}_topk_time.txt
 grep '^{' $O/gen_bench.log | tail -1 > profiles/${R}_generation_bench.json
