@@ -280,16 +280,22 @@ __device__ __forceinline__ void decode_proj_body(const KmbDecodeBlock& p, char* 
   }
   f32x4 bias[NTW];
   uint2 res[NTW];
+  auto load_bias_res = [&]() {
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int col = (nt0 + t) * 16 + g * 4;
-    bias[t] = *reinterpret_cast<const f32x4*>(p.bias + col);
-    res[t] = (p.residual != nullptr && row < p.R) ? *reinterpret_cast<const uint2*>(p.residual + (size_t)row * p.ld_res + col) : uint2{0u, 0u};
-  }
+    for (int t = 0; t < NTW; ++t) {
+      const int col = (nt0 + t) * 16 + g * 4;
+      bias[t] = *reinterpret_cast<const f32x4*>(p.bias + col);
+      res[t] = (p.residual != nullptr && row < p.R) ? *reinterpret_cast<const uint2*>(p.residual + (size_t)row * p.ld_res + col) : uint2{0u, 0u};
+    }
+  };
+  if (NTW == 1) load_bias_res();
   DSTAMP(stype, 1);
   rows_finish<NCH>(rr, row0, p.R, p.K, p.gamma, p.beta, p.eps, nb == 0 ? p.ln_out : nullptr, smem, a_stride, wave, lane);
   if (NTW == 2) {
     __builtin_amdgcn_sched_barrier(0);   // (keeps the second tile's 96 registers out of the LayerNorm's live range)
+    // bias / residual of the 256-register kernel are requested here, into registers the staged rows have left: requested with
+    // the first tile's fragments they were spilled while still in flight -- `s_waitcnt vmcnt(2)` in front of the LayerNorm
+    load_bias_res();
     load_wblock(wb[1], p.W, p.K, nt0 + 1, 0, lane);
   }
   __syncthreads();
@@ -391,38 +397,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   f32x4 acc[NTW], bias[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) load_wblock(wb[t], p.W, p.K, tile_of(wave * NTW + t), 0, lane);
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int tile = wave * NTW + t;
-    bias[t] = *reinterpret_cast<const f32x4*>(p.bias + (tile >> 2) * d + h * HD + (tile & 3) * 16 + (lane >> 4) * 4);
-  }
   // SELF: the first 4 * KU cached keys and VU cached values of this thread's row (all of them for max_length <= 21 / 11)
-  // are requested now, behind the weight fragments: they do not depend on the projection, and fetched after it they
-  // were two exposed L2 round trips (5 of the block's 14.6 us)
+  // do not depend on the projection; fetched after it they were two exposed L2 round trips (5 of the block's 14.6 us).
+  // They are requested behind the LayerNorm (below), not in front of it: in the in-order return path they follow the weight
+  // fragments either way, and requested first they were 60 more live registers across the LayerNorm -- hipcc parked them in
+  // accumulator registers there, and a copy of a value that is still in flight is `s_waitcnt vmcnt(0)`: the LayerNorm
+  // waited for the whole weight stream (stamps: 10 of the block's 16 us before the projection could start).
   const int a_lr = threadIdx.x >> 4, a_s = threadIdx.x & 15;
   [[maybe_unused]] u32x4 pk0[SELF ? KU : 1], pk1[SELF ? KU : 1];
   [[maybe_unused]] uint2 pv[SELF ? VU : 1];
-  if (SELF) {
-    const int prow = row0 + a_lr < p.R ? row0 + a_lr : 0;
-    const bf16_t* kc = p.Kc + (size_t)prow * p.Tmax * p.ldc + h * HD;
-    const bf16_t* vc = p.Vc + (size_t)prow * p.Tmax * p.ldc + h * HD;
-    const int tc = p.Tk - 1;
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {   // (positions past the cache: no request; their scores / weights are never used)
-      const int t = (a_s >> 2) + 4 * u;
-      pk0[u] = pk1[u] = u32x4{0u, 0u, 0u, 0u};
-      if (4 * u < tc) {   // wave-uniform
-        const bf16_t* kr = kc + (size_t)(t < tc ? t : 0) * p.ldc + (a_s & 3) * 16;
-        pk0[u] = *reinterpret_cast<const u32x4*>(kr);
-        pk1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < VU; ++u) {
-      pv[u] = uint2{0u, 0u};
-      if (u < tc) pv[u] = *reinterpret_cast<const uint2*>(vc + (size_t)u * p.ldc + a_s * 4);
-    }
-  }
   // KVLDS: this thread's chunks of the tile's keys / values (chunk c = tid + 256 i: staged row c / 8, 16-byte piece c % 8)
   [[maybe_unused]] u32x4 kreg[KVLDS ? NKV : 1], vreg[KVLDS ? NKV : 1];
   [[maybe_unused]] int first_item = 0, kv_rows = 0;
@@ -457,6 +440,29 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   }
   DSTAMP(stype, 7);   // every load of the block has been issued
   rows_finish<2>(rr, row0, p.R, p.K, p.gamma, p.beta, p.eps, h == 0 ? p.ln_out : nullptr, smem, a_stride, wave, lane);
+  // the bias is requested only now, into the registers the staged rows have left: requested with the weights it was the
+  // value hipcc chose to spill in the self-attention block (288 fragment registers), and a spill of a value that is still
+  // in flight is `s_waitcnt vmcnt(0)` -- the block waited for its whole weight stream before it requested its keys
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int tile = wave * NTW + t;
+    bias[t] = *reinterpret_cast<const f32x4*>(p.bias + (tile >> 2) * d + h * HD + (tile & 3) * 16 + (lane >> 4) * 4);
+  }
+  if (SELF) {
+    const int prow = row0 + a_lr < p.R ? row0 + a_lr : 0;
+    const bf16_t* kc = p.Kc + (size_t)prow * p.Tmax * p.ldc + h * HD;
+    const bf16_t* vc = p.Vc + (size_t)prow * p.Tmax * p.ldc + h * HD;
+    const int tc = p.Tk - 1;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {   // (clamped addresses, no branch: a conditional load's register copy waits for the load)
+      const int t = (a_s >> 2) + 4 * u;
+      const bf16_t* kr = kc + (size_t)(t < tc ? t : 0) * p.ldc + (a_s & 3) * 16;
+      pk0[u] = *reinterpret_cast<const u32x4*>(kr);
+      pk1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < VU; ++u) pv[u] = *reinterpret_cast<const uint2*>(vc + (size_t)(u < tc ? u : 0) * p.ldc + a_s * 4);
+  }
   __syncthreads();
   DSTAMP(stype, 1);
 #pragma unroll
