@@ -271,14 +271,15 @@ __device__ __forceinline__ void decode_proj_body(const KmbDecodeBlock& p, char* 
   // NTW = 1: up to three K blocks are requested before anything is waited for (these launches have at most one
   // workgroup per CU, so the 288 registers cost no occupancy).  NTW = 2 (fc1: two workgroups per CU have to fit, 256
   // registers each): the second tile's fragments are requested after the LayerNorm, when its registers are free.
-  // NCH = 6 (fc2, K = 3072): a FOURTH block, requested behind the row staging into the registers the staged rows (96) have left --
-  // requested after the first block's MFMAs (round 2-3: "slot b % 3") its round trip was exposed at the end of the block.
-  constexpr int NWB = NTW == 2 ? 2 : (NCH > 4 ? 4 : 3);
+  // (Measured and dropped at the end of round 4: a FOURTH block for fc2, requested behind the row staging into the registers the
+  // staged rows have left, instead of into slot 0 after the first block's MFMAs -- 9.8 -> 10.2 us: the block is bound by the
+  // number of requests its CU issues, not by when the last one is issued.)
+  constexpr int NWB = NTW == 2 ? 2 : 3;
   WBlock wb[NWB];
   load_wblock(wb[0], p.W, p.K, nt0, 0, lane);
   if (NTW == 1) {
     if (nblk > 1) load_wblock(wb[1], p.W, p.K, nt0, KBLK, lane);
-    if (nblk > 2) load_wblock(wb[NWB > 2 ? 2 : 0], p.W, p.K, nt0, 2 * KBLK, lane);
+    if (nblk > 2) load_wblock(wb[NWB - 1], p.W, p.K, nt0, 2 * KBLK, lane);
   }
   f32x4 bias[NTW];
   uint2 res[NTW];
@@ -300,10 +301,6 @@ __device__ __forceinline__ void decode_proj_body(const KmbDecodeBlock& p, char* 
     load_bias_res();
     load_wblock(wb[1], p.W, p.K, nt0 + 1, 0, lane);
   }
-  if (NWB == 4) {
-    __builtin_amdgcn_sched_barrier(0);
-    if (nblk > 3) load_wblock(wb[NWB - 1], p.W, p.K, nt0, 3 * KBLK, lane);
-  }
   __syncthreads();
   DSTAMP(stype, 2);
   f32x4 acc[NTW];
@@ -312,12 +309,12 @@ __device__ __forceinline__ void decode_proj_body(const KmbDecodeBlock& p, char* 
   if (NTW == 2) {
     mma_wblock(acc[0], wb[0], smem, a_stride, 0, lane);
     mma_wblock(acc[NTW - 1], wb[1], smem, a_stride, 0, lane);
-  } else {   // K blocks 0 .. 3 (host: K <= 3072); NWB = 3 (K <= 2304 instantiations): block 3 would reuse slot 0
+  } else {   // K blocks 0 .. 3 (host: K <= 3072); slot of block b: b % 3
     mma_wblock(acc[0], wb[0], smem, a_stride, 0, lane);
-    if (NWB == 3 && nblk > 3) load_wblock(wb[0], p.W, p.K, nt0, 3 * KBLK, lane);
+    if (nblk > 3) load_wblock(wb[0], p.W, p.K, nt0, 3 * KBLK, lane);
     if (nblk > 1) mma_wblock(acc[0], wb[1], smem, a_stride, KBLK, lane);
-    if (nblk > 2) mma_wblock(acc[0], wb[NWB > 2 ? 2 : 0], smem, a_stride, 2 * KBLK, lane);
-    if (nblk > 3) mma_wblock(acc[0], wb[NWB == 4 ? 3 : 0], smem, a_stride, 3 * KBLK, lane);
+    if (nblk > 2) mma_wblock(acc[0], wb[NWB - 1], smem, a_stride, 2 * KBLK, lane);
+    if (nblk > 3) mma_wblock(acc[0], wb[0], smem, a_stride, 3 * KBLK, lane);
   }
   DSTAMP(stype, 3);
   if (row >= p.R) return;
