@@ -565,12 +565,13 @@ def test_adamw_matches_hf_form():
     assert torch.equal(pb, p.to(torch.bfloat16))
 
 
-def test_beam_merge_matches_torch_topk_over_all_beams():
+@pytest.mark.parametrize("nb,k", [(5, 10), (8, 16), (16, 16)])
+def test_beam_merge_matches_torch_topk_over_all_beams(nb, k):
     """kmb_beam_merge: per batch item the best k of its beams' top-k lists == torch.topk over the num_beams * V scores
-    (ties: the earlier candidate position first), including forced-token steps where most candidates are -inf."""
+    (ties: the earlier candidate position first), including forced-token steps where most candidates are -inf.
+    nb * k = 50 / 128 / 256 candidates: one, two and four keys per lane of the merging wave."""
     lib = _lib.load()
-    B, nb, V, ld = 7, 5, 50320, 50432
-    k = 2 * nb
+    B, V, ld = 7, 50320, 50432
     logits = torch.zeros((B * nb, ld), device=DEV)
     logits[:, :V] = rnd(B * nb, V, seed=91) * 3
     logits[3, 100] = logits[3, 7]                    # an exact tie inside one row
