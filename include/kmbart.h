@@ -248,7 +248,9 @@ int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretra
                          float* logits_out, kmb_bf16* enc_out, void* stream);
 
 /* ================= generation ================= */
-/* encoder once (src/model/mixins.py:281-283) + cross-attention K/V of every decoder layer */
+/* encoder once (src/model/mixins.py:281-283) + cross-attention K/V of every decoder layer.  Asynchronous: everything is
+   enqueued on `stream` and the call returns without synchronising (the batch's device buffers must stay valid until the
+   generation's last kmb_gen_step has run). */
 int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_length, void* stream);
 /* encoder output [B*S, d_model] (bf16) of the kmb_gen_begin still active: the `encoder_outputs` element of the cached
  * forward's return tuple (src/model/model.py:384-397 returns decoder_outputs + encoder_outputs) */
