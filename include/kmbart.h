@@ -281,6 +281,13 @@ int kmb_beam_merge(const float* val, const int32_t* idx, int B, int num_beams, i
  * `out` still carries every candidate for the host's hypothesis bookkeeping. */
 int kmb_beam_merge_select(const float* val, const int32_t* idx, int B, int num_beams, int k, int V, int32_t* out,
                           int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, void* stream);
+/* kmb_logsoftmax_topk_ws over the B * num_beams rows + kmb_beam_merge_select in two launches instead of three (one when the
+ * token is forced): the per-row top-k lists stay in the workgroup that merges them.  Same outputs as the two calls
+ * (src/model/mixins.py:336-361, one beam-search step).  Fails for shapes the fused form does not cover (k > 16,
+ * num_beams > 16, num_beams * k > 256): use the two calls. */
+int kmb_beam_step(const float* logits, int ld, int V, int B, int num_beams, const float* add, int force_token, int ban_token,
+                  int k, int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                  float* scratch, int64_t scratch_floats, void* stream);
 int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
 
 /* Data-parallel runs share the GPU between the GEMMs and RCCL's all-reduce kernel (reference: torch DDP's NCCL streams,

@@ -133,6 +133,19 @@ int kmb_beam_merge_select(const float* val, const int32_t* idx, int B, int num_b
   return hipfail(kmb_beam_merge_launch(val, idx, B, num_beams, k, V, out, eos_token, next_scores, next_tokens, next_beam_idx,
                                        (hipStream_t)stream), "beam_merge_select");
 }
+int kmb_beam_step(const float* logits, int ld, int V, int B, int num_beams, const float* add, int force_token, int ban_token,
+                  int k, int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                  float* scratch, int64_t scratch_floats, void* stream) {
+  if (!logits || !out || !scratch) return kmb_set_error("kmb_beam_step: missing tensor");
+  if (!next_scores || !next_tokens || !next_beam_idx) return kmb_set_error("kmb_beam_step: missing output");
+  const hipError_t e = kmb_beam_step_launch(logits, ld, V, B, num_beams, add, force_token, ban_token, k, out, eos_token, next_scores,
+                                            next_tokens, next_beam_idx, scratch, scratch_floats > 0 ? (size_t)scratch_floats : 0,
+                                            (hipStream_t)stream);
+  if (e == hipErrorNotSupported)
+    return kmb_set_error("kmb_beam_step: unsupported shape (k <= 16, num_beams <= 16, num_beams * k <= 256, ld %% 4 == 0, "
+                         "scratch of kmb_logsoftmax_topk_scratch(B * num_beams) floats): use kmb_logsoftmax_topk_ws + kmb_beam_merge_select");
+  return hipfail(e, "beam_step");
+}
 int kmb_logsoftmax_topk(const float* logits, int ld, int V, int rows, const float* add, int force_token, int ban_token,
                         int k, float* out_val, int32_t* out_idx, void* stream) {
   return hipfail(kmb_logsoftmax_topk_launch(logits, ld, V, rows, add, force_token, ban_token, k, out_val, out_idx, nullptr, 0,

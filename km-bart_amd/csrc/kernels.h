@@ -119,6 +119,9 @@ hipError_t kmb_ce_bf16_launch(const bf16_t* logits, int ldv, int V, const int64_
 hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
                                   hipStream_t stream);
 // generation: per row log_softmax over V then top-k of (logp + add[row]); writes k (value, index) pairs
+hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
+                                int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                                float* scratch, size_t scratch_floats, hipStream_t stream);
 hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out, int eos,
                                  float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, hipStream_t stream);
 // ban_token >= 0: that token's score is -inf AFTER the normalisation (min_length, transformers 3.0.2

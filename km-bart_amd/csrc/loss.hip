@@ -731,17 +731,14 @@ __global__ __launch_bounds__(256, KMB_TOPK_OCC) void topk_part_kernel(const floa
   }
 }
 
-// one wave per row: combine the parts
-__global__ __launch_bounds__(256) void topk_combine_kernel(const float* __restrict__ part, int rows, const float* __restrict__ add,
-                                                           int force_token, int k, float* __restrict__ out_val,
-                                                           int32_t* __restrict__ out_idx) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (r >= rows) return;
+// one wave per row: combine the parts (val_row / idx_row: the row's k outputs, global memory or LDS)
+__device__ __forceinline__ void topk_combine_row(const float* __restrict__ part, int r, const float* __restrict__ add, int force_token,
+                                                 int k, float* val_row, int32_t* idx_row, int lane) {
   const float a = add != nullptr ? add[r] : 0.f;
   if (force_token >= 0) {   // every other logit is -inf: log_softmax is 0 at the forced token (ties in index order)
     for (int j = lane; j < k; j += 64) {
-      out_val[(size_t)r * k + j] = j == 0 ? a : -INFINITY;
-      out_idx[(size_t)r * k + j] = j == 0 ? force_token : (j - 1 < force_token ? j - 1 : j);
+      val_row[j] = j == 0 ? a : -INFINITY;
+      idx_row[j] = j == 0 ? force_token : (j - 1 < force_token ? j - 1 : j);
     }
     return;
   }
@@ -765,11 +762,18 @@ __global__ __launch_bounds__(256) void topk_combine_kernel(const float* __restri
   for (int jr = 0; jr < k; ++jr) {
     const unsigned long long wk = wave_max_u64(key);
     if (lane == 0) {
-      out_val[(size_t)r * k + jr] = ((wk != 0ull ? topk_key_value(wk) : -INFINITY) - lse) + a;
-      out_idx[(size_t)r * k + jr] = wk != 0ull ? 0x7fffffff - (int)(uint32_t)wk : 0x7fffffff;
+      val_row[jr] = ((wk != 0ull ? topk_key_value(wk) : -INFINITY) - lse) + a;
+      idx_row[jr] = wk != 0ull ? 0x7fffffff - (int)(uint32_t)wk : 0x7fffffff;
     }
     if (key == wk) key = 0ull;
   }
+}
+__global__ __launch_bounds__(256) void topk_combine_kernel(const float* __restrict__ part, int rows, const float* __restrict__ add,
+                                                           int force_token, int k, float* __restrict__ out_val,
+                                                           int32_t* __restrict__ out_idx) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  topk_combine_row(part, r, add, force_token, k, out_val + (size_t)r * k, out_idx + (size_t)r * k, lane);
 }
 
 // Beam search, per batch item: the best `k` of the nb * k candidates its beams produced (val / idx from
@@ -783,22 +787,22 @@ __global__ __launch_bounds__(256) void topk_combine_kernel(const float* __restri
 // _generate_beam_search: an EOS candidate either closes a hypothesis or is skipped, it never continues a beam) ->
 // next_scores / next_tokens / next_beam_idx [b*nb + i] (beam index = row of the KV cache to continue from).  What the
 // host does with the finished hypotheses and with `done` batch items does not feed back into the other rows.
-__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx,
-                                                        int nb, int k, int V, int32_t* __restrict__ out, int eos,
-                                                        float* __restrict__ next_scores, int64_t* __restrict__ next_tokens,
-                                                        int32_t* __restrict__ next_beam_idx) {
+// (val / idx: the nb * k candidates of batch item b -- global memory or LDS; one wave)
+__device__ __forceinline__ void beam_merge_item(const float* val, const int32_t* idx, int b, int lane, int nb, int k, int V,
+                                                int32_t* __restrict__ out, int eos, float* __restrict__ next_scores,
+                                                int64_t* __restrict__ next_tokens, int32_t* __restrict__ next_beam_idx) {
   // one wave per batch item; lane l holds candidates l, l + 64, l + 128, l + 192 (n <= 256) as 64-bit keys
   // (value bits in order | ~position): a selection round is one DPP wave maximum (round 4; the first form ran a shuffle
   // tree over (value, position) pairs, a workgroup barrier and a global load of the winner's token per round: 1 us each)
-  const int b = blockIdx.x, lane = threadIdx.x, n = nb * k;
+  const int n = nb * k;
   unsigned long long key[4];
   int tokv[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = lane + 64 * q;
     const bool in = i < n;
-    const float v = val[(size_t)b * n + (in ? i : 0)];
-    tokv[q] = idx[(size_t)b * n + (in ? i : 0)];
+    const float v = val[in ? i : 0];
+    tokv[q] = idx[in ? i : 0];
     key[q] = in ? topk_key(v, i) : 0ull;     // topk_key: larger value first, then smaller position; never 0 for a real entry
   }
   int n_sel = 0;
@@ -832,6 +836,26 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
       next_scores[o] = -1e9f; next_tokens[o] = eos >= 0 ? eos : 0; next_beam_idx[o] = b * nb;
     }
   }
+}
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx,
+                                                        int nb, int k, int V, int32_t* __restrict__ out, int eos,
+                                                        float* __restrict__ next_scores, int64_t* __restrict__ next_tokens,
+                                                        int32_t* __restrict__ next_beam_idx) {
+  const int b = blockIdx.x, n = nb * k;
+  beam_merge_item(val + (size_t)b * n, idx + (size_t)b * n, b, threadIdx.x, nb, k, V, out, eos, next_scores, next_tokens, next_beam_idx);
+}
+// The two in one launch per batch item (the decode loop): wave w < nb combines the parts of beam row b * nb + w into LDS, wave 0
+// then merges the item's nb * k candidates.  Same arithmetic and order as topk_combine_kernel + beam_merge_kernel.
+__global__ __launch_bounds__(1024) void beam_combine_merge_kernel(const float* __restrict__ part, const float* __restrict__ add,
+                                                                  int force_token, int nb, int k, int V, int32_t* __restrict__ out,
+                                                                  int eos, float* __restrict__ next_scores,
+                                                                  int64_t* __restrict__ next_tokens, int32_t* __restrict__ next_beam_idx) {
+  __shared__ float sval[256];
+  __shared__ int32_t sidx[256];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < nb) topk_combine_row(part, b * nb + wave, add, force_token, k, sval + wave * k, sidx + wave * k, lane);
+  __syncthreads();
+  if (wave == 0) beam_merge_item(sval, sidx, b, lane, nb, k, V, out, eos, next_scores, next_tokens, next_beam_idx);
 }
 
 
@@ -1028,6 +1052,25 @@ hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int r
     hipLaunchKernelGGL((logsoftmax_topk_reg_kernel<13>), dim3(rows), dim3(1024), 0, stream, logits, ldv, V, add, force_token, ban_token, k, out_val, out_idx);
   else
     hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, ldv, V, add, force_token, ban_token, k, out_val, out_idx);
+  return hipGetLastError();
+}
+
+// log-softmax top-k of every beam row + the per-item merge + the next step's beams: topk_part (unless the token is forced) and ONE
+// launch for the rest.  hipErrorNotSupported: the shape needs the separate launches (kmb_logsoftmax_topk_launch + kmb_beam_merge_launch).
+hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
+                                int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                                float* scratch, size_t scratch_floats, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  const int rows = B * nb;
+  const int chunks = (ldv / 4 + TOPK_PARTS - 1) / TOPK_PARTS;
+  if (!(scratch != nullptr && scratch_floats >= kmb_logsoftmax_topk_scratch_floats(rows) && k >= 1 && k <= TOPK_KMAX && nb >= 1 &&
+        nb <= 16 && nb * k <= 256 && (ldv & 3) == 0 && ((uintptr_t)logits & 15) == 0 && chunks <= 13 * 256 && rows <= 65535))
+    return hipErrorNotSupported;
+  if (next_scores != nullptr && (!next_tokens || !next_beam_idx)) return hipErrorInvalidValue;
+  if (force_token < 0)
+    hipLaunchKernelGGL((topk_part_kernel<13>), dim3(TOPK_PARTS, rows), dim3(256), 0, stream, logits, ldv, V, ban_token, k, chunks, scratch);
+  hipLaunchKernelGGL(beam_combine_merge_kernel, dim3(B), dim3(64 * nb), 0, stream, scratch, add, force_token, nb, k, V, out, eos,
+                     next_scores, next_tokens, next_beam_idx);
   return hipGetLastError();
 }
 

@@ -124,6 +124,8 @@ PROTOTYPES = {
     "kmb_gen_reorder": (C.c_int, [c_p, c_p, C.c_int, c_p]),
     "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),
     "kmb_beam_merge_select": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p]),
+    "kmb_beam_step": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p,
+                                c_p, C.c_int64, c_p]),
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_logsoftmax_topk_scratch": (C.c_int64, [C.c_int]),
     "kmb_logsoftmax_topk_ws": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p,

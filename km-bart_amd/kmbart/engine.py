@@ -514,24 +514,36 @@ class Engine:
         copied to the host.  `add` may be one of the returned next_scores (stream order makes that safe)."""
         R = logits.shape[0]
         B = R // num_beams
-        val, idx = self.logsoftmax_topk(logits, k, add=add, force_token=force_token, ban_token=ban_token)
         cand = torch.empty((B, k, 2), dtype=torch.int32, device=self.device)
         nscore = torch.empty((R,), dtype=torch.float32, device=self.device)
         ntok = torch.empty((R,), dtype=torch.int64, device=self.device)
         nidx = torch.empty((R,), dtype=torch.int32, device=self.device)
+        if k <= 16 and num_beams <= 16 and num_beams * k <= 256 and logits.stride(0) % 4 == 0:
+            # kmb_beam_step: the rows' top-k lists never leave the workgroup that merges them (one launch less per decode step)
+            scr = self._topk_scratch_for(R)
+            with torch.cuda.device(self.device):
+                check(self.lib.kmb_beam_step(ptr(logits), logits.stride(0), int(self.config.vocab_size), B, int(num_beams), ptr(add),
+                                             int(force_token), int(ban_token), int(k), ptr(cand), int(eos_token), ptr(nscore),
+                                             ptr(ntok), ptr(nidx), ptr(scr), scr.numel(), _stream()))
+            return cand, nscore, ntok, nidx
+        val, idx = self.logsoftmax_topk(logits, k, add=add, force_token=force_token, ban_token=ban_token)
         with torch.cuda.device(self.device):
             check(self.lib.kmb_beam_merge_select(ptr(val), ptr(idx), B, int(num_beams), int(k), int(self.config.vocab_size),
                                                  ptr(cand), int(eos_token), ptr(nscore), ptr(ntok), ptr(nidx), _stream()))
         return cand, nscore, ntok, nidx
 
-    def logsoftmax_topk(self, logits, k, add=None, force_token=-1, ban_token=-1):
-        R = logits.shape[0]
-        val = torch.empty((R, k), dtype=torch.float32, device=self.device)
-        idx = torch.empty((R, k), dtype=torch.int32, device=self.device)
+    def _topk_scratch_for(self, R):
         nscr = int(self.lib.kmb_logsoftmax_topk_scratch(R))
         scr = self.__dict__.get("_topk_scratch")
         if scr is None or scr.numel() < nscr:
             scr = self._topk_scratch = torch.empty(nscr, dtype=torch.float32, device=self.device)
+        return scr
+
+    def logsoftmax_topk(self, logits, k, add=None, force_token=-1, ban_token=-1):
+        R = logits.shape[0]
+        val = torch.empty((R, k), dtype=torch.float32, device=self.device)
+        idx = torch.empty((R, k), dtype=torch.int32, device=self.device)
+        scr = self._topk_scratch_for(R)
         with torch.cuda.device(self.device):
             check(self.lib.kmb_logsoftmax_topk_ws(ptr(logits), logits.stride(0), int(self.config.vocab_size), R,
                                                   ptr(add), int(force_token), int(ban_token), int(k), ptr(val), ptr(idx),

@@ -635,6 +635,41 @@ def test_beam_merge_select_picks_the_beams_the_host_bookkeeping_sends_on():
                 assert (wt, wi) == (gt, gi) and (ws == gs or (ws != ws and gs != gs))
 
 
+@pytest.mark.parametrize("B,nb,k", [(6, 5, 10), (64, 5, 10), (3, 8, 16), (2, 16, 16), (5, 1, 2)])
+def test_beam_step_equals_topk_plus_merge_select(B, nb, k):
+    """kmb_beam_step (the decode loop's form: the rows' top-k lists stay in the workgroup that merges them) returns exactly what
+    kmb_logsoftmax_topk_ws + kmb_beam_merge_select return -- free, forced and min_length (banned EOS) steps."""
+    lib = _lib.load()
+    V, ld, eos = 50320, 50432, 2
+    R = B * nb
+    logits = torch.zeros((R, ld), device=DEV)
+    logits[:, :V] = rnd(R, V, seed=95 + B) * 3
+    logits[0, eos] = 40.0
+    add = rnd(R, seed=96)
+    scr = torch.empty(int(lib.kmb_logsoftmax_topk_scratch(R)), device=DEV)
+    for force, ban in ((-1, -1), (eos, -1), (-1, eos), (0, -1)):
+        val = torch.empty((R, k), device=DEV)
+        idx = torch.empty((R, k), dtype=torch.int32, device=DEV)
+        check(lib.kmb_logsoftmax_topk_ws(ptr(logits), ld, V, R, ptr(add), force, ban, k, ptr(val), ptr(idx), ptr(scr), scr.numel(), stream()))
+        ref = torch.empty((B, k, 2), dtype=torch.int32, device=DEV)
+        rs = torch.empty(R, device=DEV)
+        rt = torch.empty(R, dtype=torch.int64, device=DEV)
+        ri = torch.empty(R, dtype=torch.int32, device=DEV)
+        check(lib.kmb_beam_merge_select(ptr(val), ptr(idx), B, nb, k, V, ptr(ref), eos, ptr(rs), ptr(rt), ptr(ri), stream()))
+        out = torch.full((B, k, 2), -7, dtype=torch.int32, device=DEV)
+        ns = torch.full((R,), -7.0, device=DEV)
+        nt = torch.full((R,), -7, dtype=torch.int64, device=DEV)
+        ni = torch.full((R,), -7, dtype=torch.int32, device=DEV)
+        check(lib.kmb_beam_step(ptr(logits), ld, V, B, nb, ptr(add), force, ban, k, ptr(out), eos, ptr(ns), ptr(nt), ptr(ni),
+                                ptr(scr), scr.numel(), stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (force, ban)
+        assert torch.equal(ns.view(torch.int32), rs.view(torch.int32)) and torch.equal(nt, rt) and torch.equal(ni, ri), (force, ban)
+    with pytest.raises(RuntimeError):   # k beyond the fused form: the caller takes the two-call path
+        check(lib.kmb_beam_step(ptr(logits), ld, V, B, nb, ptr(add), -1, -1, 17, ptr(out), eos, ptr(ns), ptr(nt), ptr(ni),
+                                ptr(scr), scr.numel(), stream()))
+
+
 @pytest.mark.parametrize("M,N,K", [(320, 50320, 768), (160, 50320, 768), (129, 1000, 128), (300, 4100, 64), (1, 512, 192)])
 def test_gemm_all_rows_kernel_is_bit_identical(M, N, K):
     """The vocabulary projection of a decode step (R = batch x beams <= 320 rows) runs gemm_kernel_allrows: one workgroup per
