@@ -508,13 +508,15 @@ class Engine:
             cache[key] = torch.empty(shape, dtype=dtype, pin_memory=True)
         return cache[key]
 
-    def beam_step(self, logits, num_beams, k, add, force_token=-1, ban_token=-1, eos_token=-1):
+    def beam_step(self, logits, num_beams, k, add, force_token=-1, ban_token=-1, eos_token=-1, cand_out=None):
         """beam_candidates plus the next step's beams chosen on the device (kmb_beam_merge_select): returns
         (cand int32 [B, k, 2], next_scores fp32 [R], next_tokens int64 [R], next_beam_idx int32 [R]); nothing is
         copied to the host.  `add` may be one of the returned next_scores (stream order makes that safe)."""
         R = logits.shape[0]
         B = R // num_beams
-        cand = torch.empty((B, k, 2), dtype=torch.int32, device=self.device)
+        # cand_out: a page-locked host tensor [B, k, 2] int32 the kernel writes directly (device-visible host memory: no copy
+        # launch between two decode steps); the caller reads it after an event recorded behind this call
+        cand = cand_out if cand_out is not None else torch.empty((B, k, 2), dtype=torch.int32, device=self.device)
         nscore = torch.empty((R,), dtype=torch.float32, device=self.device)
         ntok = torch.empty((R,), dtype=torch.int64, device=self.device)
         nidx = torch.empty((R,), dtype=torch.int32, device=self.device)

@@ -729,11 +729,12 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                     logits = eng._gen_logits
                 else:
                     logits = eng.gen_step(last_tokens, cur_len - 1, want_logits=force < 0)
+                # the candidates land in the page-locked staging buffer straight from the kernel (no copy launch per step)
                 cand, beam_scores_dev, last_tokens, beam_idx = eng.beam_step(
-                    logits, num_beams, k, beam_scores_dev, force_token=force, ban_token=ban, eos_token=eos)
+                    logits, num_beams, k, beam_scores_dev, force_token=force, ban_token=ban, eos_token=eos,
+                    cand_out=staging[cur_len - 1])
                 if not last:
                     eng.gen_reorder(beam_idx, cur_len - 1)   # _reorder_cache, mixins.py:419-434
-                staging[cur_len - 1].copy_(cand, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 if pending is not None and replay(pending):
