@@ -2604,7 +2604,11 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       }
       if (verbose) fprintf(stderr, "[kmb gemm tune] akc=%d bkc=%d M=%d N=%d K=%d split=%d act=%d v%d order%d %.1f us\n",
                            p.a_kc, p.b_kc, p.M, p.N, p.K, p.split_k, p.act, c & 15, c >> 4, ms / 3 * 1e3);
-      if (ms < best_ms) { best_ms = ms; best = c; }
+      // diagnostic build: KMB_GEMM_BIAS6=<percent> ranks variant 6 as if it were that much faster than timed back-to-back (its
+      // cross-tile L2 touch costs it ~4 us per tile in this loop and pays inside a step: DESIGN.md section 4 "Round 4")
+      static const float bias6 = KMB_DIAG_ENV("KMB_GEMM_BIAS6") ? 1.f - 0.01f * (float)atof(KMB_DIAG_ENV("KMB_GEMM_BIAS6")) : 1.f;
+      const float rank_ms = (c & 15) == 6 ? ms * bias6 : ms;
+      if (rank_ms < best_ms) { best_ms = rank_ms; best = c; }
       timed.emplace_back(ms, c);
     }
     (void)hipEventDestroy(e0);
