@@ -348,6 +348,9 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
             "ms_per_generate": round(dt * 1e3, 2), "decoder_steps": int(steps),
             "us_per_decoder_step": round(dt / steps * 1e6, 1),
             "hbm_bytes_per_step": int(per_step), "hbm_frac": round(per_step / (dt / steps) / 6.3e12, 4),
+            # SURVEY.md section 8d's algorithmic bytes (weights + self-KV + cross-KV, NO logits round trip) over the 8 TB/s peak
+            "hbm_bytes_per_step_survey": int(weights + self_kv + cross_kv),
+            "hbm_frac_survey": round((weights + self_kv + cross_kv) / (dt / steps) / 8.0e12, 4),
             "gen_ids_match": ids_match, "gen_check_ok": gen_ok, "gen_rows_identical": "%d/%d" % (rows_equal, int(out.shape[0])),
             "gen_score_gap_max": float("%.3e" % gap), "gen_score_gap_of_differing_rows": float("%.3e" % diff_gap),
             "gen_score_gap_of_identical_rows": float("%.3e" % same_gap),
@@ -361,6 +364,44 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
                        "max_length": max_length}}
 
 
+def spawn_ranks(n):
+    """One child `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>`; its stdout /
+    stderr are inherited, so rank 0's JSON line comes out of this process's stdout unchanged.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+class ClockProbe:
+    """The shader clock the chip held between two points of the current stream (kmb_clock_stamp: s_memtime over
+    s_memrealtime per XCD).  A box that runs the GEMMs 3 % slower shows it here, not as a regression of the code."""
+
+    def __init__(self, lib, dev):
+        self.lib, self.buf = lib, torch.zeros((2, 16), dtype=torch.int64, device=dev)
+
+    def stamp(self, i):
+        from kmbart import _lib
+        _lib.check(self.lib.kmb_clock_stamp(C.c_void_p(self.buf[i].data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def mhz(self):
+        b = self.buf.cpu().view(2, 8, 2)
+        out = []
+        for x in range(8):
+            dc, dr = int(b[1, x, 0] - b[0, x, 0]), int(b[1, x, 1] - b[0, x, 1])
+            if b[0, x, 1] and b[1, x, 1] and dr > 0:
+                out.append(dc / dr * 100.0)
+        out.sort()
+        return round(out[len(out) // 2], 1) if out else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,6 +411,8 @@ def main():
                     help="per-GPU batch (weak scaling); 1024 x 96 tokens uses ~60 of the 288 GB; the GEMM grids fill better "
                          "with every doubling (`batch_sweep` reports 64 .. 2048: 0.79 / 1.53 / 1.72 / 1.80 / 1.89 M "
                          "tokens/s); rounds 1-2 quoted 512; the reference default is 64")
+    ap.add_argument("--windows", type=int, default=3,
+                    help="timed windows of --steps steps each; `value` / `ms_per_step` are the median window's")
     ap.add_argument("--lr", type=float, default=1e-5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -384,9 +427,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as a plain command (reference: vcg_train.py:350-355 mp.spawn's its ranks from one
+        # command): start N FRESH rank processes through torch.distributed.run -- before this process has made any GPU
+        # call, and as children, never as a re-exec -- relay their output (rank 0 prints the JSON line) and their exit code
+        sys.exit(spawn_ranks(args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.set_num_threads(usable_cores())
     # test hooks for a one-GPU box: KMB_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and KMB_BENCH_BACKEND=gloo carries
@@ -451,16 +496,27 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    # THREE timed windows of exactly --steps steps each, every one bracketed by barrier + synchronize and reduced with
+    # MAX over ranks; `value` is the MEDIAN window, `value_min` / `value_max` and `clock_mhz` (shader clock held inside each
+    # window) go beside it: a round whose gains are <= 3 % cannot be read off one window on one box
+    probe = ClockProbe(_lib.load(), dev)
+    windows = []
+    for _w in range(args.windows):
+        fence()
+        probe.stamp(0)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        probe.stamp(1)
+        fence()
+        wdt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([wdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wdt = float(t)
+        windows.append((wdt, probe.mhz()))
+    order = sorted(range(len(windows)), key=lambda i: windows[i][0])
+    dt, clock = windows[order[len(order) // 2]]
     last_loss = float(loss)
 
     tokens_per_step = world * args.batch * (S_ENC + T_DEC)
@@ -473,6 +529,10 @@ def main():
                                "%d enc tokens, %d dec tokens, random-init weights" % (REGIONS, S_ENC, T_DEC),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                    "target_tokens_per_sec": round(world * args.batch * T_DEC * args.steps / dt, 1)},
+        "windows": len(windows), "value_min": round(tokens_per_step * args.steps / windows[order[-1]][0], 1),
+        "value_max": round(tokens_per_step * args.steps / windows[order[0]][0], 1),
+        "ms_per_step_windows": [round(w[0] / args.steps * 1e3, 3) for w in windows],
+        "clock_mhz": clock, "clock_mhz_windows": [w[1] for w in windows],
         "final_loss": round(last_loss, 4),
         "model_tflops_per_gpu": round(value / world * GFLOP_PER_TOKEN / 1e3, 1),
         "mfma_frac_whole_step": round(value / world * GFLOP_PER_TOKEN / 1e3 / PEAK_BF16_TFLOPS, 4),

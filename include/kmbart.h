@@ -323,6 +323,23 @@ int kmb_allreduce_grads(kmb_handle* h, const kmb_allreduce_opts* opts, void* com
 int kmb_comm_wait(kmb_handle* h, void* compute_stream);                  /* compute_stream waits for the communication stream */
 int kmb_comm_gather_moments(kmb_handle* h, void* compute_stream);        /* algo 1: every rank gets every shard's exp_avg / exp_avg_sq */
 int64_t kmb_comm_pieces(const kmb_handle* h, int64_t max_piece_elems);   /* number of collectives one kmb_allreduce_grads issues */
+/* The partition itself, as a PURE HOST function of the arena layout (no communicator, no device: the world > 1 offsets of
+ * kmb_allreduce_grads / kmb_comm_gather_moments come from here and are checked on a CPU, tests/test_comm_plan_cpu.py).
+ * Piece i (0 <= i < kmb_comm_pieces) of a `world`-rank exchange as rank `rank` sees it; what DDP's bucket assignment is
+ * in the reference (vcg_train.py:98). */
+typedef struct kmb_comm_piece {
+  int32_t bucket;        /* gradient bucket (kmb_bucket_range) whose completion event the piece waits for */
+  int32_t repad_piece;   /* 1: the piece overlaps the image-projection weight (its padded bf16 copy is rebuilt after an update) */
+  int32_t repad_shard;   /* 1: this rank's shard does */
+  int32_t reserved;
+  int64_t offset, count; /* arena range of the piece, in elements; 64-element aligned */
+  int64_t shard;         /* count / world, 8-element aligned; 0 when the piece does not split that way (algo 1 refuses it) */
+  int64_t mine;          /* offset + rank * shard: the range [mine, mine + shard) this rank reduces / updates / owns moments of */
+} kmb_comm_piece;
+int kmb_comm_plan(const kmb_handle* h, int world, int rank, int64_t max_piece_elems, int64_t i, kmb_comm_piece* out);
+/* 1 after an algo-1 exchange with a fused optimizer on more than one rank (exp_avg / exp_avg_sq current on the owning
+ * rank's shards only), 0 again after kmb_comm_gather_moments */
+int kmb_comm_moments_sharded(const kmb_handle* h);
 
 /* ================= measurement ================= */
 /* time every GEMM launch of the following calls with HIP events on its own stream (bench.py roofline leg);
@@ -333,6 +350,10 @@ int kmb_set_side_stream(kmb_handle* h, int enable);   /* weight-gradient GEMMs o
 int kmb_profile_gemm(int enable);
 int kmb_profile_read(int variant, int64_t* launches, double* total_ms, double* total_flops);
 int kmb_profile_dump(const char* path);   /* one text line per profiled GEMM launch */
+/* out16 (device, zeroed by the caller): per XCD x (s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks) at the point
+ * of the stream where it runs; (d ticks / d real) x 100 MHz between two stamps = the clock the chip held in between
+ * (bench.py `clock_mhz`: a 3 % box difference shows as clock, not as a regression) */
+int kmb_clock_stamp(int64_t* out16, void* stream);
 
 /* ================= single operators (unit tests / profiling) ================= */
 int kmb_op_gemm(const KmbGemm* p, void* stream);

@@ -18,7 +18,23 @@ int hipfail(hipError_t e, const char* what) {
 }
 }  // namespace
 
+// (shader clock ticks, 100 MHz real-time ticks) per XCD: the quotient of two stamps' differences is the clock the chip held in
+// between (MI355X_MICROARCH.md "DVFS give-back" item 6).  One wave per workgroup, the grid round-robins over the eight XCDs.
+__global__ void clock_stamp_kernel(long long* out) {
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(0xF814) & 7u;   // HW_REG_XCC_ID
+    const long long c = (long long)__builtin_amdgcn_s_memtime(), r = (long long)__builtin_amdgcn_s_memrealtime();
+    out[2 * xcc] = c; out[2 * xcc + 1] = r;   // any workgroup of the XCD may win: the pairs are microseconds apart at most
+  }
+}
+
 extern "C" {
+
+int kmb_clock_stamp(int64_t* out16, void* stream) {
+  if (!out16) return kmb_set_error("kmb_clock_stamp: out16 (device, 16 x int64) is required");
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, (long long*)out16);
+  return hipfail(hipGetLastError(), "clock_stamp");
+}
 
 int kmb_op_gemm(const KmbGemm* p, void* stream) {
   const char* why = kmb_gemm_check(*p);

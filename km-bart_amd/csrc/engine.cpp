@@ -157,6 +157,7 @@ struct kmb_handle {
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 0;
   hipStream_t comm_stream = nullptr; hipEvent_t comm_ev = nullptr;
   int64_t comm_piece_cap = 0;   // piece size of the last algo-1 exchange: the moments' shards follow its piece boundaries
+  bool moments_sharded = false; // set by an algo-1 exchange with a fused optimizer on more than one rank, cleared by kmb_comm_gather_moments
   float* parts = nullptr;
   // pre-training head scratch
   bf16_t *hx = nullptr, *hy = nullptr, *hdy = nullptr, *hdx = nullptr, *hdlg = nullptr; float *hlg = nullptr, *hloss = nullptr, *dhead = nullptr;
@@ -1691,6 +1692,21 @@ std::vector<Piece> comm_pieces(const kmb_handle* h, int64_t max_piece_elems) {
   return out;
 }
 
+// piece i of the exchange as rank `rank` of `world` sees it: a pure function of the arena layout (no communicator, no device).
+// Every collective of kmb_allreduce_grads / kmb_comm_gather_moments takes its offsets from here, so the world > 1 arithmetic
+// is testable on a CPU (tests/test_comm_plan_cpu.py).
+int comm_plan_piece(const kmb_handle* h, const Piece& pc, int world, int rank, kmb_comm_piece* out) {
+  const size_t W = (size_t)world;
+  out->bucket = pc.bucket; out->offset = (int64_t)pc.off; out->count = (int64_t)pc.cnt;
+  const size_t shard = pc.cnt / W;   // pieces are multiples of 64 elements and world divides 8: shards stay 8-element aligned
+  out->shard = (shard * W == pc.cnt && (shard & 7) == 0) ? (int64_t)shard : 0;   // 0: this piece has no aligned shards (algo 1 refuses it)
+  out->mine = (int64_t)(pc.off + (size_t)rank * shard);
+  const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
+  out->repad_piece = (pc.off < iw1 && pc.off + pc.cnt > iw0) ? 1 : 0;
+  out->repad_shard = ((size_t)out->mine < iw1 && (size_t)out->mine + shard > iw0) ? 1 : 0;
+  return 0;
+}
+
 int comm_ready(const kmb_handle* h, const char* who) {
   if (!h->comm || !h->comm_stream) return fail("%s: no communicator (call kmb_comm_init first)", who);
   if (!h->P || !h->G) return fail("%s: arenas are not bound", who);
@@ -1757,6 +1773,15 @@ int kmb_comm_broadcast_params(kmb_handle* h, int root, void* stream) {
 
 int64_t kmb_comm_pieces(const kmb_handle* h, int64_t max_piece_elems) { return (int64_t)comm_pieces(h, max_piece_elems).size(); }
 
+int kmb_comm_plan(const kmb_handle* h, int world, int rank, int64_t max_piece_elems, int64_t i, kmb_comm_piece* out) {
+  if (!h || !out) return fail("kmb_comm_plan: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail("kmb_comm_plan: bad rank %d / world %d", rank, world);
+  const std::vector<Piece> pcs = comm_pieces(h, max_piece_elems);
+  if (i < 0 || i >= (int64_t)pcs.size()) return fail("kmb_comm_plan: piece %lld out of range (%zu pieces)", (long long)i, pcs.size());
+  return comm_plan_piece(h, pcs[(size_t)i], world, rank, out);
+}
+int kmb_comm_moments_sharded(const kmb_handle* h) { return h && h->moments_sharded ? 1 : 0; }
+
 int kmb_allreduce_grads(kmb_handle* h, const kmb_allreduce_opts* opts, void* compute_stream) {
   KCHK(comm_ready(h, "kmb_allreduce_grads"));
   static const kmb_allreduce_opts dflt{0, 0, 0, nullptr};
@@ -1784,18 +1809,19 @@ int kmb_allreduce_grads(kmb_handle* h, const kmb_allreduce_opts* opts, void* com
       continue;
     }
     // reduce-scatter: rank r ends up with the mean of shard r (in place: recvbuff = sendbuff + r * shard)
-    const size_t shard = pc.cnt / (size_t)W;   // pieces are multiples of 64 elements and W divides 8: shards stay 8-aligned
-    if (shard * (size_t)W != pc.cnt || (shard & 7)) return fail("kmb_allreduce_grads: piece of %zu elements does not split into %d aligned shards", pc.cnt, W);
-    const size_t mine = pc.off + (size_t)rank * shard;
+    kmb_comm_piece pl;
+    KCHK(comm_plan_piece(h, pc, W, rank, &pl));
+    if (pl.shard == 0) return fail("kmb_allreduce_grads: piece of %zu elements does not split into %d aligned shards", pc.cnt, W);
+    const size_t shard = (size_t)pl.shard, mine = (size_t)pl.mine;
     NCCLCHK(ncclReduceScatter(g, h->G + mine, shard, ncclFloat, ncclAvg, h->comm, cs));
     if (o.adamw) {
       KCHK(adamw_range(h, *o.adamw, mine, shard, cs));                                              // 30 B / parameter / W
       NCCLCHK(ncclAllGather(h->P + mine, h->P + pc.off, shard, ncclFloat, h->comm, cs));           // updated fp32 masters
       if (W > 1) {   // the other ranks' shards of the bf16 mirror (this rank's was written by the optimizer kernel)
         HIPCHK(kmb_cast_f32_bf16_launch(h->P + pc.off, h->PB + pc.off, pc.cnt, cs));
-        const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
-        if (pc.off < iw1 && pc.off + pc.cnt > iw0)
+        if (pl.repad_piece)
           HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, cs));
+        h->moments_sharded = true;   // exp_avg / exp_avg_sq are current on the owning rank's shard only
       }
     } else {
       NCCLCHK(ncclAllGather(h->G + mine, g, shard, ncclFloat, h->comm, cs));
@@ -1818,10 +1844,13 @@ int kmb_comm_gather_moments(kmb_handle* h, void* compute_stream) {
   if ((8 % W) != 0) return fail("kmb_comm_gather_moments: world size must divide 8");
   hipStream_t s = (hipStream_t)compute_stream;
   for (const Piece& pc : comm_pieces(h, h->comm_piece_cap)) {
-    const size_t shard = pc.cnt / (size_t)W, mine = pc.off + (size_t)rank * shard;
-    NCCLCHK(ncclAllGather(h->M1 + mine, h->M1 + pc.off, shard, ncclFloat, h->comm, s));
-    NCCLCHK(ncclAllGather(h->M2 + mine, h->M2 + pc.off, shard, ncclFloat, h->comm, s));
+    kmb_comm_piece pl;
+    KCHK(comm_plan_piece(h, pc, W, rank, &pl));
+    if (pl.shard == 0) return fail("kmb_comm_gather_moments: piece of %zu elements does not split into %d aligned shards", pc.cnt, W);
+    NCCLCHK(ncclAllGather(h->M1 + pl.mine, h->M1 + pc.off, (size_t)pl.shard, ncclFloat, h->comm, s));
+    NCCLCHK(ncclAllGather(h->M2 + pl.mine, h->M2 + pc.off, (size_t)pl.shard, ncclFloat, h->comm, s));
   }
+  h->moments_sharded = false;
   return 0;
 }
 

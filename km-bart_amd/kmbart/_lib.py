@@ -85,6 +85,11 @@ class KmbAllreduceOpts(C.Structure):
     _fields_ = [("algo", i32), ("after_compute", i32), ("max_piece_elems", i64), ("adamw", C.POINTER(KmbAdamW))]
 
 
+class KmbCommPiece(C.Structure):
+    _fields_ = [("bucket", i32), ("repad_piece", i32), ("repad_shard", i32), ("reserved", i32),
+                ("offset", i64), ("count", i64), ("shard", i64), ("mine", i64)]
+
+
 # name -> (restype, argtypes); must list every function include/kmbart.h declares
 PROTOTYPES = {
     "kmb_last_error": (C.c_char_p, []),
@@ -142,12 +147,15 @@ PROTOTYPES = {
     "kmb_comm_wait": (C.c_int, [c_p, c_p]),
     "kmb_comm_gather_moments": (C.c_int, [c_p, c_p]),
     "kmb_comm_pieces": (i64, [c_p, i64]),
+    "kmb_comm_plan": (C.c_int, [c_p, C.c_int, C.c_int, i64, i64, C.POINTER(KmbCommPiece)]),
+    "kmb_comm_moments_sharded": (C.c_int, [c_p]),
     "kmb_debug_trace": (C.c_int, [C.c_int]),
     "kmb_debug_trace_dump": (C.c_int, [C.c_char_p]),
     "kmb_set_side_stream": (C.c_int, [c_p, C.c_int]),
     "kmb_profile_gemm": (C.c_int, [C.c_int]),
     "kmb_profile_read": (C.c_int, [C.c_int, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
     "kmb_profile_dump": (C.c_int, [C.c_char_p]),
+    "kmb_clock_stamp": (C.c_int, [c_p, c_p]),
     "kmb_op_gemm": (C.c_int, [C.POINTER(KmbGemm), c_p]),
     "kmb_op_gemm_allrows": (C.c_int, [C.POINTER(KmbGemm), c_p]),
     "kmb_op_attn_fwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),

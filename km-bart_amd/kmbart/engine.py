@@ -447,8 +447,26 @@ class Engine:
             check(self.lib.kmb_comm_wait(self.h, _stream()))
 
     def comm_gather_moments(self):
+        """COLLECTIVE (every rank must call it): all-gathers the shards of exp_avg / exp_avg_sq that an algo-1 exchange with a
+        fused optimizer leaves current on their owning rank only."""
         with torch.cuda.device(self.device):
             check(self.lib.kmb_comm_gather_moments(self.h, _stream()))
+
+    @property
+    def moments_sharded(self):
+        """True after a reduce-scatter exchange with a fused optimizer on more than one rank, until comm_gather_moments()."""
+        return bool(self.lib.kmb_comm_moments_sharded(self.h))
+
+    def comm_plan(self, world, rank, max_piece_elems=0):
+        """The exchange's partition as rank `rank` of `world` sees it (kmb_comm_plan: a pure host function, no communicator
+        needed): list of dicts bucket / offset / count / shard / mine / repad_piece / repad_shard."""
+        from ._lib import KmbCommPiece
+        out = []
+        for i in range(int(self.lib.kmb_comm_pieces(self.h, int(max_piece_elems)))):
+            pc = KmbCommPiece()
+            check(self.lib.kmb_comm_plan(self.h, int(world), int(rank), int(max_piece_elems), i, C.byref(pc)))
+            out.append({k: int(getattr(pc, k)) for k in ("bucket", "offset", "count", "shard", "mine", "repad_piece", "repad_shard")})
+        return out
 
     # ---- generation -------------------------------------------------------------------------
     def gen_begin(self, input_ids, image_features, attention_mask, num_beams, max_length):

@@ -159,6 +159,12 @@ class AdamW(torch.optim.Optimizer):
             self._fused_pending = False
             return loss
         all_ranges = [self._engine_ranges(group) for group in self.param_groups]
+        for e in self._engines():
+            # a reduce-scatter exchange with the fused optimizer left exp_avg / exp_avg_sq current on their owning rank only
+            # (kmbart.parallel, algo "rsag"); this whole-arena step needs them everywhere.  step() runs on every rank, so the
+            # collective is matched.
+            if getattr(e, "moments_sharded", False):
+                e.comm_gather_moments()
         # ONE bias-correction step per optimizer.step(), whatever the number of parameter groups
         for e in self._engines():
             e.step_count += 1
@@ -177,6 +183,11 @@ class AdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         eng = self._engines()
+        for e in eng:
+            if getattr(e, "moments_sharded", False):
+                raise RuntimeError("exp_avg / exp_avg_sq are sharded over the data-parallel ranks (reduce-scatter exchange with "
+                                   "the fused optimizer): call DistributedDataParallel.gather_optimizer_state() on EVERY rank "
+                                   "(it is a collective) before optimizer.state_dict()")
         return {
             "kmbart_adamw": True,
             "step": [e.step_count for e in eng],
@@ -189,16 +200,28 @@ class AdamW(torch.optim.Optimizer):
             "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
         }
 
-    def load_state_dict(self, state):
+    def load_state_dict(self, state, assume_layout=False):
         """Accepts this class's own format and the torch / transformers.AdamW format the reference saves in
         `training_data.pt` (reference src/utils.py:20-39: {'state': {index: {'step', 'exp_avg', 'exp_avg_sq'}},
-        'param_groups': [{..., 'params': [indices]}]}): per-parameter moments are copied into the arena slices."""
+        'param_groups': [{..., 'params': [indices]}]}): per-parameter moments are copied into the arena slices.
+        assume_layout=True: a kmbart state saved before the arena layout was recorded is copied raw when its arena size
+        equals this engine's (correct only if the arena order has not changed since it was saved: the caller's claim)."""
         if state.get("kmbart_adamw"):
             layouts = state.get("layout")
             if layouts is None:
+                engines = self._engines()
+                if assume_layout and all(state["exp_avg"][i].numel() == e.exp_avg.numel() for i, e in enumerate(engines)):
+                    for i, e in enumerate(engines):
+                        e.step_count = int(state["step"][i])
+                        e.exp_avg.copy_(state["exp_avg"][i])
+                        e.exp_avg_sq.copy_(state["exp_avg_sq"][i])
+                    for g, s in zip(self.param_groups, state["param_groups"]):
+                        g.update(s)
+                    return
                 raise ValueError("this kmbart AdamW state has no arena layout (saved before the layout was recorded): the "
                                  "moment arenas cannot be assigned to parameters safely; save the optimizer again with this "
-                                 "build, or load a torch-format {state, param_groups} dict")
+                                 "build, load a torch-format {state, param_groups} dict, or -- if the arena order is known to "
+                                 "be unchanged and the sizes match -- pass assume_layout=True")
             for i, e in enumerate(self._engines()):
                 saved = layouts[i]
                 here = {n: (int(off), int(rows) * int(cols)) for n, (off, rows, cols) in e.index.items()}

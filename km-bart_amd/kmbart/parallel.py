@@ -23,7 +23,9 @@ update, so the un-overlapped tail is one piece, not 564 MB of all-reduce plus a 
 cast back (fp32 accumulation inside the optimizer is unchanged); off by default -- xGMI has the bandwidth at the
 benchmark batch, SURVEY.md section 5 prices when it does not.
 
-Native exchange (default on the nccl backend).  The library owns an RCCL communicator and a communication stream
+Native exchange (nccl backend; the default for a one-rank group, OPT-IN with KMB_DP_NATIVE=1 / native=True for more than one
+rank until a multi-GPU run of tests/dp_rccl_worker.py has passed on hardware: none of its world > 1 collectives has ever
+executed; their offsets are pinned on the CPU by tests/test_comm_plan_cpu.py).  The library owns an RCCL communicator and a communication stream
 (include/kmbart.h "data parallelism: native RCCL"): `kmb_allreduce_grads` enqueues EVERY bucket's ncclAllReduce(avg)
 behind its completion event -- and, with an optimizer attached, each piece's fused AdamW behind its collective -- from
 C++ in one call; torch.distributed only bootstraps the communicator's id and serves bench.py's barrier.  `KMB_DP_ALGO=rsag`
@@ -139,7 +141,9 @@ class DistributedDataParallel(torch.nn.Module):
         self.native = False
         active = self.world > 1 or (reduce_single_rank and dist.is_initialized())
         if native is None:
-            native = os.environ.get("KMB_DP_NATIVE", "1") != "0"
+            # world > 1 has never run on hardware through the library's own collectives: torch.distributed's reducer (same
+            # RCCL, same buckets, same fused optimizer pieces) stays the default there until it has; KMB_DP_NATIVE=1 opts in
+            native = os.environ.get("KMB_DP_NATIVE", "1" if self.world == 1 else "0") != "0"
         if algo is None:
             algo = os.environ.get("KMB_DP_ALGO", "allreduce")
         if algo not in ("allreduce", "rsag"):
@@ -162,7 +166,7 @@ class DistributedDataParallel(torch.nn.Module):
             if int(flag.item()) != 1:
                 if ok:
                     self.native_error = "the native RCCL bootstrap failed on another rank"
-                    eng.comm_destroy()
+                eng.comm_destroy()   # idempotent: also drops a communicator whose parameter broadcast raised on this rank
                 import sys
                 print("[kmbart] native RCCL exchange unavailable (%s): using the torch.distributed path" % self.native_error,
                       file=sys.stderr, flush=True)
@@ -171,6 +175,9 @@ class DistributedDataParallel(torch.nn.Module):
             # native exchange: the library's own communicator and communication stream (module docstring)
             self.native = True
             self.algo = 1 if (algo == "rsag" and 8 % self.world == 0) else 0
+            if algo == "rsag" and self.algo == 0:
+                import warnings
+                warnings.warn("algo='rsag' needs a world size that divides 8 (got %d): using all-reduce" % self.world)
             self.max_piece_elems = max_bucket_mb * (1 << 20) // 4
             self._opt = None
             module._post_backward = self._reduce_native
@@ -259,7 +266,9 @@ class DistributedDataParallel(torch.nn.Module):
             self._opt.fused_piece_step(self.engine, off, cnt)
 
     def gather_optimizer_state(self):
-        """rsag: exp_avg / exp_avg_sq are updated on the owning rank only; this all-gathers them (before a checkpoint)."""
+        """rsag: exp_avg / exp_avg_sq are updated on the owning rank only; this all-gathers them (before a checkpoint).
+        A COLLECTIVE: every rank must call it (calling it on rank 0 only hangs).  `AdamW.state_dict()` refuses to dump
+        sharded moments and a plain `AdamW.step()` gathers them first (every rank runs `step()`)."""
         if self.native and self.algo == 1:
             self.engine.comm_gather_moments()
 
