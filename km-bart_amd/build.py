@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libkmbart_hip.so")
-SOURCES = ["gemm.hip", "gemm_rolesplit.hip", "gemm_pair.hip", "gemm_lean.hip", "attention.hip", "norm.hip", "embed.hip", "loss.hip", "optim.hip", "heads.hip", "fp32_validate.hip", "decode.hip", "engine.cpp", "capi_ops.cpp"]
+SOURCES = ["gemm.hip", "gemm_pair.hip", "gemm_lean.hip", "attention.hip", "norm.hip", "embed.hip", "loss.hip", "optim.hip", "heads.hip", "fp32_validate.hip", "decode.hip", "engine.cpp", "capi_ops.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 # -fno-slp-vectorize: with SLP-packed fp32 math (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers on register pairs
 # assembled by v_mov) hipcc 7.2 produced an ln_bwd_kernel whose dz output is wrong in a few elements per launch (lanes 48-63,
@@ -41,7 +41,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src + ".o")
-        deps = [s] + headers + ([os.path.join(CSRC, "gemm.hip")] if src in ("gemm_rolesplit.hip", "gemm_pair.hip", "gemm_lean.hip") else [])   # they #include gemm.hip
+        deps = [s] + headers + ([os.path.join(CSRC, "gemm.hip")] if src in ("gemm_pair.hip", "gemm_lean.hip") else [])   # they #include gemm.hip
         if force or _stale(o, deps):
             jobs.append((s, o))
 
@@ -68,12 +68,23 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def build_variant(name, defines, sources=("gemm.hip",)):
+EXPERIMENTS = os.path.join(os.path.dirname(HERE), "tools", "experiments")   # measured-and-lost kernels: never in the product library
+
+
+def build_variant(name, defines, sources=("gemm.hip",), extra_sources=()):
     """Experiment build: lib/libkmbart_hip_<name>.so with extra -D defines on the given sources (the other objects are
-    the product build's).  Select it with KMB_LIB_PATH.  Never shipped: diagnostics and A/B measurements only."""
+    the product build's) plus `extra_sources` from tools/experiments/.  Select it with KMB_LIB_PATH.  Never shipped (built
+    on demand, on the box that uses it): diagnostics and A/B measurements only."""
     build(verbose=False)
     objdir = os.path.join(LIBDIR, "obj")
     objs = []
+    for src in extra_sources:
+        o = os.path.join(objdir, "%s.%s.o" % (src, name))
+        cmd = ["hipcc", "-x", "hip"] + FLAGS + ["-I" + CSRC] + ["-D" + d for d in defines] + ["-c", os.path.join(EXPERIMENTS, src), "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+        objs.append(o)
     for src in SOURCES:
         o = os.path.join(objdir, src + ".o")
         if src in sources:
@@ -96,10 +107,14 @@ if __name__ == "__main__":
         defs = sys.argv[i + 2:]
         # KMB_DIAG (csrc/diag.h) switches the A/B environment knobs and ablation bits on in every file that has them
         srcs = ("gemm.hip", "gemm_lean.hip", "engine.cpp", "attention.hip") if "KMB_DIAG" in defs else ("gemm.hip",)
-        if any(d.startswith("KMB_RS_") for d in defs):   # experiment builds of the role-split kernel
-            srcs = ("gemm_rolesplit.hip",)
+        extra = ()
+        if sys.argv[i + 1].startswith("rolesplit") or any(d.startswith("KMB_RS_") for d in defs):
+            # the role-split GEMM (variant 10, tools/experiments/gemm_rolesplit.hip): `--variant rolesplit` (+ KMB_RS_NOEPI ...
+            # for its timing-only builds); KMB_GEMM_VARIANT=10 KMB_LIB_PATH=lib/libkmbart_hip_rolesplit.so selects it
+            defs = list(defs) + ["KMB_WITH_ROLESPLIT"]
+            srcs, extra = ("gemm.hip",), ("gemm_rolesplit.hip",)
         if any(d.startswith("KMB_PR_") for d in defs):   # ... of the two-workgroups-per-CU kernel
             srcs = ("gemm_pair.hip",)
-        print(build_variant(sys.argv[i + 1], defs, srcs))
+        print(build_variant(sys.argv[i + 1], defs, srcs, extra))
     else:
         build(force="--force" in sys.argv)

@@ -2255,7 +2255,9 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
     if (!g_shared_device) return kmb_gemm_pair_launch(p, stream);
     variant = 12;
   }
-  if (variant == 10) return kmb_gemm_rs_launch(p, stream);   // role-split persistent kernel (gemm_rolesplit.hip)
+#ifdef KMB_WITH_ROLESPLIT   // experiment build only (tools/experiments/gemm_rolesplit.hip, build.py --variant rolesplit): not in the product library
+  if (variant == 10) return kmb_gemm_rs_launch(p, stream);
+#endif
   if (variant == 11) {
     dim3 grid(v11_grid(p, BN4)), block(256);
     uint32_t* sched = p.K / BK >= 4 ? v11_sched_slot(stream) : nullptr;
@@ -2535,7 +2537,11 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     int v = forced;
     if (v == 6 && !kmb_gemm_lean_ok(p)) v = 11;
     if (v == 9 && !kmb_gemm_pair_ok(p)) v = 11;
+#ifdef KMB_WITH_ROLESPLIT
     if (v == 10 && !kmb_gemm_rs_ok(p)) v = 11;
+#else
+    if (v == 10) v = 11;   // the role-split experiment is not part of this library
+#endif
     if (v == 11 && !v11_ok(p)) v = 8;
     if (v == 12 && !v11_ok(p, 128)) v = 8;
     if (v == 13 && !v11_ok(p, 192)) v = 8;
@@ -2553,8 +2559,8 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   auto it = g_best.find(key);
   if (it == g_best.end()) {
     if (!autotune || writes_an_input(p)) return p.act == 5 ? launch_config(p, 11, stream) : launch_variant(7, p, stream);
-    // (variant 10, the role-split kernel of gemm_rolesplit.hip, is NOT a candidate: bit-identical and tested, but slower than
-    //  the persistent variants on every benchmark-batch shape but two -- DESIGN.md section 4 "Round 4"; KMB_GEMM_VARIANT=10 forces it)
+    // (variant 10, the role-split kernel, lives in tools/experiments/ since round 5: bit-identical, slower than the persistent
+    //  variants on every benchmark-batch shape but two -- DESIGN.md section 4 "Round 4"; `build.py --variant rolesplit` links it)
     const int cands[18] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
                            14, 14 + 16, 15, 15 + 16,
                            7 + 16 * 5, 8 + 16 * 5,                                        // split-K only: slice-major
@@ -2580,7 +2586,6 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
       if (exclude & (1u << (c & 15))) continue;
       if ((c & 15) == 6 && !kmb_gemm_lean_ok(p)) continue;
       if ((c & 15) == 9 && !kmb_gemm_pair_ok(p)) continue;
-      if ((c & 15) == 10 && !kmb_gemm_rs_ok(p)) continue;
       if ((c & 15) == 11 && !v11_ok(p)) continue;
       if ((c & 15) == 12 && !v11_ok(p, 128)) continue;
       if ((c & 15) == 13 && !v11_ok(p, 192)) continue;

@@ -20,7 +20,8 @@ hipError_t kmb_gemm_lean_launch(const KmbGemm& p, hipStream_t stream, uint32_t* 
 // variant 9 (gemm_pair.hip): two persistent 256 x 128 workgroups per CU, 32-deep stages (forward layout)
 bool kmb_gemm_pair_ok(const KmbGemm& p);
 hipError_t kmb_gemm_pair_launch(const KmbGemm& p, hipStream_t stream);
-// variant 10 (gemm_rolesplit.hip): role-split persistent kernel, epilogue of tile t under the MFMAs of tile t + 1
+// variant 10 (tools/experiments/gemm_rolesplit.hip, experiment builds only: -DKMB_WITH_ROLESPLIT): role-split persistent
+// kernel, epilogue of tile t under the MFMAs of tile t + 1
 bool kmb_gemm_rs_ok(const KmbGemm& p);
 hipError_t kmb_gemm_rs_launch(const KmbGemm& p, hipStream_t stream);
 

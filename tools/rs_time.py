@@ -1,4 +1,6 @@
-"""Times the role-split GEMM (variant 10) against the tuner-free persistent variants on the benchmark-batch shapes, one
+"""(Round 5: the role-split kernel left the product library; build it with `python km-bart_amd/build.py --variant rolesplit` and run
+this tool with KMB_LIB_PATH=km-bart_amd/lib/libkmbart_hip_rolesplit.so -- in the product library KMB_GEMM_VARIANT=10 means 11.)
+Times the role-split GEMM (variant 10) against the tuner-free persistent variants on the benchmark-batch shapes, one
 process per variant (KMB_GEMM_VARIANT is read once); KMB_LIB_PATH selects an experiment build (-DKMB_RS_NODMA / -DKMB_RS_NOEPI:
 timing only, results are garbage).
 
