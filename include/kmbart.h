@@ -246,6 +246,10 @@ int kmb_reserve_head_rows(kmb_handle* h, int n);
 /* kmb_forward plus the three classification heads; `labels` must already carry -100 at <cls> positions (:297-298) */
 int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, int train, int need_grad,
                          float* logits_out, kmb_bf16* enc_out, void* stream);
+/* ... with a kmb_forward_opts record -- encoder_states: the reference passes `encoder_outputs` through to self.model,
+ * src/model/model.py:225-242; decoder_states_out; skip_head is refused */
+int kmb_forward_pretrain_ex(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, const kmb_forward_opts* opts,
+                            int train, int need_grad, float* logits_out, kmb_bf16* enc_out, void* stream);
 
 /* ================= generation ================= */
 /* encoder once (src/model/mixins.py:281-283) + cross-attention K/V of every decoder layer.  Asynchronous: everything is
@@ -260,6 +264,9 @@ int kmb_gen_encoder_states(kmb_handle* h, kmb_bf16* enc_out, void* stream);
 int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_out, void* stream);
 /* _reorder_cache (src/model/mixins.py:419-434): self-attention caches follow beam_idx [B*num_beams] */
 int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stream);
+/* The final decoder states of the last kmb_gen_step as bf16 [rows, d_model] (the `decoder_outputs[0]` of a cached bare-model
+ * forward, reference src/model/model.py:87-103 with use_cache; transformers 3.0.2 BartDecoder returns the one new position). */
+int kmb_gen_last_hidden(kmb_handle* h, kmb_bf16* out, void* stream);
 /* log_softmax + top-k per row of (logp + add[row]); force_token >= 0 forces that token
  * (adjust_logits_during_generation, src/model/mixins.py:400-417); ban_token >= 0 scores that token -inf AFTER the
  * normalisation (min_length: transformers 3.0.2 postprocess_next_token_scores acts on the log-probabilities) */

@@ -177,6 +177,9 @@ struct kmb_handle {
     int32_t *kv_row_base = nullptr;
     bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd; float* slab;
     std::vector<bf16_t*> wp;               // fused decode blocks: fragment-order weight copies, 6 per layer (empty: not eligible)
+    // the last kmb_gen_step's final decoder states: normalised rows at last_x, or (fused blocks, no vocabulary projection)
+    // pre-LayerNorm sums at last_z with the last layer's LayerNorm (last_g, last_b) still to be applied
+    const bf16_t* last_x = nullptr; const bf16_t* last_z = nullptr; const float *last_g = nullptr, *last_b = nullptr;
   } gen;
 
   KmbDrop drop_site(int site, bool train) const {
@@ -1371,6 +1374,15 @@ int kmb_forward_pretrain(kmb_handle* h, const kmb_batch* batch, const kmb_pretra
   return forward_impl(h, batch, extra, nullptr, train, need_grad, nullptr, logits_out, enc_out, stream);
 }
 
+int kmb_forward_pretrain_ex(kmb_handle* h, const kmb_batch* batch, const kmb_pretrain* extra, const kmb_forward_opts* opts,
+                            int train, int need_grad, float* logits_out, kmb_bf16* enc_out, void* stream) {
+  if (!extra) return fail("kmb_forward_pretrain_ex: extra is required");
+  if (opts && opts->skip_head) return fail("kmb_forward_pretrain_ex: skip_head does not apply to the pre-training forward");
+  if ((extra->n_mrm > 0 && !h->head[0].on) || (extra->n_attr > 0 && !h->head[1].on) || (extra->n_rel > 0 && !h->head[2].on))
+    return fail("kmb_forward_pretrain_ex: rows given for a head this model was built without (num_labels / num_attributes / num_relations)");
+  return forward_impl(h, batch, extra, opts, train, need_grad, nullptr, logits_out, enc_out, stream);
+}
+
 // --------------------------------------------------------------------------------- backward
 static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scale_dev, void* stream);
 int kmb_backward(kmb_handle* h, float loss_scale, void* stream) { return backward_impl(h, loss_scale, nullptr, stream); }
@@ -1948,6 +1960,7 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.ckv = g.ckv; G.kc[0] = g.kc[0]; G.kc[1] = g.kc[1]; G.vc[0] = g.vc[0]; G.vc[1] = g.vc[1];
   G.kv_row = g.kv_row; G.kv_row_base = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
   G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab; G.wp = g.wp;
+  G.last_x = nullptr; G.last_z = nullptr; G.last_g = nullptr; G.last_b = nullptr;
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam), all layers in ONE GEMM
   if (Ld > 0) {
     KmbGemm gm = lin_fwd(enc, d, h->wb(h->xkv_w), h->pf(h->xkv_b), Me, Ld * 2 * d, d);
@@ -2072,10 +2085,13 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       KCHK(block(b));
       zin = G.z; lg = h->pf(L.ln_g); lb = h->pf(L.ln_b);
     }
+    G.last_x = nullptr; G.last_z = G.z; G.last_g = lg; G.last_b = lb;
     if (lg && logits_out) {   // the last LayerNorm feeds only the vocabulary projection
       HIPCHK(kmb_ln_fwd_launch(G.z, lg, lb, G.x1, G.mean, G.rstd, R, d, eps, s));
       x = G.x1;
+      G.last_x = x; G.last_z = nullptr;
     }
+    if (!lg) { G.last_x = G.x0; G.last_z = nullptr; }   // a decoder without layers: the embedding output
   }
   for (int l = 0; !fused && l < h->cfg.decoder_layers; ++l) {
     const LayerP& L = h->dec[l];
@@ -2106,10 +2122,26 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     KCHK(proj_ln(G.hh, F, L.fc2_w, L.fc2_b, G.y, L.ln_g, L.ln_b, xn));
     bf16_t* t = x; x = xn; xn = t;
   }
+  if (!fused) { G.last_x = x; G.last_z = nullptr; }
   if (logits_out) {
     KmbGemm g = lin_fwd(x, d, h->wb(h->shared), h->flb, R, h->V, d);
     g.out_f32 = logits_out; g.ld_out_f32 = h->Vpad;
     KCHK(run_vocab_gemm(g, s));
+  }
+  return 0;
+}
+
+int kmb_gen_last_hidden(kmb_handle* h, kmb_bf16* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  auto& G = h->gen;
+  if (!G.active) return fail("kmb_gen_last_hidden: call kmb_gen_begin first");
+  if (!out) return fail("kmb_gen_last_hidden: out is required");
+  if (G.last_x) {
+    HIPCHK(hipMemcpyAsync(out, G.last_x, (size_t)G.R * h->d * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
+  } else if (G.last_z && G.last_g) {
+    HIPCHK(kmb_ln_fwd_launch(G.last_z, G.last_g, G.last_b, out, G.mean, G.rstd, G.R, h->d, h->cfg.layer_norm_eps, s));
+  } else {
+    return fail("kmb_gen_last_hidden: no kmb_gen_step has run since kmb_gen_begin");
   }
   return 0;
 }

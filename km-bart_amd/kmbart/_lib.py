@@ -118,6 +118,8 @@ PROTOTYPES = {
     "kmb_act_bytes": (C.c_int, [c_p]),
     "kmb_reserve_head_rows": (C.c_int, [c_p, C.c_int]),
     "kmb_forward_pretrain": (C.c_int, [c_p, C.POINTER(KmbBatch), C.POINTER(KmbPretrain), C.c_int, C.c_int, c_p, c_p, c_p]),
+    "kmb_forward_pretrain_ex": (C.c_int, [c_p, C.POINTER(KmbBatch), C.POINTER(KmbPretrain), C.POINTER(KmbForwardOpts), C.c_int, C.c_int,
+                                          c_p, c_p, c_p]),
     "kmb_backward": (C.c_int, [c_p, f32, c_p]),
     "kmb_backward_dev": (C.c_int, [c_p, c_p, c_p]),
     "kmb_adamw_step": (C.c_int, [c_p, C.POINTER(KmbAdamW), i64, i64, c_p]),
@@ -127,6 +129,7 @@ PROTOTYPES = {
     "kmb_gen_encoder_states": (C.c_int, [c_p, c_p, c_p]),
     "kmb_gen_step": (C.c_int, [c_p, c_p, C.c_int, c_p, c_p]),
     "kmb_gen_reorder": (C.c_int, [c_p, c_p, C.c_int, c_p]),
+    "kmb_gen_last_hidden": (C.c_int, [c_p, c_p, c_p]),
     "kmb_beam_merge": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p]),
     "kmb_beam_merge_select": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p]),
     "kmb_beam_step": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p,

@@ -256,12 +256,14 @@ class Engine:
 
     def forward_pretrain(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask,
                          labels, mrm=None, attr=None, rel=None, factors=(1.0, 1.0, 1.0, 1.0), train=False,
-                         need_grad=False, want_logits=False):
+                         need_grad=False, want_logits=False, encoder_states=None, want_encoder=False):
         """mrm = (rows int32 [n], soft targets fp32 [n, C]); attr = (rows, labels int64); rel = (obj rows, subj rows,
-        labels).  Returns (losses fp32 [5] = total, lm, mrm, attribute, relation; logits or None)."""
+        labels).  Returns (losses fp32 [5] = total, lm, mrm, attribute, relation; logits or None) -- plus the encoder states
+        with want_encoder.  `encoder_states` [B,S,D] skips the encoder (reference src/model/model.py:225-242 passes
+        `encoder_outputs` through to self.model)."""
         with torch.cuda.device(self.device):
-            b, keep, (B, S, T, ntot) = self._batch(input_ids, image_features, attention_mask, decoder_input_ids,
-                                                   decoder_attention_mask, labels)
+            b, keep, (B, S, T, ntot) = self._batch(input_ids, image_features if encoder_states is None else [], attention_mask,
+                                                   decoder_input_ids, decoder_attention_mask, labels)
             dev = self.device
 
             def i32(t):
@@ -292,12 +294,23 @@ class Engine:
             logits = torch.empty((B * T, self.logits_ld), dtype=torch.float32, device=dev) if want_logits else None
             self.fwd_serial += 1
             self._last_bt = (B, T)
-            check(self.lib.kmb_forward_pretrain(self.h, C.byref(b), C.byref(ex), 1 if train else 0,
-                                                1 if need_grad else 0, ptr(logits), None, _stream()))
+            self._last_S = S
+            D = int(self.config.d_model)
+            opts = KmbForwardOpts()
+            if encoder_states is not None:
+                if tuple(encoder_states.shape) != (B, S, D):
+                    raise ValueError("encoder_outputs[0] must be [batch, src_len, d_model] = %s, got %s"
+                                     % ((B, S, D), tuple(encoder_states.shape)))
+                encoder_states = encoder_states.to(device=dev, dtype=self.act_dtype).contiguous()
+                opts.encoder_states = ptr(encoder_states)
+                keep.append(encoder_states)
+            enc = torch.empty((B, S, D), dtype=self.act_dtype, device=dev) if want_encoder else None
+            check(self.lib.kmb_forward_pretrain_ex(self.h, C.byref(b), C.byref(ex), C.byref(opts), 1 if train else 0,
+                                                   1 if need_grad else 0, ptr(logits), ptr(enc), _stream()))
             self._keep = keep
             if logits is not None:
                 logits = logits.view(B, T, self.logits_ld)[:, :, : int(self.config.vocab_size)]
-            return losses, logits
+            return (losses, logits, enc) if want_encoder else (losses, logits)
 
     def check_inputs(self):
         """Raises if the device-side validation of the last forward flagged the batch (syncs)."""
@@ -500,6 +513,13 @@ class Engine:
                                         _stream()))
             self._keep_tok = tokens
         return self._gen_logits
+
+    def gen_last_hidden(self):
+        """[rows, d] bf16: the final decoder states of the last gen_step (kmb_gen_last_hidden)."""
+        out = torch.empty((self._gen_rows, int(self.config.d_model)), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_gen_last_hidden(self.h, ptr(out), _stream()))
+        return out
 
     def gen_reorder(self, beam_idx, step):
         with torch.cuda.device(self.device):

@@ -197,7 +197,10 @@ class _EncoderHandle:
         cap = int(max_cache_length or max(int(m.config.max_length), 64))
         eng.gen_begin(input_ids, image_features, attention_mask, 1, cap)
         enc = eng.gen_encoder_states()
-        enc._kmb_cache = DecoderCache(eng, input_ids.shape[0], cap)
+        # The cache handle is kept BY ENGINE, not on the returned tensor: the reference's generate loop expands the encoder
+        # states with index_select before the first cached step (src/model/mixins.py:286-324), which makes a new tensor.
+        # The inputs stay with it so that rows expanded num_beams-fold can re-create the cross-attention tables.
+        eng._gen_pending = {"cache": DecoderCache(eng, input_ids.shape[0], cap), "inputs": (input_ids, image_features, attention_mask, cap)}
         return (enc,)
 
     forward = __call__
@@ -339,8 +342,8 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         position there; no caller of the reference relies on that (fine_tune / validation pass labels, generate passes
         use_cache), and the teacher-forced logits of every position are what the parity tests compare."""
         eng = self._need_engine()
-        if labels is not None:
-            use_cache = False     # src/model/model.py:381-382
+        use_cache = self._resolve_use_cache(use_cache, labels is not None, decoder_input_ids, decoder_cached_states,
+                                            output_attentions, output_hidden_states)
         if use_cache or decoder_cached_states is not None:
             if output_attentions or output_hidden_states:
                 raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
@@ -394,8 +397,22 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             logits = LazyLogits(eng)
         return (loss, logits) + dec_extra + (enc,) + enc_extra
 
+    def _resolve_use_cache(self, use_cache, has_labels, decoder_input_ids, decoder_cached_states, output_attentions,
+                           output_hidden_states):
+        """Reference src/model/model.py:52-59 and :381-382: labels (any loss) or missing decoder_input_ids switch the cache
+        off, an explicit value is kept, None means config.use_cache.  Two cases keep the DEFAULT off here (an explicit
+        use_cache=True still raises there): training mode (the cached decode blocks are an inference path without dropout)
+        and requested attention / hidden-state outputs (the decode blocks do not materialise them)."""
+        if has_labels or decoder_input_ids is None:
+            return False
+        if use_cache is None:
+            if self.training or output_attentions or output_hidden_states:
+                return False
+            return bool(getattr(self.config, "use_cache", True))
+        return bool(use_cache)
+
     def _forward_cached(self, input_ids, image_features, attention_mask, encoder_outputs, decoder_input_ids,
-                        decoder_cached_states, max_cache_length=None):
+                        decoder_cached_states, max_cache_length=None, want_hidden=False):
         """One KV-cached decoder step over kmb_gen_step (reference src/model/model.py:384-397, mixins.py:386-398;
         transformers 3.0.2 BartDecoder with use_cache: only the last column of decoder_input_ids is embedded, at position
         len - 1).  First call (decoder_cached_states None): the encoder runs from input_ids / image_features -- or is
@@ -409,18 +426,32 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             raise ValueError("use_cache=True needs decoder_input_ids (src/model/model.py:52-53 turns the cache off without them)")
         cache = decoder_cached_states
         enc = encoder_outputs[0] if isinstance(encoder_outputs, (tuple, list)) else encoder_outputs
-        if cache is None and enc is not None and getattr(enc, "_kmb_cache", None) is not None:
-            cache = enc._kmb_cache
-            if cache.length != 0:
-                raise RuntimeError("this encoder output already has decoder positions behind it; pass its decoder_cached_states")
+        pend = getattr(eng, "_gen_pending", None)
+        if cache is None and enc is not None and input_ids is None:
+            # the reference's flow (mixins.py:281-324, :386-398): get_encoder()(...) ran, its states -- possibly expanded
+            # num_beams-fold with index_select(0, arange(B).repeat_interleave(k)) -- come back as encoder_outputs
+            if pend is None or pend["cache"].serial != eng.fwd_serial or pend["cache"].length != 0:
+                raise ValueError("the first cached step needs input_ids / image_features, or encoder_outputs made by "
+                                 "model.get_encoder()(...) of THIS model with no other forward in between")
+            cache = pend["cache"]
+            rows = decoder_input_ids.shape[0]
+            if rows != cache.rows:
+                ids0, feats0, mask0, cap0 = pend["inputs"]
+                if rows % ids0.shape[0] != 0 or enc.shape[0] != rows:
+                    raise ValueError("decoder_input_ids has %d rows; the encoder ran on %d items" % (rows, ids0.shape[0]))
+                # rows expanded k-fold: row i belongs to item i // k (the reference's expansion order); the encoder side
+                # is rebuilt with k rows per item (one more encoder pass; generate() itself never takes this route)
+                eng.gen_begin(ids0, feats0, mask0, rows // ids0.shape[0], cap0)
+                cache = DecoderCache(eng, rows, cap0)
+            eng._gen_pending = None
         new_cache = cache is None
         if new_cache:
             if input_ids is None:
                 raise ValueError("the first cached step needs input_ids / image_features, or the tuple returned by "
-                                 "model.get_encoder()(...) as encoder_outputs (expanded or re-created encoder states cannot "
-                                 "be mapped back to the engine's cross-attention cache)")
+                                 "model.get_encoder()(...) as encoder_outputs")
             enc = self.get_encoder()(input_ids, image_features, attention_mask, max_cache_length=max_cache_length)[0]
-            cache = enc._kmb_cache
+            cache = eng._gen_pending["cache"]
+            eng._gen_pending = None
         elif not isinstance(cache, DecoderCache) or cache.engine is not eng:
             raise TypeError("decoder_cached_states must be the DecoderCache a previous cached forward of this model returned")
         cache.check()
@@ -435,10 +466,13 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             raise ValueError("decoder position %d exceeds the cache (max_cache_length=%d)" % (t, cache.max_length))
         logits = None
         for pos in range(first, t):
-            logits = eng.gen_step(decoder_input_ids[:, pos], pos, want_logits=(pos == t - 1))
+            logits = eng.gen_step(decoder_input_ids[:, pos], pos, want_logits=(pos == t - 1) and not want_hidden)
         cache.length = t
-        V = int(self.config.vocab_size)
-        out = logits[:, :V].clone().view(R, 1, V)
+        if want_hidden:   # the bare model: the decoder's last hidden states of the new position (src/model/model.py:87-103)
+            out = eng.gen_last_hidden().view(R, 1, int(self.config.d_model))
+        else:
+            V = int(self.config.vocab_size)
+            out = logits[:, :V].clone().view(R, 1, V)
         if enc is None:
             enc = eng.gen_encoder_states()
         return (out, cache, enc)
@@ -870,13 +904,24 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
                 decoder_attention_mask=None, decoder_cached_states=None, labels=None, mrm_labels=None, mrm_mask=None,
                 attribute_labels=None, attribute_mask=None, relation_labels=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_logits=None, **unused):
+        """Reference src/model/model.py:162-309.  With any label the loss dict comes first: (losses, logits[, decoder hidden
+        states, decoder attentions], encoder states[, encoder hidden states, encoder attentions]) -- `outputs[1:]` of the bare
+        model behind the logits (:291, :309); without labels it is the conditional-generation forward (cache included).
+        `encoder_outputs` is passed through to the model as there (:225-242)."""
         eng = self._need_engine()
         cfg = self.config
-        if encoder_outputs is not None or decoder_cached_states is not None or output_attentions or output_hidden_states:
-            raise NotImplementedError("only the training forward of MultiModalBartForPreTraining is implemented")
         if labels is None and mrm_labels is None and attribute_labels is None and relation_labels is None:
-            return super().forward(input_ids, image_features, attention_mask=attention_mask,
-                                   decoder_input_ids=decoder_input_ids, decoder_attention_mask=decoder_attention_mask)
+            return super().forward(input_ids, image_features, attention_mask=attention_mask, encoder_outputs=encoder_outputs,
+                                   decoder_input_ids=decoder_input_ids, decoder_attention_mask=decoder_attention_mask,
+                                   decoder_cached_states=decoder_cached_states, use_cache=use_cache,
+                                   output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                                   return_logits=return_logits, **unused)
+        # any label switches the cache off (model.py:222-223); decoder_cached_states then has no meaning
+        output_attentions = cfg.output_attentions if output_attentions is None else output_attentions
+        output_hidden_states = cfg.output_hidden_states if output_hidden_states is None else output_hidden_states
+        enc_states = None
+        if encoder_outputs is not None:
+            enc_states = encoder_outputs[0] if isinstance(encoder_outputs, (tuple, list)) else encoder_outputs
         if mrm_labels is not None and mrm_mask is None:
             raise ValueError('"mrm_mask" cannot be None while "mrm_labels" is set')   # model.py:228-229
         B, T = decoder_input_ids.shape
@@ -910,11 +955,24 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
         need_grad = torch.is_grad_enabled()
         factors = (float(cfg.lm_loss_factor), float(cfg.mrm_loss_factor), float(cfg.attribute_loss_factor),
                    float(cfg.relation_loss_factor))
-        losses, logits = eng.forward_pretrain(input_ids, image_features, attention_mask, decoder_input_ids,
-                                              decoder_attention_mask, lm_labels, mrm=mrm, attr=attr, rel=rel,
-                                              factors=factors, train=self.training, need_grad=need_grad,
-                                              want_logits=bool(return_logits))
-        total = _LossFn.apply(self._anchor, self, losses[0:1]) if need_grad else losses[0]
+        losses, logits, enc = eng.forward_pretrain(input_ids, image_features, attention_mask, decoder_input_ids,
+                                                   decoder_attention_mask, lm_labels, mrm=mrm, attr=attr, rel=rel,
+                                                   factors=factors, train=self.training, need_grad=need_grad,
+                                                   want_logits=bool(return_logits), encoder_states=enc_states,
+                                                   want_encoder=True)
+        dec_extra, enc_extra = (), ()
+        if output_hidden_states:
+            dec_extra += (eng.hidden_states(1)[:-1],)
+            if enc_states is None:
+                enc_extra += (list(eng.hidden_states(0)),)
+        if output_attentions:
+            dec_extra += (eng.attention_probs(1),)
+            if enc_states is None:
+                enc_extra += (list(eng.attention_probs(0)),)
+        if enc_states is not None and isinstance(encoder_outputs, (tuple, list)):
+            enc_extra = tuple(x for x in encoder_outputs[1:] if isinstance(x, torch.Tensor) or x)
+        total = (_LossFn.apply(self._anchor, self, losses[0:1], enc_states if torch.is_tensor(enc_states) else None)
+                 if need_grad else losses[0])
         out = _DeviceLossDict(loss=total)
         if lm_labels is not None:   # model.py:293-302: without LM labels the term is 0 and the key is absent
             out["lm_loss"] = losses[1]
@@ -926,7 +984,7 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
             out["relation_loss"] = losses[4]
         if logits is None:
             logits = LazyLogits(eng)
-        return (out, logits)
+        return (out, logits) + dec_extra + (enc,) + enc_extra
 
 
 def _postprocess_next_token_scores(scores, prev_ids, cur_len, min_length, eos_token_id, repetition_penalty=1.0,
@@ -999,12 +1057,26 @@ class MultiModalBartModel(MultiModalBartForConditionalGeneration):
     def forward(self, input_ids, image_features, attention_mask=None, decoder_input_ids=None, encoder_outputs=None,
                 decoder_attention_mask=None, decoder_cached_states=None, use_cache=None, output_attentions=None,
                 output_hidden_states=None, **unused):
+        """Reference src/model/model.py:39-103: (decoder states[, cache][, decoder hidden states, decoder attentions], encoder
+        states[, encoder hidden states, encoder attentions]).  use_cache (default config.use_cache, _resolve_use_cache): the
+        KV-cached step -- decoder states of the new position [rows, 1, d], the DecoderCache, the encoder states."""
         eng = self._need_engine()
-        if decoder_cached_states is not None or (use_cache and not self.training):
-            raise NotImplementedError("the KV-cached decode step runs inside generate() (kmb_gen_step)")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused kernels")
-        assert decoder_input_ids is not None   # model.py:74
+        use_cache = self._resolve_use_cache(use_cache, False, decoder_input_ids, decoder_cached_states, output_attentions,
+                                            output_hidden_states)
+        if use_cache or decoder_cached_states is not None:
+            if output_attentions or output_hidden_states:
+                raise NotImplementedError("attention / hidden-state outputs are not materialised by the fused decode blocks")
+            return self._forward_cached(input_ids, image_features, attention_mask, encoder_outputs, decoder_input_ids,
+                                        decoder_cached_states, unused.get("max_cache_length"), want_hidden=True)
+        output_attentions = self.config.output_attentions if output_attentions is None else output_attentions
+        output_hidden_states = self.config.output_hidden_states if output_hidden_states is None else output_hidden_states
+        if decoder_input_ids is None:   # transformers 3.0.2 _prepare_bart_decoder_inputs: shift_tokens_right(input_ids)
+            pad = self.config.pad_token_id
+            prev = input_ids.clone()
+            idx_eos = (input_ids.ne(pad).sum(dim=1) - 1).unsqueeze(-1)
+            prev[:, 0] = input_ids.gather(1, idx_eos).squeeze()
+            prev[:, 1:] = input_ids[:, :-1]
+            decoder_input_ids = prev
         enc_states = None
         if encoder_outputs is not None:
             assert isinstance(encoder_outputs, tuple)   # model.py:84
@@ -1014,7 +1086,18 @@ class MultiModalBartModel(MultiModalBartForConditionalGeneration):
         _, _, enc, dec = eng.forward(input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask,
                                      None, train=self.training, need_grad=False, want_logits=False, want_encoder=True,
                                      encoder_states=enc_states, want_decoder_states=True, skip_head=True)
-        return (dec, enc)
+        dec_extra, enc_extra = (), ()
+        if output_hidden_states:
+            dec_extra += (eng.hidden_states(1)[:-1],)
+            if enc_states is None:
+                enc_extra += (list(eng.hidden_states(0)),)
+        if output_attentions:
+            dec_extra += (eng.attention_probs(1),)
+            if enc_states is None:
+                enc_extra += (list(eng.attention_probs(0)),)
+        if enc_states is not None:
+            enc_extra = tuple(x for x in encoder_outputs[1:] if isinstance(x, torch.Tensor) or x)
+        return (dec,) + dec_extra + (enc,) + enc_extra
 
     def generate(self, *args, **kwargs):
         raise AttributeError("MultiModalBartModel has no LM head; use MultiModalBartForConditionalGeneration.generate")

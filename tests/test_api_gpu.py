@@ -35,7 +35,7 @@ def test_bare_model_returns_decoder_and_encoder_states():
     model = MultiModalBartModel(cfg_from_oracle(ocfg))
     model.load_state_dict({k: v for k, v in sd.items()}, strict=False)
     model.to(DEV).eval()
-    out = model(decoder_input_ids=b["decoder_input_ids"].to(DEV),
+    out = model(decoder_input_ids=b["decoder_input_ids"].to(DEV), use_cache=False,
                 decoder_attention_mask=b["decoder_attention_mask"].to(DEV), **dev_batch(b))
     assert isinstance(out, tuple) and len(out) == 2
     dm, am = b["decoder_attention_mask"].bool(), b["attention_mask"].bool()
@@ -45,7 +45,7 @@ def test_bare_model_returns_decoder_and_encoder_states():
     keys = model.state_dict().keys()
     assert "shared.weight" in keys and "final_logits_bias" not in keys and not any(k.startswith("model.") for k in keys)
     # the second call reuses the encoder output (model.py:76-83): identical decoder states
-    again = model(decoder_input_ids=b["decoder_input_ids"].to(DEV), encoder_outputs=(out[1],),
+    again = model(decoder_input_ids=b["decoder_input_ids"].to(DEV), encoder_outputs=(out[1],), use_cache=False,
                   decoder_attention_mask=b["decoder_attention_mask"].to(DEV), **dev_batch(b))
     assert torch.equal(again[0], out[0])
 
@@ -298,7 +298,7 @@ def test_cached_forward_returns_logits_cache_and_encoder_states():
     dec = dec.to(DEV)
     V = ocfg.vocab_size
     with torch.no_grad():
-        full_logits, enc_full = model(decoder_input_ids=dec, **kw)[:2]
+        full_logits, enc_full = model(decoder_input_ids=dec, use_cache=False, **kw)[:2]
         ref_logits = O.forward(sd, ocfg, b["input_ids"], b["image_features"], b["attention_mask"], dec.cpu(), None, None)[1]
     assert rel(full_logits, ref_logits) < ACT_TOL
     # (a) one call with several columns = prefill: logits of the last position, the cache, the encoder states
@@ -320,7 +320,7 @@ def test_cached_forward_returns_logits_cache_and_encoder_states():
     nxt = model(input_ids=None, image_features=None, decoder_input_ids=dec[perm][:, :8], use_cache=True, decoder_cached_states=cache)
     assert rel(nxt[0][:, 0], full_logits[perm][:, 7]) < 1e-2
     # a stale cache is refused (another forward re-used the workspace); labels switch the cache off (model.py:381-382)
-    model(decoder_input_ids=dec, **kw)
+    model(decoder_input_ids=dec, use_cache=False, **kw)
     with pytest.raises(RuntimeError):
         model(input_ids=None, image_features=None, decoder_input_ids=dec, use_cache=True, decoder_cached_states=cache)
     three = model(decoder_input_ids=dec, labels=dec, use_cache=True, **kw)
@@ -340,6 +340,103 @@ def test_cached_forward_returns_logits_cache_and_encoder_states():
         if int(unfinished.max()) == 0:
             break
     assert ids.cpu().tolist() == want.cpu().tolist()
+    # (e) use_cache=None falls back to config.use_cache (True) when there are no labels (reference src/model/model.py:59):
+    # an eval forward returns the last position and the cache, exactly what use_cache=True returns
+    dflt = model(decoder_input_ids=dec[:, :7], **kw)
+    assert len(dflt) == 3 and isinstance(dflt[1], DecoderCache) and tuple(dflt[0].shape) == (4, 1, V)
+    assert torch.equal(dflt[0], model(decoder_input_ids=dec[:, :7], use_cache=True, **kw)[0])
+    model.config.use_cache = False
+    assert tuple(model(decoder_input_ids=dec[:, :7], **kw)[0].shape) == (4, 7, V)
+    model.config.use_cache = True
+    # (f) the reference's BEAM plumbing (mixins.py:281-324): the encoder output is expanded num_beams-fold with index_select
+    # (a new tensor: nothing rides on it) before the first cached step, which gets input_ids=None
+    k = 3
+    enc_out = model.get_encoder()(kw["input_ids"], kw["image_features"], kw["attention_mask"])
+    expand = torch.arange(4, device=DEV).repeat_interleave(k)
+    enc_exp = (enc_out[0].index_select(0, expand),)
+    mask_exp = kw["attention_mask"].index_select(0, expand)
+    start = torch.full((4 * k, 1), model.config.decoder_start_token_id, dtype=torch.long, device=DEV)
+    inp = model.prepare_inputs_for_generation(start, past=(enc_exp, None), attention_mask=mask_exp, use_cache=True)
+    lg, cache = model(**inp)[:2]
+    assert tuple(lg.shape) == (4 * k, 1, V) and cache.rows == 4 * k
+    one = model(decoder_input_ids=start[:4], use_cache=True, **kw)[0]
+    assert rel(lg[::k], one) < 1e-3 and rel(lg[1::k], one) < 1e-3     # every copy of an item decodes that item
+
+
+def test_bare_model_cached_step_and_taps():
+    """MultiModalBartModel.forward(use_cache / decoder_cached_states / output_*) (reference src/model/model.py:39-103): the
+    cached step returns the new position's decoder states + cache + encoder states; the hidden-state / attention taps of the
+    teacher-forced forward sit where the reference's filtered tuple puts them."""
+    from oracle.make_golden import copy_task_batch
+    from src.model.model import DecoderCache
+    ocfg = G.tiny_config()
+    sd = G.trained_state_dict()
+    model = MultiModalBartModel(cfg_from_oracle(ocfg))
+    model.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    model.to(DEV).eval()
+    b = copy_task_batch(13, 4)
+    kw = dev_batch(b)
+    g = torch.Generator().manual_seed(5)
+    dec = torch.randint(3, 400, (4, 6), generator=g)
+    dec[:, 0] = 0
+    dec = dec.to(DEV)
+    with torch.no_grad():
+        full = model(decoder_input_ids=dec, use_cache=False, **kw)
+        assert len(full) == 2
+        cache = None
+        for t in range(1, 7):
+            first = dict(kw) if cache is None else {"input_ids": None, "image_features": None}
+            step = model(decoder_input_ids=dec[:, :t], decoder_cached_states=cache, **first)   # use_cache defaults to True
+            assert len(step) == 3 and isinstance(step[1], DecoderCache) and tuple(step[0].shape) == (4, 1, ocfg.d_model)
+            cache = step[1]
+            assert rel(step[0][:, 0], full[0][:, t - 1]) < 1e-2, t
+        assert rel(step[2], full[1]) < 1e-2
+        taps = model(decoder_input_ids=dec, use_cache=False, output_hidden_states=True, output_attentions=True, **kw)
+    dec_states, dec_hidden, dec_attn, enc, enc_hidden, enc_attn = taps
+    assert torch.equal(dec_states, full[0]) and torch.equal(enc, full[1])
+    assert len(dec_hidden) == ocfg.decoder_layers and len(dec_attn) == ocfg.decoder_layers
+    assert len(enc_hidden) == ocfg.encoder_layers + 1 and len(enc_attn) == ocfg.encoder_layers
+    assert torch.equal(enc_hidden[-1], enc)
+
+
+def test_pretraining_forward_passes_encoder_outputs_and_taps_through():
+    """MultiModalBartForPreTraining.forward(encoder_outputs=..., output_*) (reference src/model/model.py:225-242 hands them to
+    self.model; :291 / :309 put the model's remaining outputs behind the logits)."""
+    from src.data.synthetic import make_pretrain_batch
+    from src.model import MultiModalBartForPreTraining
+    ocfg = G.tiny_config(num_labels=37, num_attributes=11, num_relations=9)
+    sd = G.golden_state_dict(ocfg, seed=33)
+    b = make_pretrain_batch(3, enc_len=24, dec_len=16, num_regions=6, seed=77, num_labels=37, num_attributes=11,
+                            num_relations=9, vocab_hi=G.TINY_SPECIAL_BASE, img_feat_id=ocfg.img_feat_id,
+                            special_base=G.TINY_SPECIAL_BASE, cls_id=ocfg.cls_token_id, mrm_probability=0.3)
+    b["image_features"] = G.golden_features([6, 6, 6])
+    cfg = cfg_from_oracle(ocfg, num_labels=37, num_attributes=11, num_relations=9)
+    torch.manual_seed(3)
+    model = MultiModalBartForPreTraining(cfg)
+    model.load_state_dict(sd, strict=False)
+    model.to(DEV).eval()
+    kw = dict(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
+              attention_mask=b["attention_mask"].to(DEV), decoder_input_ids=b["decoder_input_ids"].to(DEV),
+              decoder_attention_mask=b["decoder_attention_mask"].to(DEV), labels=b["labels"].to(DEV),
+              mrm_labels=b["mrm_labels"], mrm_mask=b["mrm_mask"], attribute_labels=b["attribute_labels"],
+              attribute_mask=b["attribute_mask"], relation_labels=b["relation_labels"])
+    with torch.no_grad():
+        base = model(**kw)
+        assert len(base) == 3 and isinstance(base[0], dict)            # (losses, logits, encoder states)
+        given = model(encoder_outputs=(base[2],), **kw)
+        for k_ in base[0]:
+            assert abs(float(given[0][k_]) - float(base[0][k_])) <= 1e-6 * abs(float(base[0][k_])) + 1e-7, k_
+        assert torch.equal(given[2], base[2])
+        taps = model(output_hidden_states=True, output_attentions=True, **kw)
+    losses, logits, dec_hidden, dec_attn, enc, enc_hidden, enc_attn = taps
+    assert len(dec_hidden) == ocfg.decoder_layers and len(enc_hidden) == ocfg.encoder_layers + 1
+    assert len(dec_attn) == ocfg.decoder_layers and len(enc_attn) == ocfg.encoder_layers
+    assert abs(float(losses["loss"]) - float(base[0]["loss"])) <= 1e-6 * abs(float(base[0]["loss"]))
+    # without any label it is the conditional-generation forward, cache included (model.py:222-223 only switch it off WITH labels)
+    nolab = {k_: v for k_, v in kw.items() if k_ in ("input_ids", "image_features", "attention_mask")}
+    with torch.no_grad():
+        out = model(decoder_input_ids=kw["decoder_input_ids"][:, :1], **nolab)
+    assert len(out) == 3 and tuple(out[0].shape) == (kw["input_ids"].shape[0], 1, ocfg.vocab_size)
 
 
 def test_embedding_accessors_and_resize():
