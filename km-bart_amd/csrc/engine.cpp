@@ -180,6 +180,7 @@ struct kmb_handle {
     // the last kmb_gen_step's final decoder states: normalised rows at last_x, or (fused blocks, no vocabulary projection)
     // pre-LayerNorm sums at last_z with the last layer's LayerNorm (last_g, last_b) still to be applied
     const bf16_t* last_x = nullptr; const bf16_t* last_z = nullptr; const float *last_g = nullptr, *last_b = nullptr;
+    uint32_t* bars = nullptr;
   } gen;
 
   KmbDrop drop_site(int site, bool train) const {
@@ -1877,6 +1878,7 @@ struct GenLayout {
   int32_t* kv_row; bf16_t *x0, *x1, *qkv, *o, *z, *y, *cq, *u, *hh; float *mean, *rstd;
   float* slab;   // split-K partial sums of the residual projections of a decode step
   std::vector<bf16_t*> wp;   // per layer: self q|k|v, self out, cross q, cross out, fc1, fc2 in fragment order (decode.hip)
+  uint32_t* bars;            // group-barrier counters of the resident decoder-layers kernel (decode.hip)
 };
 constexpr int GEN_MAX_SPLIT = 12;
 
@@ -1920,6 +1922,7 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
     for (int l = 0; l < Ld; ++l)
       for (int i = 0; i < 6; ++i) g.wp.push_back(bp.act(sizes[i]));
   }
+  g.bars = bp.take<uint32_t>(kmb_decode_layers_bar_words((int)R, Ld > 0 ? Ld : 1) + 64);
   if (out) *out = g;
   return bp.used();
 }
@@ -1961,6 +1964,7 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.kv_row = g.kv_row; G.kv_row_base = g.kv_row; G.x0 = g.x0; G.x1 = g.x1; G.qkv = g.qkv; G.o = g.o; G.z = g.z; G.y = g.y; G.cq = g.cq;
   G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab; G.wp = g.wp;
   G.last_x = nullptr; G.last_z = nullptr; G.last_g = nullptr; G.last_b = nullptr;
+  G.bars = g.bars;
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam), all layers in ONE GEMM
   if (Ld > 0) {
     KmbGemm gm = lin_fwd(enc, d, h->wb(h->xkv_w), h->pf(h->xkv_b), Me, Ld * 2 * d, d);
@@ -2052,7 +2056,48 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       HIPCHK(kmb_decode_block_launch(b, s));
       return 0;
     };
-    for (int l = 0; l < h->cfg.decoder_layers; ++l) {
+    // Resident form (decode.hip "resident decoder-layers kernel", round 5; KMB_GEN_FUSED=2): ALL the layers in one launch
+    // (KMB_GEN_LAYERS of them per launch), twelve co-resident workgroups per row tile behind counter barriers.  Bit-identical to the
+    // six-launches-per-layer blocks and MEASURED SLOWER than them (12.0 against 10.3 ms per generate at batch 64 x 5 beams: an
+    // in-kernel hand-off costs ~3.5 us where a kernel boundary costs ~1.7, and what a layer streams is bound by the CU's request
+    // rate either way -- DESIGN.md section 4 "Generation", round 5; profiles/r05_generation_resident_kernel_stamps.md), so it is
+    // opt-in; the blocks stay the default.
+    const int Ld = h->cfg.decoder_layers;
+    bool resident = fused_env && fused_env[0] == '2' && Ld > 0;
+    KmbDecodeLayers A;
+    if (resident) {
+      memset(&A, 0, sizeof(A));
+      A.n_layers = 1; A.x_in = G.x0; A.o = G.o; A.z = G.z; A.hh = G.hh; A.bars = G.bars; A.status = h->status;
+      A.R = R; A.F = F; A.H = h->Hd; A.Tmax = G.Tmax; A.Tk = step + 1; A.S = G.S; A.ldc = Ld * 2 * d; A.kv_group = G.nb;
+      A.key_mask = G.bt.attention_mask; A.mask_ld = G.S; A.eps = eps; A.q_scale = 0.125f;
+      if (kmb_decode_layers_check(A) != nullptr) resident = false;
+    }
+    if (resident) {
+      const char* lenv = getenv("KMB_GEN_LAYERS");
+      int per = lenv && atoi(lenv) > 0 ? atoi(lenv) : Ld;
+      if (per > KMB_DL_MAX_LAYERS) per = KMB_DL_MAX_LAYERS;
+      for (int l0 = 0; l0 < Ld; l0 += per) {
+        const int n = std::min(per, Ld - l0);
+        A.n_layers = n;
+        A.x_in = l0 == 0 ? G.x0 : G.z;
+        for (int i = 0; i < n; ++i) {
+          const int l = l0 + i;
+          const LayerP& L = h->dec[l];
+          KmbDecodeLayerP& P = A.L[i];
+          P.Wqkv = G.wp[(size_t)l * 6 + 0]; P.Wo = G.wp[(size_t)l * 6 + 1]; P.Wcq = G.wp[(size_t)l * 6 + 2];
+          P.Wco = G.wp[(size_t)l * 6 + 3]; P.W1 = G.wp[(size_t)l * 6 + 4]; P.W2 = G.wp[(size_t)l * 6 + 5];
+          P.bqkv = h->pf(L.sa.qkv_b); P.bo = h->pf(L.sa.o_b); P.bcq = h->pf(L.ca.qkv_b); P.bco = h->pf(L.ca.o_b);
+          P.b1 = h->pf(L.fc1_b); P.b2 = h->pf(L.fc2_b);
+          P.lnin_g = l == 0 ? nullptr : h->pf(h->dec[l - 1].ln_g); P.lnin_b = l == 0 ? nullptr : h->pf(h->dec[l - 1].ln_b);
+          P.ln1_g = h->pf(L.sa.ln_g); P.ln1_b = h->pf(L.sa.ln_b); P.ln2_g = h->pf(L.ca.ln_g); P.ln2_b = h->pf(L.ca.ln_b);
+          P.Kc = G.kc[G.cur][l]; P.Vc = G.vc[G.cur][l]; P.cK = G.ckv[l]; P.cV = G.ckv[l] + d;
+        }
+        const hipError_t le = kmb_decode_layers_launch(A, s);
+        if (le != hipSuccess) return fail("kmb_gen_step: resident decoder-layers launch failed: %s", hipGetErrorString(le));
+      }
+      zin = G.z; lg = h->pf(h->dec[Ld - 1].ln_g); lb = h->pf(h->dec[Ld - 1].ln_b);
+    }
+    for (int l = 0; !resident && l < h->cfg.decoder_layers; ++l) {
       const LayerP& L = h->dec[l];
       KmbDecodeBlock b;
       memset(&b, 0, sizeof(b));

@@ -37,6 +37,32 @@ hipError_t kmb_attn_decode_launch(const KmbAttnDecode& p, hipStream_t stream);
 // fused [LayerNorm ->] projection [-> attention] block of a decode step (R = batch x beams rows)
 const char* kmb_decode_block_check(const KmbDecodeBlock& p);
 hipError_t kmb_decode_block_launch(const KmbDecodeBlock& p, hipStream_t stream);
+// the resident decoder-layers kernel (decode.hip, round 5): n_layers whole decoder layers of a decode step in ONE launch,
+// 12 co-resident workgroups per 16-row tile separated by counter barriers instead of kernel boundaries
+constexpr int KMB_DL_MAX_LAYERS = 6;
+struct KmbDecodeLayerP {
+  const bf16_t *Wqkv, *Wo, *Wcq, *Wco, *W1, *W2;      // fragment-order copies (kmb_decode_pack_launch)
+  const float *bqkv, *bo, *bcq, *bco, *b1, *b2;
+  const float *lnin_g, *lnin_b;                       // LayerNorm of the rows entering the layer (null: already normalised)
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;         // self_attn_layer_norm, encoder_attn_layer_norm
+  bf16_t *Kc, *Vc;                                    // self-attention caches [R, Tmax, 768]
+  const bf16_t *cK, *cV;                              // cross-attention keys / values of this layer [B * S rows, stride ldc]
+};
+struct KmbDecodeLayers {
+  KmbDecodeLayerP L[KMB_DL_MAX_LAYERS];
+  int n_layers;
+  const bf16_t* x_in;             // [R, 768] rows entering L[0]
+  bf16_t *o, *z, *hh;             // exchange buffers [R, 768], [R, 768] (also the output: the last layer's pre-LayerNorm sums), [R, F]
+  unsigned* bars;                 // kmb_decode_layers_bar_words() counters, zeroed by the launcher
+  int32_t* status;                // bit 8: a group barrier gave up
+  int R, F, H, Tmax, Tk, S, ldc, kv_group;
+  const int64_t* key_mask; int mask_ld;
+  float eps, q_scale;
+};
+size_t kmb_decode_layers_lds(int Tmax, int S, int F);
+size_t kmb_decode_layers_bar_words(int R, int n_layers);
+const char* kmb_decode_layers_check(const KmbDecodeLayers& a);
+hipError_t kmb_decode_layers_launch(const KmbDecodeLayers& a, hipStream_t stream);
 // packed[i] <- copy of the row-major weight W[i] ([N, K], row stride ld) in the MFMA-fragment order the decode blocks read
 // (N % 16 == 0, K % 64 == 0), n <= 48 matrices in one launch
 hipError_t kmb_decode_pack_launch(const bf16_t* const* W, const int* ld, const int* N, const int* K, bf16_t* const* packed, int n,

@@ -327,6 +327,17 @@ class Engine:
         if st & 2:
             raise RuntimeError("a label is neither -100 nor inside [0, number of classes) "
                                "(the reference's CrossEntropyLoss raises on such a target, src/model/model.py:400-402)")
+        if st & 8:
+            raise RuntimeError("a group barrier of the resident decoder-layers kernel gave up (csrc/decode.hip: its workgroups were "
+                               "not all co-resident -- another kernel held CUs?); the generated tokens of this call are invalid. "
+                               "KMB_GEN_FUSED=1 selects the six-launches-per-layer blocks")
+
+    def read_status(self):
+        """The device status word of the last forward / generation (syncs); bits: _raise_on_status."""
+        st = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_read_status(self.h, C.byref(st), _stream()))
+        return int(st.value)
 
     def check_inputs_begin(self):
         """check_inputs without the wait: the status word is copied to page-locked memory in stream order; the caller
