@@ -113,6 +113,10 @@ typedef struct KmbAttnDecode {
    * attention over the cache) */
   const kmb_bf16* new_k; const kmb_bf16* new_v; int32_t ld_new;
   kmb_bf16* Kw; kmb_bf16* Vw;
+  /* optional history index of the self-attention cache ([R, Tmax] int32; NULL: a row's history lives in its own cache row): position
+   * t < Tk-1 of row r is read from cache row hist[r*Tmax + t]; the launch records hist[r*Tmax + Tk-1] = r for the row it appends.  A beam
+   * reorder then permutes these small rows instead of copying the caches (src/model/mixins.py:419-434 _reorder_cache). */
+  int32_t* hist;
 } KmbAttnDecode;
 
 /* One fused block of a KV-cached decode step (csrc/decode.hip): [LayerNorm ->] projection of R rows [-> attention].
@@ -139,6 +143,7 @@ typedef struct KmbDecodeBlock {
   int32_t Tmax, ldc, Tk;
   const int32_t* kv_row;                    /* kind 2: cache row (batch item) of every row */
   const int64_t* key_mask; int32_t mask_ld; /* kind 2: key t of cache row c is masked when key_mask[c*mask_ld + t] == 0 */
+  int32_t* hist;                            /* kind 1, optional: history index of the cache (see KmbAttnDecode.hist) */
   int32_t kv_group;                         /* kind 2, optional: a promise that kv_row[r] == r / kv_group (beam rows of a
                                              * batch item are consecutive): lets a workgroup stage each item's keys /
                                              * values once for all of its rows.  0: no promise. */

@@ -706,11 +706,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const KmbAttnDecode p)
   if (t_new >= 0) {
     p.Kw[((size_t)crow * p.Tmax + t_new) * HDm + h * HD + lane] = knew[lane];
     p.Vw[((size_t)crow * p.Tmax + t_new) * HDm + h * HD + lane] = vnew[lane];
+    if (p.hist != nullptr && h == 0 && lane == 0) p.hist[(size_t)row * p.Tmax + t_new] = crow;
   }
+  // history index (decode self-attention after beam reorders): position t of this row lives in cache row hist[row][t]
+  const int32_t* hrow = p.hist != nullptr ? p.hist + (size_t)row * p.Tmax : nullptr;
   float mx = -INFINITY;
   for (int t = lane; t < p.Tk; t += 64) {
     float s = 0.f;
-    const bf16_t* krow = (t == t_new) ? knew : Kc + (size_t)t * HDm;
+    const bf16_t* krow = (t == t_new) ? knew
+                         : hrow != nullptr ? p.Kc + ((size_t)hrow[t] * p.Tmax + t) * HDm + h * HD : Kc + (size_t)t * HDm;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float k8[8];
@@ -739,14 +743,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const KmbAttnDecode p)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   const int Tc = t_new >= 0 ? p.Tk - 1 : p.Tk;   // rows that live in the cache
   int t = 0;
+  auto vrow = [&](int tt) -> const bf16_t* {
+    return hrow != nullptr ? p.Vc + ((size_t)hrow[tt] * p.Tmax + tt) * HDm + h * HD : Vc + (size_t)tt * HDm;
+  };
 #pragma unroll 2
   for (; t + 4 <= Tc; t += 4) {
-    a0 += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
-    a1 += sc[t + 1] * bf2f(Vc[(size_t)(t + 1) * HDm + lane]);
-    a2 += sc[t + 2] * bf2f(Vc[(size_t)(t + 2) * HDm + lane]);
-    a3 += sc[t + 3] * bf2f(Vc[(size_t)(t + 3) * HDm + lane]);
+    a0 += sc[t] * bf2f(vrow(t)[lane]);
+    a1 += sc[t + 1] * bf2f(vrow(t + 1)[lane]);
+    a2 += sc[t + 2] * bf2f(vrow(t + 2)[lane]);
+    a3 += sc[t + 3] * bf2f(vrow(t + 3)[lane]);
   }
-  for (; t < Tc; ++t) a0 += sc[t] * bf2f(Vc[(size_t)t * HDm + lane]);
+  for (; t < Tc; ++t) a0 += sc[t] * bf2f(vrow(t)[lane]);
   if (t_new >= 0) a1 += sc[t_new] * bf2f(vnew[lane]);
   const float acc = (a0 + a1) + (a2 + a3);
   p.O[(size_t)row * p.ldo + h * HD + lane] = f2bf(acc * inv);

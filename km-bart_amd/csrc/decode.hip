@@ -419,6 +419,19 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   const int a_lr = threadIdx.x >> 4, a_s = threadIdx.x & 15;
   [[maybe_unused]] u32x4 pk0[SELF ? KU : 1], pk1[SELF ? KU : 1];
   [[maybe_unused]] uint2 pv[SELF ? VU : 1];
+  // history index (p.hist: position t of a row lives in cache row hist[row][t]; a beam reorder permutes these rows instead of copying the
+  // caches): the cache rows of the keys / values prefetched below, requested first of all so that they are back when the LayerNorm is done
+  [[maybe_unused]] int hk[SELF ? KU : 1], hv[SELF ? VU : 1];
+  if (SELF) {
+    const int prow = row0 + a_lr < p.R ? row0 + a_lr : 0;
+    const int tc = p.Tk - 1;
+    const int32_t* hrow = p.hist != nullptr ? p.hist + (size_t)prow * p.Tmax : nullptr;
+#pragma unroll
+    // (positions past the cached ones are dummy loads of position 0: from the row's OWN cache row -- hist[.][0] may not be written yet)
+    for (int u = 0; u < KU; ++u) { const int t = (a_s >> 2) + 4 * u; const int v = hrow != nullptr ? hrow[t < tc ? t : 0] : prow; hk[u] = t < tc ? v : prow; }
+#pragma unroll
+    for (int u = 0; u < VU; ++u) { const int v = hrow != nullptr ? hrow[u < tc ? u : 0] : prow; hv[u] = u < tc ? v : prow; }
+  }
   // KVLDS: this thread's chunks of the tile's keys / values (chunk c = tid + 256 i: staged row c / 8, 16-byte piece c % 8)
   [[maybe_unused]] u32x4 kreg[KVLDS ? NKV : 1], vreg[KVLDS ? NKV : 1];
   [[maybe_unused]] int first_item = 0, kv_rows = 0;
@@ -463,18 +476,18 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   }
   if (SELF) {
     const int prow = row0 + a_lr < p.R ? row0 + a_lr : 0;
-    const bf16_t* kc = p.Kc + (size_t)prow * p.Tmax * p.ldc + h * HD;
-    const bf16_t* vc = p.Vc + (size_t)prow * p.Tmax * p.ldc + h * HD;
     const int tc = p.Tk - 1;
 #pragma unroll
     for (int u = 0; u < KU; ++u) {   // (clamped addresses, no branch: a conditional load's register copy waits for the load)
-      const int t = (a_s >> 2) + 4 * u;
-      const bf16_t* kr = kc + (size_t)(t < tc ? t : 0) * p.ldc + (a_s & 3) * 16;
+      const int t = (a_s >> 2) + 4 * u, tt = t < tc ? t : 0;
+      const bf16_t* kr = p.Kc + ((size_t)hk[u] * p.Tmax + tt) * p.ldc + h * HD + (a_s & 3) * 16;
       pk0[u] = *reinterpret_cast<const u32x4*>(kr);
       pk1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
     }
 #pragma unroll
-    for (int u = 0; u < VU; ++u) pv[u] = *reinterpret_cast<const uint2*>(vc + (size_t)(u < tc ? u : 0) * p.ldc + a_s * 4);
+    for (int u = 0; u < VU; ++u)
+      pv[u] = *reinterpret_cast<const uint2*>(p.Vc + ((size_t)hv[u] * p.Tmax + (u < tc ? u : 0)) * p.ldc + h * HD + a_s * 4);
+    (void)prow;
   }
   __syncthreads();
   DSTAMP(stype, 1);
@@ -498,9 +511,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
       }
       const uint2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
       *reinterpret_cast<uint2*>(lds_q + r * QS + (part * HD + col) * 2) = pk;
-      if (SELF && part > 0 && row0 + r < p.R) {   // append to the cache
+      if (SELF && part > 0 && row0 + r < p.R) {   // append to the cache (the row's own cache row; the history index records it)
         bf16_t* dst = (part == 1 ? p.Kc : p.Vc) + ((size_t)(row0 + r) * p.Tmax + (p.Tk - 1)) * p.ldc + h * HD + col;
         *reinterpret_cast<uint2*>(dst) = pk;
+        if (p.hist != nullptr && h == 0 && tile == 4 && g == 0) p.hist[(size_t)(row0 + r) * p.Tmax + (p.Tk - 1)] = row0 + r;
       }
     }
   }
@@ -641,6 +655,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
         k0[u] = *reinterpret_cast<const u32x4*>(kr);
         k1[u] = *reinterpret_cast<const u32x4*>(kr + 16);
         madd[u] = my_m[ok ? t : 0];
+      } else if (SELF && p.hist != nullptr) {
+        const int tt = ok ? t : 0;
+        const bf16_t* kr = p.Kc + ((size_t)p.hist[(size_t)crow * p.Tmax + tt] * p.Tmax + tt) * p.ldc + h * HD + part * 16;
+        k0[u] = *reinterpret_cast<const u32x4*>(kr);
+        k1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
       } else {
         const bf16_t* kr = Kc + (size_t)(ok ? t : 0) * p.ldc + part * 16;
         k0[u] = *reinterpret_cast<const u32x4*>(kr);
@@ -705,7 +724,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
       const int t = t0 + u < Tc ? t0 + u : 0;
       if (SELF && t0 == 0) { vv[u] = pv[u]; continue; }
       vv[u] = KVLDS ? *reinterpret_cast<const uint2*>(my_v + (size_t)t * 128 + s * 8)
-                    : *reinterpret_cast<const uint2*>(Vc + (size_t)t * p.ldc + s * 4);
+              : (SELF && p.hist != nullptr)
+                  ? *reinterpret_cast<const uint2*>(p.Vc + ((size_t)p.hist[(size_t)crow * p.Tmax + t] * p.Tmax + t) * p.ldc + h * HD + s * 4)
+                  : *reinterpret_cast<const uint2*>(Vc + (size_t)t * p.ldc + s * 4);
     }
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
@@ -1007,6 +1028,18 @@ __global__ __launch_bounds__(256) void decode_layers_kernel(const KmbDecodeLayer
       DLSTAMP(0);
       if (l > 0) group_wait(bar - tiles, a.status);
       DLSTAMP(1);
+      // history index of the self-attention cache (a.hist; the same for every layer): the cache rows of the prefetched keys / values
+      constexpr int KU = 5, VU = 10;
+      const int a_lr = tid >> 4, a_s = tid & 15;
+      int hk[KU], hv[VU];
+      {
+        const int prow = row0 + a_lr < a.R ? row0 + a_lr : 0, tc = Tk - 1;
+        const int32_t* hrow = a.hist != nullptr ? a.hist + (size_t)prow * a.Tmax : nullptr;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) { const int t = (a_s >> 2) + 4 * u; const int v = hrow != nullptr ? hrow[t < tc ? t : 0] : prow; hk[u] = t < tc ? v : prow; }
+#pragma unroll
+        for (int u = 0; u < VU; ++u) { const int v = hrow != nullptr ? hrow[u < tc ? u : 0] : prow; hv[u] = u < tc ? v : prow; }
+      }
       {
         RowRegs<2> rr;
         rows_issue_sc1<2>(rr, l == 0 ? rs_in : rs_z, d, row0, a.R, d, P.lnin_g, P.lnin_b, wave, lane);
@@ -1025,24 +1058,19 @@ __global__ __launch_bounds__(256) void decode_layers_kernel(const KmbDecodeLayer
         const int tl = wave * 3 + t;
         bias[t] = *reinterpret_cast<const f32x4*>(P.bqkv + (tl >> 2) * d + h * HD + (tl & 3) * 16 + g * 4);
       }
-      constexpr int KU = 5, VU = 10;
-      const int a_lr = tid >> 4, a_s = tid & 15;
       u32x4 pk0[KU], pk1[KU];
       uint2 pv[VU];
       {
-        const int prow = row0 + a_lr < a.R ? row0 + a_lr : 0;
-        const bf16_t* kc = P.Kc + (size_t)prow * a.Tmax * d + h * HD;
-        const bf16_t* vc = P.Vc + (size_t)prow * a.Tmax * d + h * HD;
         const int tc = Tk - 1;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-          const int t = (a_s >> 2) + 4 * u;
-          const bf16_t* kr = kc + (size_t)(t < tc ? t : 0) * d + (a_s & 3) * 16;
+          const int t = (a_s >> 2) + 4 * u, tt = t < tc ? t : 0;
+          const bf16_t* kr = P.Kc + ((size_t)hk[u] * a.Tmax + tt) * d + h * HD + (a_s & 3) * 16;
           pk0[u] = *reinterpret_cast<const u32x4*>(kr);
           pk1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
         }
 #pragma unroll
-        for (int u = 0; u < VU; ++u) pv[u] = *reinterpret_cast<const uint2*>(vc + (size_t)(u < tc ? u : 0) * d + a_s * 4);
+        for (int u = 0; u < VU; ++u) pv[u] = *reinterpret_cast<const uint2*>(P.Vc + ((size_t)hv[u] * a.Tmax + (u < tc ? u : 0)) * d + h * HD + a_s * 4);
       }
       DLSTAMP(2);
       __syncthreads();
@@ -1080,6 +1108,7 @@ __global__ __launch_bounds__(256) void decode_layers_kernel(const KmbDecodeLayer
         if (part > 0 && row0 + r < a.R) {   // append to the cache
           bf16_t* dst = (part == 1 ? P.Kc : P.Vc) + ((size_t)(row0 + r) * a.Tmax + (Tk - 1)) * d + h * HD + col;
           *reinterpret_cast<uint2*>(dst) = pk;
+          if (a.hist != nullptr && l == 0 && h == 0 && tl == 4 && g == 0) a.hist[(size_t)(row0 + r) * a.Tmax + (Tk - 1)] = row0 + r;
         }
       }
       __syncthreads();
@@ -1103,7 +1132,12 @@ __global__ __launch_bounds__(256) void decode_layers_kernel(const KmbDecodeLayer
           const int t = t0 + kq + 4 * u;
           const bool ok = t < Tc;
           if (t0 == 0) { k0[u] = pk0[u]; k1[u] = pk1[u]; }
-          else {
+          else if (a.hist != nullptr) {
+            const int tt = ok ? t : 0;
+            const bf16_t* kr = P.Kc + ((size_t)a.hist[(size_t)row * a.Tmax + tt] * a.Tmax + tt) * d + h * HD + part * 16;
+            k0[u] = *reinterpret_cast<const u32x4*>(kr);
+            k1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
+          } else {
             const bf16_t* kr = Kc + (size_t)(ok ? t : 0) * d + part * 16;
             k0[u] = *reinterpret_cast<const u32x4*>(kr);
             k1[u] = *reinterpret_cast<const u32x4*>(kr + 8);
@@ -1162,7 +1196,8 @@ __global__ __launch_bounds__(256) void decode_layers_kernel(const KmbDecodeLayer
         for (int u = 0; u < VU; ++u) {
           const int t = t0 + u < Tc ? t0 + u : 0;
           if (t0 == 0) { vv[u] = pv[u]; continue; }
-          vv[u] = *reinterpret_cast<const uint2*>(Vc + (size_t)t * d + s * 4);
+          vv[u] = a.hist != nullptr ? *reinterpret_cast<const uint2*>(P.Vc + ((size_t)a.hist[(size_t)row * a.Tmax + t] * a.Tmax + t) * d + h * HD + s * 4)
+                                    : *reinterpret_cast<const uint2*>(Vc + (size_t)t * d + s * 4);
         }
 #pragma unroll
         for (int u = 0; u < VU; ++u) {

@@ -181,6 +181,11 @@ struct kmb_handle {
     // pre-LayerNorm sums at last_z with the last layer's LayerNorm (last_g, last_b) still to be applied
     const bf16_t* last_x = nullptr; const bf16_t* last_z = nullptr; const float *last_g = nullptr, *last_b = nullptr;
     uint32_t* bars = nullptr;
+    // History index of the self-attention caches (round 5): position t of beam row r lives in cache row hist[r][t].  A beam reorder
+    // (mixins.py:419-434 _reorder_cache) permutes these [R, Tmax] int rows into the other copy instead of gathering every layer's
+    // K and V cache ([R, t, d] x 12 buffers: 5-40 us per decode step at batch 64 x 5 beams); the caches are never copied
+    // (kc[0] / vc[0] only).  KMB_GEN_HIST=0 restores the physical reorder.
+    int32_t* hist[2] = {nullptr, nullptr}; int hcur = 0; bool use_hist = true;
   } gen;
 
   KmbDrop drop_site(int site, bool train) const {
@@ -1879,6 +1884,7 @@ struct GenLayout {
   float* slab;   // split-K partial sums of the residual projections of a decode step
   std::vector<bf16_t*> wp;   // per layer: self q|k|v, self out, cross q, cross out, fc1, fc2 in fragment order (decode.hip)
   uint32_t* bars;            // group-barrier counters of the resident decoder-layers kernel (decode.hip)
+  int32_t* hist[2];          // history index of the self-attention caches [R, Tmax], ping-pong over beam reorders
 };
 constexpr int GEN_MAX_SPLIT = 12;
 
@@ -1923,6 +1929,7 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
       for (int i = 0; i < 6; ++i) g.wp.push_back(bp.act(sizes[i]));
   }
   g.bars = bp.take<uint32_t>(kmb_decode_layers_bar_words((int)R, Ld > 0 ? Ld : 1) + 64);
+  g.hist[0] = bp.take<int32_t>(R * Tmax); g.hist[1] = bp.take<int32_t>(R * Tmax);
   if (out) *out = g;
   return bp.used();
 }
@@ -1965,6 +1972,8 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.u = g.u; G.hh = g.hh; G.mean = g.mean; G.rstd = g.rstd; G.slab = g.slab; G.wp = g.wp;
   G.last_x = nullptr; G.last_z = nullptr; G.last_g = nullptr; G.last_b = nullptr;
   G.bars = g.bars;
+  G.hist[0] = g.hist[0]; G.hist[1] = g.hist[1]; G.hcur = 0;
+  { const char* he = getenv("KMB_GEN_HIST"); G.use_hist = !(he && he[0] == '0'); }
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam), all layers in ONE GEMM
   if (Ld > 0) {
     KmbGemm gm = lin_fwd(enc, d, h->wb(h->xkv_w), h->pf(h->xkv_b), Me, Ld * 2 * d, d);
@@ -2070,6 +2079,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       A.n_layers = 1; A.x_in = G.x0; A.o = G.o; A.z = G.z; A.hh = G.hh; A.bars = G.bars; A.status = h->status;
       A.R = R; A.F = F; A.H = h->Hd; A.Tmax = G.Tmax; A.Tk = step + 1; A.S = G.S; A.ldc = Ld * 2 * d; A.kv_group = G.nb;
       A.key_mask = G.bt.attention_mask; A.mask_ld = G.S; A.eps = eps; A.q_scale = 0.125f;
+      A.hist = G.use_hist ? G.hist[G.hcur] : nullptr;
       if (kmb_decode_layers_check(A) != nullptr) resident = false;
     }
     if (resident) {
@@ -2104,6 +2114,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       b.kind = 1; b.in = zin; b.ld_in = d; b.gamma = lg; b.beta = lb; b.eps = eps; b.ln_out = lg ? G.x1 : nullptr;
       b.W = G.wp[(size_t)l * 6 + 0]; b.bias = h->pf(L.sa.qkv_b); b.R = R; b.K = d; b.N = 3 * d; b.out = G.o; b.ld_out = d;
       b.H = h->Hd; b.q_scale = 0.125f; b.Kc = G.kc[G.cur][l]; b.Vc = G.vc[G.cur][l]; b.Tmax = G.Tmax; b.ldc = d; b.Tk = step + 1;
+      b.hist = G.use_hist ? G.hist[G.hcur] : nullptr;
       KCHK(block(b));
       const bf16_t* xres = lg ? G.x1 : zin;
       memset(&b, 0, sizeof(b));
@@ -2148,6 +2159,7 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     a.R = R; a.H = h->Hd; a.Tk = step + 1; a.O = G.o; a.ldo = d;
     // this step's key / value: attended to from the projection output and appended to the cache by the same launch
     a.new_k = G.qkv + d; a.new_v = G.qkv + 2 * d; a.ld_new = 3 * d; a.Kw = G.kc[G.cur][l]; a.Vw = G.vc[G.cur][l];
+    a.hist = G.use_hist ? G.hist[G.hcur] : nullptr;
     HIPCHK(kmb_attn_decode_launch(a, s));
     KCHK(proj_ln(G.o, d, L.sa.o_w, L.sa.o_b, x, L.sa.ln_g, L.sa.ln_b, G.y));
     // cross attention over the cached encoder K|V of the row's batch item
@@ -2196,6 +2208,16 @@ int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stre
   auto& G = h->gen;
   if (!G.active) return fail("kmb_gen_reorder: call kmb_gen_begin first");
   const int d = h->d;
+  if (G.use_hist) {   // permute the history index, not the caches
+    HIPCHK(kmb_gather_hist_launch(G.hist[G.hcur], beam_idx, G.hist[G.hcur ^ 1], G.R, G.Tmax, step + 1, s));
+    G.hcur ^= 1;
+    if (G.nb == 1) {   // independent rows: the row -> cross-attention item table follows (see below)
+      int32_t* other = G.kv_row == G.kv_row_base ? G.kv_row_base + G.R : G.kv_row_base;
+      HIPCHK(kmb_gather_i32_launch(G.kv_row, beam_idx, other, G.R, s));
+      G.kv_row = other;
+    }
+    return 0;
+  }
   const int row_bytes = (step + 1) * d * (int)sizeof(bf16_t);
   const size_t stride = (size_t)G.Tmax * d * sizeof(bf16_t);
   // every layer's K and V cache in one launch per 16 buffers (12 launches -> 1 for a 6-layer decoder)

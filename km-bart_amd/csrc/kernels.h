@@ -58,6 +58,7 @@ struct KmbDecodeLayers {
   int R, F, H, Tmax, Tk, S, ldc, kv_group;
   const int64_t* key_mask; int mask_ld;
   float eps, q_scale;
+  int32_t* hist;                  // optional history index of the self-attention caches (KmbAttnDecode.hist)
 };
 size_t kmb_decode_layers_lds(int Tmax, int S, int F);
 size_t kmb_decode_layers_bar_words(int R, int n_layers);
@@ -176,6 +177,7 @@ hipError_t kmb_gather_rows_multi_launch(const void* const* src, void* const* dst
                                         int row_bytes, size_t stride_bytes, hipStream_t stream);
 // dst[i] = src[idx[i]]  (dst must not alias src)
 hipError_t kmb_gather_i32_launch(const int32_t* src, const int32_t* idx, int32_t* dst, int n, hipStream_t stream);
+hipError_t kmb_gather_hist_launch(const int32_t* src, const int32_t* idx, int32_t* dst, int rows, int ld, int nt, hipStream_t stream);
 hipError_t kmb_iota_div_launch(int32_t* out, int n, int div, hipStream_t stream);   // out[i] = i / div
 hipError_t kmb_gather_rows_launch(const void* src, const int32_t* idx, void* dst, int rows, int row_bytes,
                                   size_t stride_bytes, hipStream_t stream);

@@ -122,6 +122,16 @@ __global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t* __restri
   if (i < n) dst[i] = src[idx[i]];
 }
 
+// dst[r][t] = src[idx[r]][t], t < nt: the beam reorder of the self-attention caches' HISTORY INDEX (rows of ld ints) -- the
+// caches themselves stay where they are (KmbAttnDecode.hist)
+__global__ __launch_bounds__(256) void gather_hist_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          int32_t* __restrict__ dst, int rows, int ld, int nt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * nt) return;
+  const int r = i / nt, t = i - r * nt;
+  dst[(size_t)r * ld + t] = src[(size_t)idx[r] * ld + t];
+}
+
 // out[i] = i / div  (the beam row -> batch item table of a generation)
 __global__ __launch_bounds__(256) void iota_div_kernel(int32_t* __restrict__ out, int n, int div) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -191,6 +201,12 @@ hipError_t kmb_iota_div_launch(int32_t* out, int n, int div, hipStream_t stream)
   if (n <= 0) return hipSuccess;
   if (div <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iota_div_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, div);
+  return hipGetLastError();
+}
+
+hipError_t kmb_gather_hist_launch(const int32_t* src, const int32_t* idx, int32_t* dst, int rows, int ld, int nt, hipStream_t stream) {
+  if (rows <= 0 || nt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_hist_kernel, dim3((rows * nt + 255) / 256), dim3(256), 0, stream, src, idx, dst, rows, ld, nt);
   return hipGetLastError();
 }
 

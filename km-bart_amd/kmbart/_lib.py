@@ -62,14 +62,14 @@ class KmbAttn(C.Structure):
 class KmbAttnDecode(C.Structure):
     _fields_ = [("Q", c_p), ("ldq", i32), ("Kc", c_p), ("Vc", c_p), ("Tmax", i32), ("ldc", i32), ("kv_row", c_p),
                 ("key_mask", c_p), ("mask_ld", i32), ("mask_row", c_p), ("R", i32), ("H", i32), ("Tk", i32),
-                ("O", c_p), ("ldo", i32), ("new_k", c_p), ("new_v", c_p), ("ld_new", i32), ("Kw", c_p), ("Vw", c_p)]
+                ("O", c_p), ("ldo", i32), ("new_k", c_p), ("new_v", c_p), ("ld_new", i32), ("Kw", c_p), ("Vw", c_p), ("hist", c_p)]
 
 
 class KmbDecodeBlock(C.Structure):
     _fields_ = [("kind", i32), ("in_", c_p), ("ld_in", i32), ("gamma", c_p), ("beta", c_p), ("eps", f32), ("ln_out", c_p),
                 ("W", c_p), ("bias", c_p), ("R", i32), ("K", i32), ("N", i32), ("act", i32), ("residual", c_p),
                 ("ld_res", i32), ("out", c_p), ("ld_out", i32), ("H", i32), ("q_scale", f32), ("Kc", c_p), ("Vc", c_p),
-                ("Tmax", i32), ("ldc", i32), ("Tk", i32), ("kv_row", c_p), ("key_mask", c_p), ("mask_ld", i32), ("kv_group", i32)]
+                ("Tmax", i32), ("ldc", i32), ("Tk", i32), ("kv_row", c_p), ("key_mask", c_p), ("mask_ld", i32), ("hist", c_p), ("kv_group", i32)]
 
 
 class KmbDrop(C.Structure):
