@@ -157,6 +157,7 @@ struct kmb_handle {
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 0;
   hipStream_t comm_stream = nullptr; hipEvent_t comm_ev = nullptr;
   int64_t comm_piece_cap = 0;   // piece size of the last algo-1 exchange: the moments' shards follow its piece boundaries
+  uint64_t mirror_version = 1;   // bumped whenever the bf16 mirror is rewritten (sync / optimizer): kmb_gen_begin repacks the decoder weights only then
   bool moments_sharded = false; // set by an algo-1 exchange with a fused optimizer on more than one rank, cleared by kmb_comm_gather_moments
   float* parts = nullptr;
   // pre-training head scratch
@@ -186,6 +187,7 @@ struct kmb_handle {
     // K and V cache ([R, t, d] x 12 buffers: 5-40 us per decode step at batch 64 x 5 beams); the caches are never copied
     // (kc[0] / vc[0] only).  KMB_GEN_HIST=0 restores the physical reorder.
     int32_t* hist[2] = {nullptr, nullptr}; int hcur = 0; bool use_hist = true;
+    uint64_t packed_version = 0; const bf16_t* packed_at = nullptr;   // the fragment-order copies at wp[0] were made from mirror version ...
   } gen;
 
   KmbDrop drop_site(int site, bool train) const {
@@ -1004,6 +1006,7 @@ int kmb_bind_arenas(kmb_handle* h, float* params, float* grads, float* exp_avg, 
     return fail("kmb_bind_arenas: arenas must be 256-byte aligned");
   h->P = params; h->G = grads; h->M1 = exp_avg; h->M2 = exp_avg_sq; h->PB = params_bf16; h->flb = final_logits_bias;
   h->imgw_pad = h->PB + align_up(h->shared + (size_t)h->Vpad * h->d, 64);
+  h->mirror_version++;
   return 0;
 }
 
@@ -1013,7 +1016,7 @@ int64_t kmb_workspace_bytes(const kmb_handle* h, int B, int S, int T, int n_feat
 }
 int kmb_bind_workspace(kmb_handle* h, void* ws, int64_t bytes) {
   if (((uintptr_t)ws) & 255) return fail("kmb_bind_workspace: workspace must be 256-byte aligned");
-  h->ws = (char*)ws; h->ws_bytes = (size_t)bytes; h->have_fwd = false; h->have_hdec = false; h->gen.active = false;
+  h->ws = (char*)ws; h->ws_bytes = (size_t)bytes; h->have_fwd = false; h->have_hdec = false; h->gen.active = false; h->gen.packed_at = nullptr;
   return 0;
 }
 
@@ -1023,6 +1026,7 @@ int kmb_sync_params(kmb_handle* h, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h->P || !h->PB) return fail("kmb_sync_params: arenas are not bound");
   HIPCHK(kmb_cast_f32_bf16_launch(h->P, h->PB, h->arena, s));
+  h->mirror_version++;
   // zero rows [V, Vpad) of the tied matrix mirror; padded image weight [d, Fpad]
   HIPCHK(hipMemsetAsync(h->PB + h->shared + (size_t)h->V * h->d, 0, (size_t)(h->Vpad - h->V) * h->d * sizeof(bf16_t), s));
   HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, s));
@@ -1103,7 +1107,7 @@ static int forward_impl(kmb_handle* h, const kmb_batch* batch, const kmb_pretrai
   if (need > h->ws_bytes) return fail("kmb_forward: workspace too small (%zu > %zu bytes)", need, h->ws_bytes);
   layout_train(h, h->ws, h->ws_bytes, bt.B, bt.S, bt.T, bt.n_features, true);
   if (!h->fp32 && h->small_floats > 1024) { g_small_slab = h->small_slab; g_small_floats = h->small_floats; }
-  h->gen.active = false;
+  h->gen.active = false; h->gen.packed_at = nullptr;   // the activations of this forward overwrite the generation workspace
   const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = B * S, Md = B * T;
   h->bt = bt; h->Me = Me; h->Md = Md; h->Ntot = bt.n_features;
   h->fwd_train = train != 0; h->have_fwd = false; h->have_hdec = false; h->have_bwd = false;
@@ -1670,6 +1674,7 @@ int kmb_adamw_step(kmb_handle* h, const KmbAdamW* hp, int64_t offset, int64_t co
   if (offset < 0 || count < 0 || (size_t)(offset + count) > h->arena) return fail("kmb_adamw_step: range out of the arena");
   if (offset & 7) return fail("kmb_adamw_step: offset must be a multiple of 8 elements");
   HIPCHK(kmb_adamw_launch(h->P + offset, h->G + offset, h->M1 + offset, h->M2 + offset, h->PB + offset, (size_t)count, *hp, s));
+  h->mirror_version++;
   // the padded image-weight mirror lives outside the flat mirror
   const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
   if ((size_t)offset < iw1 && (size_t)(offset + count) > iw0)
@@ -1735,6 +1740,7 @@ int comm_ready(const kmb_handle* h, const char* who) {
 int adamw_range(kmb_handle* h, const KmbAdamW& hp, size_t off, size_t cnt, hipStream_t s) {
   if (!h->M1 || !h->M2) return fail("fused optimizer step: the moment arenas are not bound");
   HIPCHK(kmb_adamw_launch(h->P + off, h->G + off, h->M1 + off, h->M2 + off, h->PB + off, cnt, hp, s));
+  h->mirror_version++;
   const size_t iw0 = h->img_w, iw1 = h->img_w + (size_t)h->d * h->Fin;
   if (off < iw1 && off + cnt > iw0)
     HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, s));
@@ -1837,6 +1843,7 @@ int kmb_allreduce_grads(kmb_handle* h, const kmb_allreduce_opts* opts, void* com
       NCCLCHK(ncclAllGather(h->P + mine, h->P + pc.off, shard, ncclFloat, h->comm, cs));           // updated fp32 masters
       if (W > 1) {   // the other ranks' shards of the bf16 mirror (this rank's was written by the optimizer kernel)
         HIPCHK(kmb_cast_f32_bf16_launch(h->P + pc.off, h->PB + pc.off, pc.cnt, cs));
+        h->mirror_version++;
         if (pl.repad_piece)
           HIPCHK(kmb_cast_rows_launch(h->pf(h->img_w), h->Fin, h->imgw_pad, h->Fpad, h->d, h->Fin, cs));
         h->moments_sharded = true;   // exp_avg / exp_avg_sq are current on the owning rank's shard only
@@ -1980,7 +1987,9 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
     gm.out_bf16 = G.ckv[0]; gm.ld_out_bf16 = Ld * 2 * d;
     KCHK(run_gemm(gm, s));
   }
-  if (!G.wp.empty()) {   // fragment-order copies of the decoder weights for the fused decode blocks, one launch per 48
+  // (skipped when the copies of the last kmb_gen_begin are still there: same place in the workspace, the bf16 mirror unchanged since,
+  //  no training forward in between -- that one re-uses the workspace and clears packed_at)
+  if (!G.wp.empty() && !(G.packed_at == G.wp[0] && G.packed_version == h->mirror_version)) {   // fragment-order copies of the decoder weights for the fused decode blocks, one launch per 48
     std::vector<const bf16_t*> src; std::vector<bf16_t*> dst; std::vector<int> ld, nn, kk;
     for (int l = 0; l < Ld; ++l) {
       const LayerP& L = h->dec[l];
@@ -1994,6 +2003,7 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
       const int n = (int)std::min<size_t>(48, src.size() - i0);
       HIPCHK(kmb_decode_pack_launch(src.data() + i0, ld.data() + i0, nn.data() + i0, kk.data() + i0, dst.data() + i0, n, s));
     }
+    G.packed_at = G.wp[0]; G.packed_version = h->mirror_version;
   }
   // beam row -> batch item, written on the device: a host table needed a copy and a stream synchronisation here, and the
   // host then sat out the encoder (1.1 ms at batch 64) instead of queueing the first decode steps behind it

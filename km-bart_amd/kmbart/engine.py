@@ -144,6 +144,9 @@ class Engine:
         instead of whatever the allocator's block happened to hold.  (torch.empty is the product behaviour.)"""
         if self.workspace is not None and os.environ.get("KMB_POISON") == "1":
             self.workspace.fill_(0xFF)
+            # (re-binding tells the library that nothing it left in the workspace -- e.g. the packed decoder weights of the last
+            #  generate -- is there any more)
+            check(self.lib.kmb_bind_workspace(self.h, ptr(self.workspace), self.workspace.numel()))
 
     def _batch(self, input_ids, image_features, attention_mask, decoder_input_ids, decoder_attention_mask, labels):
         dev = self.device
