@@ -601,20 +601,26 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
         dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, frag_rows(Vs, j, kk, r, g), dp[j], 0, 0, 0);
       }
     }
+    // P and dS go to LDS TRANSPOSED ([key][query]): a lane holds one key (r) and four consecutive query rows (4 g ..), i.e. eight
+    // contiguous bytes of the transposed image -- 8 stores of 8 bytes per lane where the [query][key] image took 32 of 2 bytes -- and
+    // the readers below swap roles (the operand that read rows reads columns and vice versa: same fragments, same bits)
+    const float lse4[4] = {lse_s[wave * 16 + g * 4], lse_s[wave * 16 + g * 4 + 1], lse_s[wave * 16 + g * 4 + 2], lse_s[wave * 16 + g * 4 + 3]};
+    const float del4[4] = {del_s[wave * 16 + g * 4], del_s[wave * 16 + g * 4 + 1], del_s[wave * 16 + g * 4 + 2], del_s[wave * 16 + g * 4 + 3]};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = j * 16 + r;
       const bool kv = key < p.Tk && key_on[j];
+      float pv[4], ds[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int lrow = wave * 16 + g * 4 + q;
         const bool ok = kv && lrow < p.Tq && (!p.causal || key <= lrow);
-        const float lse = lse_s[lrow];
-        const float pv = (ok && lse != -INFINITY) ? __expf(s4[j][q] - lse) : 0.f;
-        const float ds = pv * (dp[j][q] - del_s[lrow]);
-        *reinterpret_cast<bf16_t*>(Ps + elem_off(lrow, j * 16 + r)) = f2bf(pv);
-        *reinterpret_cast<bf16_t*>(dSs + elem_off(lrow, j * 16 + r)) = f2bf(ds);
+        pv[q] = (ok && lse4[q] != -INFINITY) ? __expf(s4[j][q] - lse4[q]) : 0.f;
+        ds[q] = pv[q] * (dp[j][q] - del4[q]);
       }
+      const int off = elem_off(key, wave * 16 + g * 4);
+      *reinterpret_cast<uint2*>(Ps + off) = uint2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+      *reinterpret_cast<uint2*>(dSs + off) = uint2{pack2bf(ds[0], ds[1]), pack2bf(ds[2], ds[3])};
     }
     __syncthreads();
     // ---- dQ^T, dV^T, dK^T tiles: lane (r, g) holds row r of this wave's 16 and the columns 16 j + 4 g .. + 3 ----
@@ -623,9 +629,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     for (int j = 0; j < 4; ++j) { dq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 dsf = frag_rows(dSs, wave, kk, r, g);
-      const bf16x8 ptf = frag_cols(Ps, wave, kk, r, g);
-      const bf16x8 dstf = frag_cols(dSs, wave, kk, r, g);
+      const bf16x8 dsf = frag_cols(dSs, wave, kk, r, g);    // rows = this wave's query rows (image columns), k = keys (image rows)
+      const bf16x8 ptf = frag_rows(Ps, wave, kk, r, g);     // rows = this wave's keys (image rows), k = query rows
+      const bf16x8 dstf = frag_rows(dSs, wave, kk, r, g);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Ks, j, kk, r, g), dsf, dq[j], 0, 0, 0);

@@ -34,7 +34,8 @@ for name, Tq, Tk, causal in (("enc self", 64, 64, 0), ("dec self", 32, 32, 1), (
     a.dQ, a.dK, a.dV = ptr(dqkv[:, :d]), ptr(dkv[:, d:2 * d]), ptr(dkv[:, 2 * d:])
     a.lddq, a.lddk, a.lddv = 3 * d, 3 * d, 3 * d
     a.dq_scale = 0.125
-    a.dq_colsum, a.dk_colsum, a.dv_colsum, a.ld_colsum = ptr(cs[:, :d]), ptr(cs[:, d:2 * d]), ptr(cs[:, 2 * d:]), 3 * d
+    if not os.environ.get("NOCOLSUM"):   # ablation: without the bias-gradient column sums (48 DPP chains + a barrier per item)
+        a.dq_colsum, a.dk_colsum, a.dv_colsum, a.ld_colsum = ptr(cs[:, :d]), ptr(cs[:, d:2 * d]), ptr(cs[:, 2 * d:]), 3 * d
     for _ in range(3):
         check(lib.kmb_op_attn_bwd(C.byref(a), stream()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
