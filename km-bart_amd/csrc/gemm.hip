@@ -73,9 +73,32 @@ extern "C" int kmb_debug_set_stamps(void* p) {
 #define KMB_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
 
-// The L2 touch of the persistent kernels: a load whose result nobody reads, into v255 -- a register their kernels are compiled
-// not to allocate (__attribute__((amdgpu_num_vgpr(255)))), so no value can ever live where a touch in flight will land.
-#define KMB_L2_TOUCH(voff, sbase) asm volatile("global_load_dword v255, %0, %1" ::"v"(voff), "s"(sbase) : "memory", "v255")
+// The L2 touch of the persistent kernels: a load whose result nobody reads.  Round 5: it is a 4-byte LDS-DMA into a dummy LDS word
+// of the issuing wave (`lds`: 256 bytes that nothing reads while a touch can be in flight -- the wave's epilogue staging image,
+// idle during the K loop) -- NO register destination.  Rounds 2-4 gave it a register: "=v" (a fresh value per touch: the allocator
+// reused the register while the load was in flight -- wrong bits), one "+v" web (split under pressure: memory fault), then v255 with
+// __attribute__((amdgpu_num_vgpr(255))), on the belief that the allocator then never hands out v255.  It does (found by grepping the ISA of every kernel with a touch for other uses of v255,
+// round 5: the eight-wave and the two-workgroup kernels are compiled with all 256 registers, v255 among them -- the attribute does not
+// cap a kernel whose budget waves_per_eu fixes); what kept the results right was the ORDER of the counted waits (a touch is older
+// than the pieces the next wait leaves outstanding), not the register.  A touch still counts as one vector-memory operation, so the
+// kernels' counted waits are unchanged; results are bit-identical (tests/test_gemm_variants_gpu.py).
+// (inline asm, not __builtin_amdgcn_global_load_lds: the builtin spends eight scalar instructions per touch on turning the generic
+//  LDS pointer into M0 -- measured -0.5...-1 % of a step; here M0 is saved, set from a 32-bit LDS address kept in a scalar
+//  register and restored inside ONE statement, as the guide's glds16_asm recipe does.  `lds_u32`: kmb_lds_addr(ptr), wave-uniform.)
+#define KMB_L2_TOUCH(voff, sbase, lds_u32)                                                                                    \
+  do {                                                                                                                        \
+    unsigned kmb_m0_keep_;                                                                                                    \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"       \
+                 : "=&s"(kmb_m0_keep_) : "v"(voff), "s"(sbase), "s"(lds_u32) : "memory");                                     \
+  } while (0)
+__device__ __forceinline__ unsigned kmb_lds_addr(const void* p) {   // the 32-bit LDS address of a (generic) pointer into shared memory, in a scalar register
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
+}
+// gemm_lean.hip keeps the register form: its LDS is full WHILE a touch is in flight (the cross-tile touch lands during the epilogue,
+// which owns the staging images -- the LDS form corrupted its outputs, caught by the bitwise test), and its forward kernels use 242-244
+// registers, so v255 is free.  That is a property of the compiled code, not of the source: tests/test_cabi_cpu.py::
+// test_lean_gemm_never_allocates_v255 compiles gemm_lean.hip to ISA and fails if any instruction but the touch names v255.
+#define KMB_L2_TOUCH_V255(voff, sbase) asm volatile("global_load_dword v255, %0, %1" ::"v"(voff), "s"(sbase) : "memory", "v255")
 
 namespace {
 
@@ -1434,7 +1457,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 // an 18.8 us K loop -- and the second wave halves exactly that part.  The K loop is v8's (same fragments, same
 // accumulation order: bit-identical), MFMA-paced either way.
 template <bool A_KC, bool B_KC, int BNT, int NW = 4>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) __attribute__((amdgpu_num_vgpr(255)))
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) __attribute__((amdgpu_num_vgpr(255)))   // (255: the allocation the round-4 kernels were tuned with; it does NOT reserve v255, see KMB_L2_TOUCH)
 void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   static_assert(NW == 4 || (NW == 8 && (BNT == 256 || BNT == 192)), "eight waves: 256 x 256 and 256 x 192 tiles only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1505,6 +1528,10 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
     }
   };
   int* const next_slot = reinterpret_cast<int*>(smem + 2 * STG);   // word 0 of wave 0's epilogue staging (idle in the K loop)
+  // the wave that issues the L2 touches: the LAST one (wave 0 also hands out tiles; the touch costs its wave five scalar instructions per K
+  // step since round 5); its landing words: 256 bytes of its own staging image (KMB_L2_TOUCH)
+  constexpr int PFW = NW - 1;
+  const unsigned touch_lds = kmb_lds_addr(smem + 2 * STG + PFW * (WCOLS > 64 ? EPW_BYTES : EPW_BYTES / 2) + 2048);
   uint32_t fetched = 0u;
   // dyn_first (the GPU is shared with a communication kernel: kmb_gemm_shared_device): the first tile comes from the
   // counter too, so a workgroup that is placed late finds nothing left and exits instead of holding the launch open
@@ -1552,7 +1579,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   // Each of them therefore touches ITS share of the panel's rows (256 / tiles_n rows = one 128-byte line each per K
   // step, ONE load instruction of wave 0) KMB_PFD steps ahead of the DMA cursor: the lines are in the XCD's L2 when the
   // DMAs of all sharers ask for them.  The load's result is never used; it stays outstanding across the stage wait
-  // (vmcnt(1) instead of 0 for wave 0) and must only be complete one step later (see the K loop for why its destination
+  // (vmcnt(1) instead of 0 for the touching wave) and must only be complete one step later (see the K loop for why its destination
   // is one register web for the whole kernel).
 #ifndef KMB_V11_PREFETCH
 #define KMB_V11_PREFETCH 1
@@ -1747,12 +1774,12 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
 #endif
 
   set_dma_tile(tile_d);
-  if (PF_ON && pf_rt && wave == 0) {   // steps 2 .. PFD + 1 of the first tile (issued before, so complete before, the stage pieces)
+  if (PF_ON && pf_rt && wave == PFW) {   // steps 2 .. PFD + 1 of the first tile (issued before, so complete before, the stage pieces)
 #pragma unroll
     for (int i = 2; i < 2 + KMB_PFD; ++i) {
       if (i < nt) {
         const char* pbase = uniform_ptr(gA_d + (size_t)i * stepA);
-        KMB_L2_TOUCH(pf_off, pbase);
+        KMB_L2_TOUCH(pf_off, pbase, touch_lds);   // one wave only: a word of its own staging image
       }
     }
   }
@@ -1848,23 +1875,19 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
       advance_cursor();
       if (PF_ON) {
         // The L2 touch is the YOUNGEST memory operation at this step's stage wait (all pieces of the stage are out), so
-        // that wait is vmcnt(1) for wave 0 and the touch -- an HBM miss by design -- has until the NEXT step's wait to
+        // that wait is vmcnt(1) for the touching wave (the last one) and the touch -- an HBM miss by design -- has until the NEXT step's wait to
         // land.  (Issued as the oldest operation of the window behind a plain vmcnt(0) it sat in front of the stage's
         // pieces in the in-order return queue and the whole gain was gone: 42.2 vs 39.5 ms of in-step GEMM time.)
-        // Its destination is v255, which the kernel is compiled NOT to allocate (amdgpu_num_vgpr(255), KMB_L2_TOUCH): a touch
-        // still in flight can never land in a register that has been handed to another value.  (Round 2's form -- "=v", a fresh
-        // value per touch -- allowed exactly that: wrong bits in the eight-wave kernel; round 3's -- one "+v" register web for the
-        // whole kernel -- held in the product builds but not under more register pressure: a memory fault in the stamp build, wrong
-        // results in an experimental build of gemm_lean.hip in round 4.)
-        // No touch in a tile's last K step: that step's wait is vmcnt(0), nothing is in flight across the epilogue,
-        // where the register may be spilled and reused.
+        // It has no register destination (KMB_L2_TOUCH: a 4-byte LDS-DMA into a word of wave 0's staging image, idle in the K loop).
+        // No touch in a tile's last K step: that step's wait is vmcnt(0), nothing is in flight across the epilogue, which
+        // writes that staging image.
         const int ps = td + KMB_PFD;   // td: the step the next fetch of this workgroup asks for
         const bool in_tile = ps < nt;
-        pf_pending = pf_rt && wave == 0 && t + 1 < nt && (in_tile || (pfn_ok && ps - nt < nt));
+        pf_pending = pf_rt && wave == PFW && t + 1 < nt && (in_tile || (pfn_ok && ps - nt < nt));
         if (pf_pending) {
           const char* pbase = uniform_ptr(in_tile ? gA_d + (size_t)KMB_PFD * stepA : pfn_base + (size_t)(ps - nt) * stepA);
           const uint32_t poff = in_tile ? pf_off : pfn_off;
-          KMB_L2_TOUCH(poff, pbase);
+          KMB_L2_TOUCH(poff, pbase, touch_lds);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

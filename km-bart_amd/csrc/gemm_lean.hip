@@ -36,7 +36,7 @@ __device__ __forceinline__ const char* ln_uniform(const char* ptr) {
 }
 
 template <bool B_KC, int EC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) __attribute__((amdgpu_num_vgpr(255))) void gemm_kernel_lean(const KmbGemm p, uint32_t* sched, int dyn_first) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel_lean(const KmbGemm p, uint32_t* sched, int dyn_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) __a
   // an L2 round trip, not a memory one, and inside a step A was just streamed out by the previous kernel.  The workgroups that
   // share a row panel (the tiles of one tm: consecutive tiles, side by side on one XCD) each touch THEIR share of its rows
   // LN_PFD steps ahead of the DMA cursor, one load instruction per wave right behind a stage's pieces; the step's wait leaves it
-  // outstanding (vmcnt 1), so it has a whole step to land.  Its result is never used; its destination is v255, which the kernel
-  // does not allocate (KMB_L2_TOUCH, gemm.hip).  Not for the data-gradient layout's B (the weights: L2 / Infinity Cache residents).
+  // outstanding (vmcnt 1), so it has a whole step to land.  Its result is never used; its destination is v255, which these
+  // kernels do not allocate -- checked on the compiled ISA (KMB_L2_TOUCH_V255, gemm.hip).  Not for the data-gradient layout's B (the weights: L2 / Infinity Cache residents).
   constexpr int LN_PFD = 2;
   const int sharers = col_blocks ? CB : tiles_n;
   const int pf_share = (256 + sharers - 1) / sharers;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) __a
       row += nx ? pf_rows_nx : pf_rows;
       row = row < 256 ? row : 255;
       const uint32_t voff = (uint32_t)row * (uint32_t)p.lda * 2u;
-      KMB_L2_TOUCH(voff, sbase);
+      KMB_L2_TOUCH_V255(voff, sbase);
     }
     gA_d = ln_uniform(gA_d + BK * 2);
     gB_d = ln_uniform(gB_d + stepB);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) __a
   // ahead of the DMA cursor -- one load instruction per wave behind every stage's pieces, a 128-byte line serves two steps, the
   // step's parity picks which half of the wave's rows it touches -- and the pieces of all sharers then hit L2.  The load's result
   // is never used; every wait leaves it outstanding (vmcnt 8 = the previous touch, a stage's six pieces, this touch) so that it
-  // has three steps to land; its destination is v255, which the kernel does not allocate (KMB_L2_TOUCH, gemm.hip).
+  // has three steps to land; it has no register destination: it lands in a dummy LDS word behind the stages (KMB_L2_TOUCH, gemm.hip).
   constexpr int PR_PFD = 4;
   const int sharers = col_blocks ? CB : tiles_n;
   int pf_share = (PR_BM + sharers - 1) / sharers;
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) __a
     gA_nx = pr_uniform(reinterpret_cast<const char*>(p.A) + (size_t)tm * PR_BM * p.lda * 2);
     pf_rows_nx = (col_blocks ? tn % CB : tn) * pf_share;
   };
+  const unsigned touch_lds = kmb_lds_addr(smem + PR_LDS + wave * 256);
   auto touch = [&]() {   // behind a stage's pieces (td = the step the NEXT fetch asks for)
     const int ps = td - 1 + PR_PFD;                        // the step whose line is touched (with its odd neighbour's)
     const bool nx = ps >= nt;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) __a
     row = row < PR_BM ? row : PR_BM - 1;
     const uint32_t voff = (uint32_t)row * (uint32_t)p.lda * 2u;
 #if !defined(KMB_PR_NODMA) && !defined(KMB_PR_NOTOUCH)
-    KMB_L2_TOUCH(voff, sbase);
+    KMB_L2_TOUCH(voff, sbase, touch_lds);   // landing words behind the three stages (never read)
 #else
     asm volatile("" ::"v"(voff), "s"(sbase));
 #endif
@@ -349,11 +350,11 @@ hipError_t kmb_gemm_pair_launch(const KmbGemm& p, hipStream_t stream) {
   case E: {                                                                                                                   \
     static bool attr = false;                                                                                                 \
     if (!attr) {                                                                                                              \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_pair<E>, hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS); \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_pair<E>, hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS + 1024); \
       if (e != hipSuccess) return e;                                                                                          \
       attr = true;                                                                                                            \
     }                                                                                                                         \
-    hipLaunchKernelGGL((gemm_kernel_pair<E>), grid, dim3(256), PR_LDS, stream, p);                                             \
+    hipLaunchKernelGGL((gemm_kernel_pair<E>), grid, dim3(256), PR_LDS + 1024, stream, p);                                             \
     break;                                                                                                                    \
   }
   switch (pr_class(p)) {

@@ -141,3 +141,38 @@ def test_no_cpu_fallback():
         if f.endswith("bench.py"):
             continue  # bench.py may use the oracle for its cpu_baseline leg only
         assert "oracle" not in text.replace("# oracle", ""), "product file %s mentions the oracle" % f
+
+
+def test_lean_gemm_never_allocates_v255(tmp_path):
+    """csrc/gemm_lean.hip's L2 touch is a load into v255 whose result nobody reads and which stays in flight across the tile's
+    epilogue (KMB_L2_TOUCH_V255, csrc/gemm.hip).  That is only sound while the register allocator never hands v255 to a value:
+    a property of the COMPILED code, which no attribute guarantees (round 5 found the other persistent kernels compiled with all
+    256 registers despite amdgpu_num_vgpr(255); they now touch through LDS-DMA).  So: compile the file to ISA (no GPU needed)
+    and require that inside every kernel that contains a touch no other instruction names v255, alone or as the top of a range."""
+    import subprocess
+    src = os.path.join(ROOT, "km-bart_amd", "csrc", "gemm_lean.hip")
+    out = str(tmp_path / "gemm_lean.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-I" + os.path.join(ROOT, "km-bart_amd", "csrc"), "-I" + os.path.join(ROOT, "include")]
+    subprocess.check_call(["hipcc", "-x", "hip"] + flags + ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+    use = re.compile(r"\bv255\b|v\[\d+:255\]")
+    name, touches, others, kernels = None, 0, [], 0
+    for line in open(out):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name, touches, others = m.group(1), 0, []
+            continue
+        if name is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            if touches:
+                kernels += 1
+                assert not others, "%s: v255 is used by the allocator (%d instructions, e.g. %s)" % (name, len(others), others[0].strip())
+            name = None
+            continue
+        code = line.split(";")[0]
+        if "global_load_dword v255" in code:
+            touches += 1
+        elif use.search(code):
+            others.append(code)
+    assert kernels >= 6, "expected the lean GEMM kernels with their touches, found %d" % kernels
