@@ -113,6 +113,8 @@ if __name__ == "__main__":
             # for its timing-only builds); KMB_GEMM_VARIANT=10 KMB_LIB_PATH=lib/libkmbart_hip_rolesplit.so selects it
             defs = list(defs) + ["KMB_WITH_ROLESPLIT"]
             srcs, extra = ("gemm.hip",), ("gemm_rolesplit.hip",)
+        if any(d.startswith("KMB_DEC_") for d in defs):   # decode-block A/B builds
+            srcs = ("decode.hip",)
         if any(d.startswith("KMB_PR_") for d in defs):   # ... of the two-workgroups-per-CU kernel
             srcs = ("gemm_pair.hip",)
         print(build_variant(sys.argv[i + 1], defs, srcs, extra))

@@ -63,6 +63,13 @@ extern "C" int kmb_debug_set_decode_stamps(void* p) {
 #define DLSTAMP(i)
 #endif
 
+#ifndef KMB_DEC_SELF_VU
+#define KMB_DEC_SELF_VU 10   // cached values of a row prefetched by the self-attention block.  20 (every value of a max_length 20 search in
+                             // flight before the LayerNorm; 484 registers, no spill) measures SLOWER: 10.13-10.21 ms per generate against
+                             // 10.01-10.03 (tools/gen_ab.sh, build.py --variant vu20 KMB_DEC_SELF_VU=20): 20 more requests per lane in
+                             // front of the in-order return path delay the keys the scores wait for
+#endif
+
 namespace {
 
 constexpr int RT = 16;      // rows per workgroup
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const KmbDecodeBlock p
   constexpr int NTW = SELF ? 3 : 1;          // 16-column tiles per wave
   constexpr int QW = SELF ? 3 * HD : HD;     // projected columns of the head
   constexpr int QS = (QW + 8) * 2;           // LDS row stride of the projected tile
-  constexpr int KU = 5, VU = 10;
+  constexpr int KU = 5, VU = SELF ? KMB_DEC_SELF_VU : 10;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int h, rt;
   if (!unit_of(p.H, (p.R + RT - 1) / RT, h, rt)) return;
