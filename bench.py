@@ -136,7 +136,7 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
                 if rest and int(rest[0]):
                     extra += M * N * 2                                   # the residual / other gradient term the epilogue adds
                 alg_bytes += 2.0 * (M * K + N * K) + out_b * M * N + extra
-                alg_n += 1
+                alg_n += 1.0 / int(rest[1]) if len(rest) > 1 else 1   # a problem of a grouped weight-gradient launch: 1 / n of a launch
                 last_us += float(us)
                 last_fl += 2.0 * M * N * K
                 if act == 5:

@@ -106,7 +106,7 @@ if __name__ == "__main__":
         i = sys.argv.index("--variant")
         defs = sys.argv[i + 2:]
         # KMB_DIAG (csrc/diag.h) switches the A/B environment knobs and ablation bits on in every file that has them
-        srcs = ("gemm.hip", "gemm_lean.hip", "engine.cpp", "attention.hip") if "KMB_DIAG" in defs else ("gemm.hip",)
+        srcs = ("gemm.hip", "gemm_lean.hip", "engine.cpp", "attention.hip", "optim.hip") if "KMB_DIAG" in defs else ("gemm.hip",)
         extra = ()
         if sys.argv[i + 1].startswith("rolesplit") or any(d.startswith("KMB_RS_") for d in defs):
             # the role-split GEMM (variant 10, tools/experiments/gemm_rolesplit.hip): `--variant rolesplit` (+ KMB_RS_NOEPI ...

@@ -41,6 +41,12 @@ int kmb_op_gemm(const KmbGemm* p, void* stream) {
   if (why) return kmb_set_error(why);
   return hipfail(kmb_gemm_launch(*p, (hipStream_t)stream), "gemm");
 }
+int kmb_op_gemm_group(const KmbGemm* probs, int32_t n, void* stream) {
+  if (!probs) return kmb_set_error("kmb_op_gemm_group: null problem list");
+  const char* why = kmb_gemm_group_check(probs, n);
+  if (why) return kmb_set_error(why);
+  return hipfail(kmb_gemm_group_launch(probs, n, (hipStream_t)stream), "gemm_group");
+}
 int kmb_op_gemm_allrows(const KmbGemm* p, void* stream) {
   const char* why = kmb_gemm_check(*p);
   if (!why) why = kmb_gemm_allrows_check(*p);

@@ -150,6 +150,8 @@ struct kmb_handle {
   // stream too, so the partials need the same lifetime as the gradient buffers above
   struct BwdBufs { bf16_t *dz[3], *dsub[3], *du, *dqkv, *dcq, *dckv; float* parts[6]; } bb[2];
   hipStream_t side = nullptr; bool side_on = true;
+  // grouped weight gradients (wgrad_side / wgrad_flush): a layer's problems wait here until the layer's last one is known
+  std::vector<KmbGemm> wg_pending; bool wg_group = false;
   std::vector<hipEvent_t> ring; size_t ring_pos = 0;
   std::vector<hipEvent_t> layer_done;   // recorded on the side stream
   hipEvent_t head_wgrad_done = nullptr; bool head_wgrad_pending = false;
@@ -259,7 +261,9 @@ void add_ffn(kmb_handle* h, const std::string& p, int F, LayerP& L) {
 struct GemmProfiler {
   bool on = false;
   std::vector<hipEvent_t> ev;        // pairs
-  struct Rec { int variant; double flops; int M, N, K, split, act, res; };
+  // pair: the event pair that brackets the launch; share: this record's part of that launch's time (1 for a launch of its own; a
+  // grouped weight-gradient launch has one record per problem, time split by FLOPs, `launch` 1 on the first of them only)
+  struct Rec { int variant; double flops; int M, N, K, split, act, res; size_t pair = 0; float share = 1.f; int launch = 1; int group_n = 1; };
   std::vector<Rec> recs;
   size_t used = 0;
 } g_prof;
@@ -310,8 +314,9 @@ int run_gemm(const KmbGemm& g, hipStream_t s) {
     HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], s));
     HIPCHK(kmb_gemm_launch(g, s));
     HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
+    g_prof.recs.push_back({g.a_kc * 2 + g.b_kc, 2.0 * g.M * g.N * (double)g.K, g.M, g.N, g.K, g.split_k, g.act, g.residual != nullptr ? 1 : 0,
+                           g_prof.used / 2, 1.f, 1, 1});
     g_prof.used += 2;
-    g_prof.recs.push_back({g.a_kc * 2 + g.b_kc, 2.0 * g.M * g.N * (double)g.K, g.M, g.N, g.K, g.split_k, g.act, g.residual != nullptr ? 1 : 0});
     return 0;
   }
   HIPCHK(kmb_gemm_launch(g, s));
@@ -426,7 +431,65 @@ int ensure_side(kmb_handle* h) {
 // Weight gradients are off the critical path (nothing in backward reads them): enqueue them on the side stream
 // behind an event that marks "everything the main stream has produced so far".  Two different GEMMs in flight are
 // out of phase, so one's output-store burst overlaps the other's matrix work and partial waves get filled.
+// Grouped weight gradients (csrc/gemm.hip, gemm_group_wgrad_kernel).  With few tokens a weight gradient has 36-144 output
+// tiles and a short reduction: alone it needs a 3- to 7-fold split-K plus a slab reduction to cover the chip -- 63 + 91
+// launches a step on the side stream, each GEMM behind an event pair.  A layer's four to six weight gradients together are
+// 432-504 tiles: ONE launch, whole reductions, no slabs (16 launches a step).  wgrad_side() parks eligible problems in
+// h->wg_pending while h->wg_group is set (kmb_backward: token count under the rule there); wgrad_flush() sends them out
+// behind a marker of the caller's stream -- at the end of every layer, before that layer's completion events are recorded
+// on the side stream.  The operands are per-layer buffers that stay valid until then (the layer_done rule).
+// Measured (same box, alternating processes, profiles/r05_grouped_weight_gradients.md): the step gets faster for up to 48
+// samples (b = 8: 5.89 -> 5.69 ms, 16: 5.54 -> 5.26, 32: 5.77 -> 5.59, 48: 6.66 -> 6.56) and slower from 64 on (7.25 -> 7.31,
+// b = 128: 9.82 -> 10.10): the side stream's busy time falls from 3.1 to 1.8 ms at b = 64, but a launch that occupies every
+// workgroup slot of the chip for 85-160 us holds up the caller's stream more than seven-fold split-K launches of 252
+// workgroups did -- and without ANY weight gradient that step still takes 6.33 ms (diagnostic KMB_SKIP_WGRAD), without the
+// optimizer 6.44: at that size the step is the caller's stream plus the 0.78 ms of AdamW traffic.
+int wgrad_flush(kmb_handle* h, hipStream_t sA) {
+  if (h->wg_pending.empty()) return 0;
+  std::vector<KmbGemm> ps;
+  ps.swap(h->wg_pending);
+  const bool on_side = h->side_on && h->side != nullptr;
+  hipStream_t s = on_side ? h->side : sA;
+  if (on_side) {
+    hipEvent_t e = h->next_event();
+    HIPCHK(hipEventRecord(e, sA));
+    HIPCHK(hipStreamWaitEvent(h->side, e, 0));
+  }
+  if (ps.size() == 1) return run_wgrad(h, ps[0], s, h->slab, h->slab_floats);   // nothing to group with
+  if (g_prof.on) {
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+      const size_t old = g_prof.ev.size();
+      g_prof.ev.resize(old + 512);
+      for (size_t i = old; i < g_prof.ev.size(); ++i) HIPCHK(hipEventCreate(&g_prof.ev[i]));
+    }
+    HIPCHK(hipEventRecord(g_prof.ev[g_prof.used], s));
+  }
+  HIPCHK(kmb_gemm_group_launch(ps.data(), (int)ps.size(), s));
+  if (g_prof.on) {
+    HIPCHK(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
+    double total = 0.0;
+    for (const KmbGemm& g : ps) total += 2.0 * g.M * g.N * (double)g.K;
+    for (size_t i = 0; i < ps.size(); ++i) {
+      const KmbGemm& g = ps[i];
+      const double fl = 2.0 * g.M * g.N * (double)g.K;
+      g_prof.recs.push_back({0, fl, g.M, g.N, g.K, 0, 0, 0, g_prof.used / 2, (float)(fl / total), i == 0 ? 1 : 0, (int)ps.size()});
+    }
+    g_prof.used += 2;
+  }
+  return 0;
+}
+
 int wgrad_side(kmb_handle* h, const KmbGemm& g, hipStream_t sA) {
+  if (h->wg_group && !g_f32 && kmb_gemm_group_check(&g, 1) == nullptr) {
+    h->wg_pending.push_back(g);
+    if ((int)h->wg_pending.size() == KMB_GEMM_GROUP_MAX) return wgrad_flush(h, sA);
+    return 0;
+  }
+  KCHK(wgrad_flush(h, sA));   // (keeps the side stream's order: an ineligible problem goes out behind the parked ones)
+  // KMB_SKIP_WGRAD=1 (diagnostic build, TIMING ONLY -- the gradients are wrong): no weight-gradient GEMM, no event.  What
+  // the step costs without them bounds what any regrouping of the side stream's work can buy (tools/step_ab.sh)
+  static const bool skip = KMB_DIAG_ENV("KMB_SKIP_WGRAD") != nullptr;
+  if (skip) return 0;
   if (!h->side_on || h->side == nullptr) return run_wgrad(h, g, sA, h->slab, h->slab_floats);
   hipEvent_t e = h->next_event();
   HIPCHK(hipEventRecord(e, sA));
@@ -1409,6 +1472,18 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
   if (!h->have_fwd) return fail("kmb_backward: no forward with need_grad=1 to differentiate");
   h->have_fwd = false;
   h->have_bwd = true;
+  // grouped weight gradients (wgrad_flush) for short token reductions; KMB_WGRAD_GROUP=0: every weight gradient its own
+  // (split-K) launch, as for long ones
+  struct GroupScope {
+    kmb_handle* h;
+    ~GroupScope() { h->wg_group = false; h->wg_pending.clear(); }
+  } group_scope{h};
+  {
+    static const bool group_ok = !(getenv("KMB_WGRAD_GROUP") && getenv("KMB_WGRAD_GROUP")[0] == '0');
+    static const int group_tokens = KMB_DIAG_ENV("KMB_WGRAD_GROUP_TOKENS") ? atoi(KMB_DIAG_ENV("KMB_WGRAD_GROUP_TOKENS")) : 3072;   // <= 48 samples x 64 tokens
+    h->wg_group = group_ok && !h->fp32 && (h->Me > h->Md ? h->Me : h->Md) <= group_tokens;
+    h->wg_pending.clear();
+  }
   const kmb_batch& bt = h->bt;
   const int d = h->d, B = bt.B, S = bt.S, T = bt.T, Me = h->Me, Md = h->Md;
   const bool tr = h->fwd_train;
@@ -1440,6 +1515,7 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
   // the bucket of layer c is complete when BOTH streams are past this point: record its event on the side stream
   // behind a marker of the main stream, so the main stream never waits here
   auto layer_end = [&](int c, int bucket) -> int {
+    KCHK(wgrad_flush(h, s));   // the layer's parked weight gradients go out as one launch (grouped path)
     if (side) {
       hipEvent_t e = h->next_event();
       HIPCHK(hipEventRecord(e, s));
@@ -1544,6 +1620,7 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
   HIPCHK(kmb_pos_bwd_launch(h->dz, B, T, d, h->gf(h->dec_pos), h->cfg.extra_pos_embeddings, h->Prows, s));
   // this bucket also holds the cross-attention k | v weights and biases of every decoder layer, whose gradients come from
   // the side stream (the batched weight gradient above, the per-layer bias reducers): complete when BOTH streams are here
+  KCHK(wgrad_flush(h, s));
   if (side) {
     hipEvent_t e = h->next_event();
     HIPCHK(hipEventRecord(e, s));
@@ -1600,6 +1677,7 @@ static int backward_impl(kmb_handle* h, float loss_scale, const float* loss_scal
     HIPCHK(hipMemsetAsync(h->gf(h->img_w), 0, ((size_t)d * h->Fin) * sizeof(float), s));
     HIPCHK(hipMemsetAsync(h->gf(h->img_b), 0, (size_t)d * sizeof(float), s));
   }
+  KCHK(wgrad_flush(h, s));
   if (side) {  // everything the optimizer reads must be ordered behind the side stream's last weight gradient
     hipEvent_t e = h->next_event();
     HIPCHK(hipEventRecord(e, h->side));
@@ -1645,24 +1723,27 @@ int kmb_profile_read(int variant, int64_t* launches, double* total_ms, double* t
   for (size_t i = 0; i < g_prof.recs.size(); ++i) {
     if (g_prof.recs[i].variant != variant) continue;
     float t = 0.f;
-    HIPCHK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
-    HIPCHK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
-    ms += t; fl += g_prof.recs[i].flops; ++n;
+    const size_t pr = g_prof.recs[i].pair;
+    HIPCHK(hipEventSynchronize(g_prof.ev[2 * pr + 1]));
+    HIPCHK(hipEventElapsedTime(&t, g_prof.ev[2 * pr], g_prof.ev[2 * pr + 1]));
+    ms += t * g_prof.recs[i].share; fl += g_prof.recs[i].flops; n += g_prof.recs[i].launch;
   }
   *launches = n; *total_ms = ms; *total_flops = fl;
   return 0;
 }
 
-// one line per GEMM launch of the profiled calls: variant M N K split act microseconds
+// one line per GEMM problem of the profiled calls: variant M N K split act microseconds residual group -- `group` = n for a
+// problem that went out as one of the n of a grouped weight-gradient launch (its microseconds are its FLOP share of that
+// launch), 1 for a launch of its own
 int kmb_profile_dump(const char* path) {
   FILE* f = fopen(path, "w");
   if (!f) return fail("kmb_profile_dump: cannot open %s", path);
   for (size_t i = 0; i < g_prof.recs.size(); ++i) {
     float t = 0.f;
-    HIPCHK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
-    HIPCHK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
     const auto& r = g_prof.recs[i];
-    fprintf(f, "%d %d %d %d %d %d %.3f %d\n", r.variant, r.M, r.N, r.K, r.split, r.act, t * 1e3, r.res);   // res: the epilogue reads a residual operand
+    HIPCHK(hipEventSynchronize(g_prof.ev[2 * r.pair + 1]));
+    HIPCHK(hipEventElapsedTime(&t, g_prof.ev[2 * r.pair], g_prof.ev[2 * r.pair + 1]));
+    fprintf(f, "%d %d %d %d %d %d %.3f %d %d\n", r.variant, r.M, r.N, r.K, r.split, r.act, t * r.share * 1e3, r.res, r.group_n);   // res: the epilogue reads a residual operand
   }
   fclose(f);
   return 0;

@@ -572,9 +572,9 @@ __device__ __forceinline__ void dma_piece_nt(const char* gbase, uint32_t off, ch
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
 }
 
+// One 128x128 output tile (block `block` of `nblocks` of problem p): the body of gemm_kernel_v7 and of the grouped launch below
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void v7_tile(const KmbGemm& p, char* smem, int block, int nblocks) {
   KMB_STAMP(0);
   KMB_STAMP_ID();
   const int tid = threadIdx.x;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
   const int r = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nsl = p.split_k > 1 ? p.split_k : 1;
-  const int bid = (p.tile_order & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bid = (p.tile_order & 1) ? xcd_remap(block, nblocks) : block;
   const int ntl = tiles_n * ((p.M + BM - 1) / BM);
   const bool slice_major = (p.tile_order & 4) != 0 && nsl > 1;   // see split_order_note
   const int tile = slice_major ? bid % ntl : bid / nsl, slice = slice_major ? bid / ntl : bid % nsl;
@@ -721,6 +721,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
   KMB_STAMP(4);
 }
 
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v7_tile<A_KC, B_KC>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+#ifndef KMB_GEMM_DEVICE_ONLY
+// Grouped weight gradients (round 5): ONE launch walks the 128x128 tiles of up to KMB_GEMM_GROUP_MAX independent problems of the
+// weight-gradient layout (dW = dY^T X: both operands token-major), each tile over the WHOLE token reduction -- no K slices,
+// no fp32 slabs, no reduction pass.  For the small batches of the reference's default (64 samples: 2048-4096 tokens) a layer's
+// four to six weight gradients have 36-144 tiles each: alone they need 7-fold split-K to cover the chip (63 GEMMs + 91 slab
+// reductions per step on the side stream, each behind an event pair).  Together they are 432-504 tiles = one round of two
+// workgroups per CU, 16 launches a step.  Used for <= 3072 tokens (kmb_backward's rule; DESIGN.md section 4, round 5: the
+// step gets 1.5-5 % faster at b = 8 .. 48; from b = 64 on a launch that holds every workgroup slot of the chip for 85-160 us
+// delays the caller's stream more than the split-K launches did, and the rule leaves those batches on them).  Blocks of problem k are
+// [first[k], first[k + 1]) with every first[k] a multiple of 8 (the per-XCD tile ranges of xcd_remap stay aligned with the
+// hardware's round-robin; surplus blocks exit).  Same tile body as gemm_kernel_v7: bit-identical to the problem launched alone
+// without split-K.
+struct KmbGemmGroup {
+  int n;
+  int first[KMB_GEMM_GROUP_MAX + 1];
+  int blocks[KMB_GEMM_GROUP_MAX];
+  KmbGemm p[KMB_GEMM_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_group_wgrad_kernel(const KmbGemmGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < KMB_GEMM_GROUP_MAX; ++i)
+    if (i < grp.n && b >= grp.first[i]) k = i;
+  const int local = b - grp.first[k];
+  if (local >= grp.blocks[k]) return;   // padding up to the next multiple of 8
+  v7_tile<false, false>(grp.p[k], smem, local, grp.blocks[k]);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // fragment reads for tiles that are 256 rows (columns) tall (v8)
@@ -2487,6 +2524,49 @@ hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream) {
     attr_set = true;
   }
   hipLaunchKernelGGL(gemm_kernel_allrows, dim3((p.N + VN - 1) / VN), dim3(512), LDS_VOC, stream, p);
+  return hipGetLastError();
+}
+
+// Grouped weight gradients (gemm_group_wgrad_kernel): nullptr if the n problems can go out as one launch
+const char* kmb_gemm_group_check(const KmbGemm* probs, int n) {
+  if (n < 1 || n > KMB_GEMM_GROUP_MAX) return "gemm group: 1 .. KMB_GEMM_GROUP_MAX problems";
+  for (int i = 0; i < n; ++i) {
+    const KmbGemm& p = probs[i];
+    if (const char* why = kmb_gemm_check(p)) return why;
+    if (p.a_kc || p.b_kc) return "gemm group: weight-gradient layout only (both operands token-major)";
+    if ((p.K % BK) || p.K < BK) return "gemm group: the reduction length must be a multiple of 64";
+    if (p.split_k > 1 || p.slab) return "gemm group: no split-K";
+    if (!p.out_f32 || p.out_bf16 || p.act != 0 || p.residual || p.aux || p.preact || p.colsum || p.drop_thr16 || p.bias || p.col_scale_n > 0)
+      return "gemm group: plain fp32 output only";
+  }
+  return nullptr;
+}
+
+hipError_t kmb_gemm_group_launch(const KmbGemm* probs, int n, hipStream_t stream) {
+  // (Measured and dropped: an LDS request of 96 KB, which keeps the launch at ONE workgroup per CU so that the other 64 KB
+  // slot of every CU stays free for the caller's stream -- the launch then takes two rounds and the step got 5 % slower at
+  // b = 64, 10 % at b = 128; profiles/r05_grouped_weight_gradients.md.)
+  constexpr int lds_req = LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_group_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  KmbGemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.n = n;
+  int at = 0;
+  for (int i = 0; i < n; ++i) {
+    grp.p[i] = probs[i];
+    grp.p[i].tile_order = 1;   // per-XCD contiguous tile ranges: the column tiles that share a dY panel sit on one XCD
+    grp.p[i].split_k = 0;
+    grp.blocks[i] = ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
+    grp.first[i] = at;
+    at += (grp.blocks[i] + 7) & ~7;
+  }
+  for (int i = n; i <= KMB_GEMM_GROUP_MAX; ++i) grp.first[i] = at;
+  hipLaunchKernelGGL(gemm_group_wgrad_kernel, dim3(at), dim3(256), lds_req, stream, grp);
   return hipGetLastError();
 }
 

@@ -11,6 +11,9 @@ typedef uint16_t bf16_t;
 const char* kmb_gemm_check(const KmbGemm& p);
 hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream);
 // the "all rows" kernel for decode-sized forward GEMMs (<= 320 rows, fp32 output, bias only): bit-identical to kmb_gemm_launch
+constexpr int KMB_GEMM_GROUP_MAX = 8;
+const char* kmb_gemm_group_check(const KmbGemm* probs, int n);
+hipError_t kmb_gemm_group_launch(const KmbGemm* probs, int n, hipStream_t stream);
 const char* kmb_gemm_allrows_check(const KmbGemm& p);
 hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream);
 void kmb_gemm_set_shared_device(int on);   // persistent variants: hand out every tile dynamically

@@ -2,6 +2,7 @@
 // parameter arena, plus small HBM-bound movers (casts, fills, KV-cache append, row gather).
 #include "common.h"
 #include "kernels.h"
+#include "diag.h"
 
 namespace {
 
@@ -45,6 +46,62 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       if (wd > 0.f) pp = pp - lr * wd * pp;
       p[i] = pp; m[i] = mm; v[i] = vv;
       if (pb != nullptr) pb[i] = f2bf(pp);
+    }
+  }
+}
+
+// The same update with U float4 per thread and loop turn in flight (4 U loads requested before the first is used) so that a
+// SMALL grid -- one or two workgroups per CU, which leaves the CU's other wave slots to the backward pass this update runs
+// beside -- still keeps the memory system busy.  Element-wise identical arithmetic.
+template <int U>
+__global__ __launch_bounds__(256) void adamw_kernel_u(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      bf16_t* __restrict__ pb, size_t n4, size_t n, float lr,
+                                                      float b1, float b2, float omb1, float omb2, float eps, float wd,
+                                                      float step_size, float gscale) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += stride * U) {
+    f32x4 pp[U], gg[U], mm[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride < n4 ? i0 + u * stride : i0;   // clamped address, no branch around the load
+      pp[u] = reinterpret_cast<f32x4*>(p)[i];
+      gg[u] = reinterpret_cast<const f32x4*>(g)[i];
+      mm[u] = reinterpret_cast<f32x4*>(m)[i];
+      vv[u] = reinterpret_cast<f32x4*>(v)[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i >= n4) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gr = gg[u][e] * gscale;
+        mm[u][e] = mm[u][e] * b1 + gr * omb1;
+        vv[u][e] = vv[u][e] * b2 + gr * gr * omb2;
+        pp[u][e] = pp[u][e] - step_size * (mm[u][e] / (sqrtf(vv[u][e]) + eps));
+        if (wd > 0.f) pp[u][e] = pp[u][e] - lr * wd * pp[u][e];
+      }
+      reinterpret_cast<f32x4*>(p)[i] = pp[u];
+      reinterpret_cast<f32x4*>(m)[i] = mm[u];
+      reinterpret_cast<f32x4*>(v)[i] = vv[u];
+      if (pb != nullptr) {
+        uint2 o;
+        o.x = pack2bf(pp[u][0], pp[u][1]);
+        o.y = pack2bf(pp[u][2], pp[u][3]);
+        reinterpret_cast<uint2*>(pb)[i] = o;
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+      const float gr = g[i] * gscale;
+      const float mm1 = m[i] * b1 + gr * omb1;
+      const float vv1 = v[i] * b2 + gr * gr * omb2;
+      float pp1 = p[i] - step_size * (mm1 / (sqrtf(vv1) + eps));
+      if (wd > 0.f) pp1 = pp1 - lr * wd * pp1;
+      p[i] = pp1; m[i] = mm1; v[i] = vv1;
+      if (pb != nullptr) pb[i] = f2bf(pp1);
     }
   }
 }
@@ -157,6 +214,19 @@ hipError_t kmb_adamw_launch(float* p, const float* g, float* m, float* v, bf16_t
     step_size = step_size * sqrt(bc2) / bc1;
   }
   const size_t n4 = n >> 2;
+  // (diagnostic build) KMB_ADAMW_GRID = cap of the grid, KMB_ADAMW_UNROLL = 1 | 2 | 4 float4 per thread and turn
+  static const int grid_cap = KMB_DIAG_ENV("KMB_ADAMW_GRID") ? atoi(KMB_DIAG_ENV("KMB_ADAMW_GRID")) : 0;
+  static const int unroll = KMB_DIAG_ENV("KMB_ADAMW_UNROLL") ? atoi(KMB_DIAG_ENV("KMB_ADAMW_UNROLL")) : 1;
+  if (grid_cap > 0) {
+    const dim3 grid(grid_for((n4 + unroll - 1) / unroll, grid_cap));
+#define KMB_ADAMW_U(U) hipLaunchKernelGGL((adamw_kernel_u<U>), grid, dim3(256), 0, stream, p, g, m, v, p_bf16, n4, n, (float)h.lr, (float)h.beta1, \
+                     (float)h.beta2, (float)(1.0 - h.beta1), (float)(1.0 - h.beta2), (float)h.eps, (float)h.weight_decay, (float)step_size, h.grad_scale)
+    if (unroll >= 4) KMB_ADAMW_U(4);
+    else if (unroll == 2) KMB_ADAMW_U(2);
+    else KMB_ADAMW_U(1);
+#undef KMB_ADAMW_U
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, stream, p, g, m, v, p_bf16, n4, n,
                      (float)h.lr, (float)h.beta1, (float)h.beta2, (float)(1.0 - h.beta1), (float)(1.0 - h.beta2),
                      (float)h.eps, (float)h.weight_decay, (float)step_size, h.grad_scale);

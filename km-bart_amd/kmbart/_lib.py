@@ -161,6 +161,7 @@ PROTOTYPES = {
     "kmb_clock_stamp": (C.c_int, [c_p, c_p]),
     "kmb_op_gemm": (C.c_int, [C.POINTER(KmbGemm), c_p]),
     "kmb_op_gemm_allrows": (C.c_int, [C.POINTER(KmbGemm), c_p]),
+    "kmb_op_gemm_group": (C.c_int, [C.POINTER(KmbGemm), C.c_int32, c_p]),
     "kmb_op_attn_fwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_bwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_decode": (C.c_int, [C.POINTER(KmbAttnDecode), c_p]),

@@ -40,7 +40,7 @@ def pytest_configure(config):
 # with `pytest -x` one end-to-end failure can never hide the kernel parity results (round 2 lost 96 tests that way).
 _ORDER = ["test_cabi_cpu", "test_oracle_golden", "test_host_logic_cpu", "test_collation_cpu", "test_dataset_cpu",
           "test_dp_gloo_cpu", "test_comm_plan_cpu",
-          "test_ops_gpu", "test_gemm_variants_gpu", "test_gemm_persistent_gpu", "test_contention_gpu",
+          "test_ops_gpu", "test_gemm_group_gpu", "test_gemm_variants_gpu", "test_gemm_persistent_gpu", "test_contention_gpu",
           "test_model_gpu", "test_fullsize_parity_gpu", "test_fp32_mode_gpu", "test_small_batch_gpu",
           "test_decode_fused_gpu", "test_fullsize_gpu", "test_bench_batch_gpu", "test_pretrain_large_gpu",
           "test_dp_engine_two_ranks_gpu", "test_dp_rccl_gpu",
