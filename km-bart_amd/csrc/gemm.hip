@@ -727,6 +727,180 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v7(const KmbGemm p) {
   v7_tile<A_KC, B_KC>(p, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// v7d ("deep", launch variant 5; round 5): the same tile with FOUR LDS stages instead of two, for launches that put at most one
+// workgroup on a CU (<= 256 workgroups: M <= 4096 rows of N = 768, the reference's default batch of 64).  There v7's K step
+// is not bound by the MFMAs (0.21 us for its 32 per wave) but by the latency of the ONE stage it has in flight -- about 1 us
+// per 64-deep step with nobody else on the CU to hide it (4096 x 768 x 3072: 52-57 us inside a b = 64 step = 48 steps).  Four
+// stages keep three in flight behind a counted wait (s_waitcnt vmcnt(16): the in-order return path guarantees the oldest
+// stage has landed); 128 KB of LDS, so one workgroup per CU by construction.  Same fragment reads, same MFMA order: bit-identical.
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void v7d_tile(const KmbGemm& p, char* smem, int block, int nblocks) {
+  KMB_STAMP(0);
+  KMB_STAMP_ID();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nsl = p.split_k > 1 ? p.split_k : 1;
+  const int bid = (p.tile_order & 1) ? xcd_remap(block, nblocks) : block;
+  const int ntl = tiles_n * ((p.M + BM - 1) / BM);
+  const bool slice_major = (p.tile_order & 4) != 0 && nsl > 1;   // see split_order_note
+  const int tile = slice_major ? bid % ntl : bid / nsl, slice = slice_major ? bid / ntl : bid % nsl;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt_all = p.K / BK;
+  const int t_begin = (int)((long)nt_all * slice / nsl), t_end = (int)((long)nt_all * (slice + 1) / nsl);
+  const int nt = t_end - t_begin;
+
+  uint32_t offA[4], offB[4];
+  dma_offsets<A_KC>(offA, p.lda, row0, p.M, wave, lane);
+  dma_offsets<B_KC>(offB, p.ldb, col0, p.N, wave, lane);
+  const size_t stepA = A_KC ? (size_t)BK * 2 : (size_t)BK * p.lda * 2;
+  const size_t stepB = B_KC ? (size_t)BK * 2 : (size_t)BK * p.ldb * 2;
+  const char* gA = reinterpret_cast<const char*>(p.A) +
+                   (A_KC ? ((size_t)row0 * p.lda + (size_t)t_begin * BK) * 2 : (size_t)row0 * 2) +
+                   (A_KC ? 0 : (size_t)t_begin * stepA);
+  const char* gB = reinterpret_cast<const char*>(p.B) +
+                   (B_KC ? ((size_t)col0 * p.ldb + (size_t)t_begin * BK) * 2 : (size_t)col0 * 2) +
+                   (B_KC ? 0 : (size_t)t_begin * stepB);
+  constexpr int A_TILE = BM * BK * 2;
+  char* const dstA = smem + wave * 4096;            // this wave's 4 pieces of the A image (stage 0)
+  char* const dstB = smem + A_TILE + wave * 4096;
+
+  // K step `ks` (relative to t_begin) of this tile -> LDS stage buffer; the tile base is forced into SGPRs so the
+  // loads take the saddr + 32-bit-voffset form (no per-piece 64-bit VALU address arithmetic)
+  auto uniform_ptr = [](const char* ptr) {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  auto dma_stage = [&](int ks, int stage_buf) {
+    char* da = dstA + stage_buf * STAGE_BYTES;
+    char* db = dstB + stage_buf * STAGE_BYTES;
+    const char* ga = uniform_ptr(gA + (size_t)ks * stepA);
+    const char* gb = uniform_ptr(gB + (size_t)ks * stepB);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(ga, offA[i], da + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(gb, offB[i], db + i * 1024);
+  };
+
+  bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  dma_stage(0, 0);
+  if (nt > 1) dma_stage(1, 1);
+  if (nt > 2) dma_stage(2, 2);
+  if (nt > 3) dma_stage(3, 3);
+  // stage 0 has landed once at most the pieces of the younger stages (eight per wave and stage) are outstanding
+  if (nt > 3) __builtin_amdgcn_s_waitcnt(0x4F78);        // vmcnt(24)
+  else if (nt > 2) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
+  else if (nt > 1) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8)
+  else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+  __builtin_amdgcn_s_barrier();   // (not __syncthreads(): its fence is a vmcnt(0) -- the three younger stages stay in flight here)
+  KMB_STAMP(1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(smem, wm * 4 + i, 0, r, g);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(smem + A_TILE, wn * 4 + j, 0, r, g);
+
+  constexpr int NDS = (A_KC ? 4 : 8) + (B_KC ? 4 : 8);  // ds_read instructions per fragment set
+  // in_flight: stages younger than t + 1 that may still be outstanding at this step's wait (2, 1 or 0)
+  auto kstep = [&](int t, auto do_dma, auto do_next, auto in_flight) {
+    const char* cur = smem + (t & 3) * STAGE_BYTES;
+    const char* nxt = smem + ((t + 1) & 3) * STAGE_BYTES;
+    // ---- phase A ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa1[i] = read_frag<A_KC>(cur, wm * 4 + i, 1, r, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb1[j] = read_frag<B_KC>(cur + A_TILE, wn * 4 + j, 1, r, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA first: they wait on phase B's reads, not on these
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);        // MFMA
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // lgkmcnt(0) + vmcnt(8 x in_flight): stage t + 1 has landed; the builtin (not inline asm) so the compiler's own wait
+    // tracking knows the fragments have arrived
+    if (decltype(in_flight)::value == 2) __builtin_amdgcn_s_waitcnt(0x4070);
+    else if (decltype(in_flight)::value == 1) __builtin_amdgcn_s_waitcnt(0x0078);
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B ----  (the DMA overwrites LDS the fragment reads may alias: reads first, DMA pieces behind them)
+    if (decltype(do_next)::value) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(nxt, wm * 4 + i, 0, r, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(nxt + A_TILE, wn * 4 + j, 0, r, g);
+    }
+    if (decltype(do_dma)::value) dma_stage(t + 4, t & 3);   // into the buffer this step has just read for the last time
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+    if (decltype(do_next)::value && decltype(do_dma)::value) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 1);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+      }
+    } else if (decltype(do_next)::value) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS / 4, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+  using I2 = std::integral_constant<int, 2>;
+  using I1 = std::integral_constant<int, 1>;
+  using I0 = std::integral_constant<int, 0>;
+  int t = 0;
+  for (; t + 4 < nt; ++t) kstep(t, Yes{}, Yes{}, I2{});                // stages t + 1 .. t + 3 outstanding, t + 4 requested
+  if (nt - t == 4) { kstep(t, No{}, Yes{}, I2{}); ++t; }
+  if (nt - t == 3) { kstep(t, No{}, Yes{}, I1{}); ++t; }
+  if (nt - t == 2) { kstep(t, No{}, Yes{}, I0{}); ++t; }
+  kstep(t, No{}, No{}, I0{});
+  __syncthreads();
+  KMB_STAMP(2);
+  gemm_epilogue<256>(p, smem, acc, tid, wm, wn, r, g, row0, col0, slice);
+  KMB_STAMP(4);
+}
+
+
+constexpr int LDS_DEEP = 4 * STAGE_BYTES;   // 128 KB (the epilogue's fp32 image + column sums fit in it)
+static_assert(LDS_DEEP >= LDS_BYTES, "the deep variant's epilogue uses the stage buffers");
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 1) void gemm_kernel_v7d(const KmbGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v7d_tile<A_KC, B_KC>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
 #ifndef KMB_GEMM_DEVICE_ONLY
 // Grouped weight gradients (round 5): ONE launch walks the 128x128 tiles of up to KMB_GEMM_GROUP_MAX independent problems of the
 // weight-gradient layout (dW = dY^T X: both operands token-major), each tile over the WHOLE token reduction -- no K slices,
@@ -2357,7 +2531,11 @@ hipError_t launch_variant(int variant, const KmbGemm& p, hipStream_t stream) {
   } else {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles * nsl), block(256);
-    if (variant == 7) {
+    if (variant == 5) {   // four LDS stages, one workgroup per CU (v7d_ok)
+      if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v7d<true, true>), grid, block, LDS_DEEP, stream, p);
+      else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v7d<true, false>), grid, block, LDS_DEEP, stream, p);
+      else hipLaunchKernelGGL((gemm_kernel_v7d<false, false>), grid, block, LDS_DEEP, stream, p);
+    } else if (variant == 7) {
       if (p.a_kc && p.b_kc) hipLaunchKernelGGL((gemm_kernel_v7<true, true>), grid, block, LDS_BYTES, stream, p);
       else if (p.a_kc) hipLaunchKernelGGL((gemm_kernel_v7<true, false>), grid, block, LDS_BYTES, stream, p);
       else hipLaunchKernelGGL((gemm_kernel_v7<false, false>), grid, block, LDS_BYTES, stream, p);
@@ -2377,6 +2555,13 @@ struct TuneKey {
   }
 };
 std::map<TuneKey, int> g_best;
+
+// v7d (four LDS stages): launches of at most one workgroup per CU with a K loop worth pipelining
+bool v7d_ok(const KmbGemm& p) {
+  const long wgs = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
+  const int nt = p.K / BK / (p.split_k > 1 ? p.split_k : 1);
+  return wgs <= 256 && (p.K % BK) == 0 && nt >= 4 && p.act != 5;
+}
 
 // v11 (persistent, one workgroup per CU): enough tiles for half the CUs, two K steps, no split-K
 bool v11_ok(const KmbGemm& p, int bn = BN4) {
@@ -2598,6 +2783,9 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7d<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEEP);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7d<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEEP);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7d<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DEEP);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
@@ -2638,6 +2826,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
   }
   if (forced) {
     int v = forced;
+    if (v == 5 && !v7d_ok(p)) v = 7;
     if (v == 6 && !kmb_gemm_lean_ok(p)) v = 11;
     if (v == 9 && !kmb_gemm_pair_ok(p)) v = 11;
 #ifdef KMB_WITH_ROLESPLIT
@@ -2651,7 +2840,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (v == 14 && !v11_ok(p)) v = 8;
     if (v == 15 && !v11_ok(p, 192)) v = 8;
     if (v == 8 && !(big && p.N > 128)) v = 7;
-    if (v != 1 && v != 6 && v != 7 && v != 8 && v != 9 && v != 10 && (v < 11 || v > 15)) v = 7;
+    if (v != 1 && v != 5 && v != 6 && v != 7 && v != 8 && v != 9 && v != 10 && (v < 11 || v > 15)) v = 7;
     if (p.act == 5 && v != 6 && v != 9 && v != 10 && (v < 11 || v == 13 || v == 15)) v = 11;
     KmbGemm q = p;
     q.tile_order = p.tile_order | (prefetch_a(p) ? 2 : 0);
@@ -2664,7 +2853,8 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     if (!autotune || writes_an_input(p)) return p.act == 5 ? launch_config(p, 11, stream) : launch_variant(7, p, stream);
     // (variant 10, the role-split kernel, lives in tools/experiments/ since round 5: bit-identical, slower than the persistent
     //  variants on every benchmark-batch shape but two -- DESIGN.md section 4 "Round 4"; `build.py --variant rolesplit` links it)
-    const int cands[18] = {7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
+    const int cands[21] = {5, 5 + 16, 5 + 16 * 5,                                          // four LDS stages (<= 256 workgroups)
+                           7, 7 + 16, 8, 8 + 16, 11, 11 + 16, 12, 12 + 16, 13, 13 + 16,   // variant | (tile_order << 4)
                            14, 14 + 16, 15, 15 + 16,
                            7 + 16 * 5, 8 + 16 * 5,                                        // split-K only: slice-major
                            9,                                                             // two workgroups per CU (gemm_pair.hip)
@@ -2687,6 +2877,7 @@ hipError_t kmb_gemm_launch(const KmbGemm& p, hipStream_t stream) {
     }
     for (int c : cands) {
       if (exclude & (1u << (c & 15))) continue;
+      if ((c & 15) == 5 && !v7d_ok(p)) continue;
       if ((c & 15) == 6 && !kmb_gemm_lean_ok(p)) continue;
       if ((c & 15) == 9 && !kmb_gemm_pair_ok(p)) continue;
       if ((c & 15) == 11 && !v11_ok(p)) continue;

@@ -1,4 +1,4 @@
-"""The persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128, 13: 256x192, 14 / 15: 256x256 / 256x192 with eight waves) against the 128x128 variant 7 on every epilogue class and operand layout:
+"""The four-stage 128x128 variant 5 (launches of at most 256 workgroups) and the persistent GEMMs (variant 11: 256x256 tiles, 12: 256x128, 13: 256x192, 14 / 15: 256x256 / 256x192 with eight waves) against the 128x128 variant 7 on every epilogue class and operand layout:
 outputs must be bit-identical (same per-element accumulation order), column sums equal after folding their partial
 rows.  Also prints the time of each variant per case.  Re-runs itself once per variant (the variant is a per-process
 environment choice).
@@ -44,6 +44,18 @@ CASES = [
     ("wgrad_split7", 3072, 768, 8192, False, False, dict(split=7)),
     ("wgrad_split14_edges", 700, 760, 4096, False, False, dict(split=14)),
     ("fwd_split3", 2048, 768, 3072, True, True, dict(split=3)),
+    # at most 256 workgroups (the reference's default batch of 64): the four-stage variant 5 takes these, every other variant number
+    # falls back to what it is eligible for
+    ("small_fc2_fwd", 4096, 768, 3072, True, True, dict(bias=True, residual=True, drop=0.1)),
+    ("small_out_dgrad", 4096, 768, 768, True, False, dict()),
+    ("small_qkv_fwd", 1024, 2304, 768, True, True, dict(bias=True, qscale=True)),
+    ("small_fc1_gelu", 1024, 3072, 768, True, True, dict(bias=True, act=1, preact=True)),
+    ("small_fc1_dgrad_cs", 1024, 3072, 768, True, False, dict(act=2, aux=True, colsum=True)),
+    ("small_wgrad", 768, 768, 4096, False, False, dict(f32=True)),
+    ("small_wgrad_split7", 768, 768, 4096, False, False, dict(split=7)),
+    ("small_edges_k320", 1000, 520, 320, True, False, dict(residual=True)),
+    ("small_k256", 2048, 768, 256, True, True, dict(bias=True)),
+    ("small_k192", 2048, 768, 192, True, True, dict(bias=True)),
     # benchmark-batch shapes of the classes whose epilogue is long (timing of the eight-wave variant 14 against 11 / 13 / 8)
     ("b1024_fc1_gelu", 32768, 3072, 768, True, True, dict(bias=True, act=1, preact=True)),
     ("b1024_fc1_dgrad", 32768, 3072, 768, True, False, dict(act=2, aux=True, colsum=True)),
@@ -124,7 +136,7 @@ def run_variant():
 
 
 VARIANTS = ("7", "8", "11", "12", "13", "14", "15", "11o1", "12o1", "13o1", "14o1", "15o1", "11s", "12o1s", "13s", "14s", "15o1s", "11o1p",
-            "13p", "14o1p", "15p", "7o5", "8o5")
+            "13p", "14o1p", "15p", "7o5", "8o5", "5", "5o1", "5o5")
 
 
 def main():
