@@ -629,13 +629,21 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             B = B * eff_mult
         V = cfg.vocab_size
         R = B * num_beams
-        eng.gen_begin(input_ids, image_features, attention_mask, num_beams, max_length)
-        # the device-side input validation is read back without waiting (the decode steps are enqueued while the encoder
-        # still runs); a flagged batch raises at the first point where the host waits for the device anyway
-        if os.environ.get("KMB_GEN_SYNC_CHECK") == "1":   # A/B knob: wait for the encoder before the first decode step
-            eng.check_inputs()
+        # fp32 validation mode (Engine.set_precision(True)): parity evidence, not a product path -- no KV cache, no fused decode
+        # blocks; every step is an eval forward on the exact-fp32 kernels over the rows' tokens so far (the encoder runs once,
+        # its fp32 states are handed back in), and the host loops below do the reference's bookkeeping on those logits
+        fp32 = bool(getattr(eng, "fp32_mode", False))
+        step_logits = None
+        if fp32:
+            step_logits = self._fp32_step_fn(eng, input_ids, image_features, attention_mask, num_beams)
         else:
-            eng.check_inputs_begin()
+            eng.gen_begin(input_ids, image_features, attention_mask, num_beams, max_length)
+            # the device-side input validation is read back without waiting (the decode steps are enqueued while the encoder
+            # still runs); a flagged batch raises at the first point where the host waits for the device anyway
+            if os.environ.get("KMB_GEN_SYNC_CHECK") == "1":   # A/B knob: wait for the encoder before the first decode step
+                eng.check_inputs()
+            else:
+                eng.check_inputs_begin()
         cur_len = 1
 
         if num_beams == 1:
@@ -647,7 +655,7 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             flags = eng.pinned((max_length + 1,), torch.long)
             pending, keep = None, None
             while cur_len < max_length:
-                logits = eng.gen_step(cols[-1], cur_len - 1)[:, :V]
+                logits = step_logits(torch.stack(cols, dim=1)) if fp32 else eng.gen_step(cols[-1], cur_len - 1)[:, :V]
                 if processors_on:
                     _postprocess_next_token_scores(logits, torch.stack(cols, dim=1).tolist(), cur_len, min_length,
                                                    eos_token_id, repetition_penalty, no_repeat_ngram_size, bad_words_ids)
@@ -674,7 +682,8 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                             break
                     pending = (cur_len, ev)
             out = torch.stack(cols[:keep] if keep is not None else cols, dim=1)
-            eng.check_inputs_end()
+            if not fp32:
+                eng.check_inputs_end()
             return out
 
         # Host bookkeeping on plain Python lists: indexing small CPU tensors element by element (as the reference does)
@@ -719,7 +728,7 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 assert n_sent == num_beams, "Beam should always be full"
             return new_scores, new_tokens, new_idx
 
-        host_loop = do_sample or processors_on
+        host_loop = do_sample or processors_on or fp32
         if not host_loop:
             # Greedy beam search, pipelined: the device picks the next step's beams itself (kmb_beam_merge_select: the
             # first num_beams non-EOS candidates, exactly what the bookkeeping below sends on), so step t+1 is enqueued
@@ -784,7 +793,7 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             # with generate_text's --do_sample/--top_p/--top_k and --num_beams: no forced BOS/EOS; 2*num_beams draws per batch
             # item from softmax over the beams' filtered (log-prob + beam score) / T) and repetition_penalty /
             # no_repeat_ngram_size / bad_words_ids (postprocess_next_token_scores on the log-probabilities).
-            logits = eng.gen_step(last_tokens, cur_len - 1)[:, :V].float()
+            logits = step_logits(torch.tensor(seqs, dtype=torch.long)) if fp32 else eng.gen_step(last_tokens, cur_len - 1)[:, :V].float()
             if not do_sample:   # adjust_logits_during_generation (mixins.py:400-405): forced BOS / EOS, greedy beams only
                 force = cfg.bos_token_id if cur_len == 1 else (eos_token_id if (cur_len == max_length - 1 and eos_token_id is not None) else None)
                 if force is not None:
@@ -816,7 +825,8 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             seqs = [seqs[j] + [t] for j, t in zip(new_idx, new_tokens)]
             tok_idx = torch.tensor([new_tokens, new_idx], dtype=torch.long).to(dev)
             last_tokens = tok_idx[0].contiguous()
-            eng.gen_reorder(tok_idx[1], cur_len - 1)   # _reorder_cache, mixins.py:419-434
+            if not fp32:
+                eng.gen_reorder(tok_idx[1], cur_len - 1)   # _reorder_cache, mixins.py:419-434
             cur_len += 1
         for b in range(B):
             if done[b]:
@@ -842,9 +852,36 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             out = torch.tensor(rows, dtype=torch.long)
         else:
             out = torch.tensor(best, dtype=torch.long)
-        eng.check_inputs_end()
+        if not fp32:
+            eng.check_inputs_end()
         out = out.to(dev)
         return (out, torch.tensor(best_scores)) if return_scores else out
+
+    @staticmethod
+    def _fp32_step_fn(eng, input_ids, image_features, attention_mask, num_beams):
+        """generate() in the fp32 validation mode: returns f(rows' decoder tokens [R, t]) -> fp32 logits [R, V] of the last
+        position.  The encoder runs once (first call) and its float32 states, repeated per beam, are handed back in
+        (reference src/model/model.py:76-83); the decoder gets NO padding mask -- the reference's cached steps
+        (src/model/model.py:384-397, use_cache) build none, finished rows are fed pad tokens there too."""
+        B = input_ids.shape[0]
+        rep = torch.arange(B).repeat_interleave(num_beams)
+        ids, am = input_ids[rep.to(input_ids.device)], attention_mask[rep.to(attention_mask.device)]
+        feats = [image_features[i] for i in rep.tolist()]
+        state = {}
+
+        def step(rows):
+            rows = rows.to(eng.device)
+            ones = torch.ones_like(rows)
+            if "enc" not in state:
+                _, logits, enc = eng.forward(ids, feats, am, rows, ones, None, train=False, need_grad=False, want_logits=True,
+                                             want_encoder=True)
+                state["enc"] = enc
+            else:
+                _, logits, _ = eng.forward(ids, feats, am, rows, ones, None, train=False, need_grad=False, want_logits=True,
+                                           want_encoder=False, encoder_states=state["enc"])
+            return logits[:, -1, :].float().clone()
+
+        return step
 
     # ------------------------------------------------------------------ checkpoints
     def save_pretrained(self, save_directory):
