@@ -400,6 +400,14 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_
   const float beta = g.beta;
   g.split_k = S; g.slab = slab; g.out_f32 = nullptr; g.beta = 0.f;
   KCHK(run_gemm(g, s));
+  // KMB_SKIP_SLAB_REDUCE=1 (diagnostic build, TIMING ONLY -- the gradients are never written): what the 63 reduction launches of a
+  // step cost where they run (b = 256: 0.62 of 15.85 ms, b = 512: 0.6 of 27.0, b = 1024: 0.6 of 49.7, b = 64: nothing).  Folding the
+  // reduction into the GEMM -- the slices of a tile meet at a counter and the last one sums the slabs, write-through stores and
+  // L2-bypassing loads so that it is correct across XCDs -- was built in round 5, bit-identical, and SLOWER (3072 x 768 x 8192 in
+  // 7 slices: 80 -> 139 us; the step +2.5 % at b = 64, +5 % at 256, +4 % at 1024): slabs written through to memory and read back
+  // past the L2 cost several times what the pass over L2- / Infinity-Cache-resident slabs costs (profiles/r05_grouped_weight_gradients.md)
+  static const bool skip_reduce = KMB_DIAG_ENV("KMB_SKIP_SLAB_REDUCE") != nullptr;
+  if (skip_reduce) return 0;
   HIPCHK(kmb_reduce_slabs_launch(slab, S, (size_t)g.M * g.N, out, (size_t)g.M * g.N, beta, s));
   return 0;
 }
