@@ -16,6 +16,23 @@
 #include "diag.h"
 #include "kernels.h"
 
+// Diagnostic build only (tools/attn_bwd_stamps.py: -DKMB_ATTN_STAMP): s_memrealtime stamps (100 MHz) of thread 0 at the phase
+// boundaries of every item a workgroup of attn_bwd_small_kernel works through (up to 32 items x 16 slots per workgroup).
+#ifdef KMB_ATTN_STAMP
+__device__ unsigned long long* g_attn_stamps = nullptr;
+extern "C" int kmb_debug_set_attn_stamps(void* p) {
+  unsigned long long* v = (unsigned long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &v, sizeof(v));
+}
+#define ASTAMP(i)                                                                                           \
+  do {                                                                                                      \
+    if (g_attn_stamps != nullptr && threadIdx.x == 0 && astamp_iter < 32)                                   \
+      g_attn_stamps[((size_t)blockIdx.x * 32 + astamp_iter) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define ASTAMP(i)
+#endif
+
 namespace {
 
 constexpr int HD = 64;          // head dim
@@ -554,9 +571,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
 #pragma unroll
   for (int j = 0; j < 4; ++j) x.mk[j] = 1;
   bwd_load_item(p, item, tid, x);
+  [[maybe_unused]] int astamp_iter = -1;
   for (; item < nitems; item += gridDim.x) {
     const int b = item / p.H, h = item % p.H;
+    ++astamp_iter;
+    ASTAMP(0);
     __syncthreads();   // everyone is done with the previous item's LDS images
+    ASTAMP(1);
     // ---- staged registers -> LDS; delta = rowsum(dO * O) from the same registers ----
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -580,13 +601,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
         lse_s[row] = x.lse[i];
       }
     }
+    ASTAMP(2);
     __syncthreads();
+    ASTAMP(3);
     bool key_on[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) key_on[j] = x.mk[j] != 0;
     // ---- next item's loads go out now and land while this item is computed ----
     const int nxt = item + (int)gridDim.x;
     if (nxt < nitems) bwd_load_item(p, nxt, tid, x);
+    ASTAMP(4);
     // ---- S = Q K^T and dP = dO V^T for this wave's 16 query rows x 64 keys ----
     f32x4 s4[4], dp[4];
 #pragma unroll
@@ -622,7 +646,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
       *reinterpret_cast<uint2*>(Ps + off) = uint2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
       *reinterpret_cast<uint2*>(dSs + off) = uint2{pack2bf(ds[0], ds[1]), pack2bf(ds[2], ds[3])};
     }
+    ASTAMP(5);
     __syncthreads();
+    ASTAMP(6);
     // ---- dQ^T, dV^T, dK^T tiles: lane (r, g) holds row r of this wave's 16 and the columns 16 j + 4 g .. + 3 ----
     f32x4 dq[4], dk[4], dv[4];
 #pragma unroll
@@ -639,6 +665,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
         dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qs, j, kk, r, g), dstf, dk[j], 0, 0, 0);
       }
     }
+    ASTAMP(7);
     const int row = wave * 16 + r;   // query row of dQ, key row of dK / dV
     const bool q_ok = row < p.Tq, k_ok = row < p.Tk;
     if (p.dk_colsum != nullptr) {   // uniform branch
@@ -656,6 +683,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
           }
         }
     }
+    ASTAMP(8);
+    // (Round 5, measured and dropped: dQ / dK / dV through wave-private rows of the Q / K / V images after one more barrier and out
+    // as whole 128-byte rows, 16 bytes per lane -- six store instructions per wave instead of these twelve 8-byte ones that touch
+    // sixteen 32-byte segments each.  Same bits; encoder shape 223 against 221 us, decoder self 173 against 140, cross 185 against
+    // 173 at b = 1024: the stores were not what the in-order memory pipe waits for -- tools/attn_bwd_stamps.py.)
     if (q_ok) {
       bf16_t* qr = p.dQ + ((size_t)b * p.Tq + row) * p.lddq + h * HD + g * 4;
 #pragma unroll
@@ -672,8 +704,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
         *reinterpret_cast<u32x2*>(vr + j * 16) = u32x2{pack2bf(dv[j][0], dv[j][1]), pack2bf(dv[j][2], dv[j][3])};
       }
     }
+    ASTAMP(9);
     if (p.dk_colsum != nullptr) {
       __syncthreads();
+      ASTAMP(10);
       if (tid < 64) {
         const size_t o = (size_t)b * p.ld_colsum + h * HD + tid;
         if (p.dq_colsum != nullptr) p.dq_colsum[o] = (colq[tid] + colq[64 + tid]) + (colq[128 + tid] + colq[192 + tid]);
