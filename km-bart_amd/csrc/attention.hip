@@ -572,12 +572,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
   for (int j = 0; j < 4; ++j) x.mk[j] = 1;
   bwd_load_item(p, item, tid, x);
   [[maybe_unused]] int astamp_iter = -1;
+  int prev_b = -1, prev_h = 0;   // the item whose column-sum partials (colq / colk / colv) are complete but not yet written
+  auto write_colsums = [&]() {   // 64 threads: the four waves' partials of the previous item -> its row of the bias-gradient partials
+    const size_t o = (size_t)prev_b * p.ld_colsum + prev_h * HD + tid;
+    if (p.dq_colsum != nullptr) p.dq_colsum[o] = (colq[tid] + colq[64 + tid]) + (colq[128 + tid] + colq[192 + tid]);
+    p.dk_colsum[o] = (colk[tid] + colk[64 + tid]) + (colk[128 + tid] + colk[192 + tid]);
+    p.dv_colsum[o] = (colv[tid] + colv[64 + tid]) + (colv[128 + tid] + colv[192 + tid]);
+  };
   for (; item < nitems; item += gridDim.x) {
     const int b = item / p.H, h = item % p.H;
     ++astamp_iter;
     ASTAMP(0);
-    __syncthreads();   // everyone is done with the previous item's LDS images
+    __syncthreads();   // everyone is done with the previous item's LDS images (and its column-sum partials are complete)
     ASTAMP(1);
+    // the previous item's column sums leave behind THIS barrier (round 5: a barrier of their own per item was 0.7 of its 16 us);
+    // the partials are next written at the end of this iteration, two barriers further on
+    if (p.dk_colsum != nullptr && prev_b >= 0 && tid < 64) write_colsums();
     // ---- staged registers -> LDS; delta = rowsum(dO * O) from the same registers ----
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -705,16 +715,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
       }
     }
     ASTAMP(9);
-    if (p.dk_colsum != nullptr) {
-      __syncthreads();
-      ASTAMP(10);
-      if (tid < 64) {
-        const size_t o = (size_t)b * p.ld_colsum + h * HD + tid;
-        if (p.dq_colsum != nullptr) p.dq_colsum[o] = (colq[tid] + colq[64 + tid]) + (colq[128 + tid] + colq[192 + tid]);
-        p.dk_colsum[o] = (colk[tid] + colk[64 + tid]) + (colk[128 + tid] + colk[192 + tid]);
-        p.dv_colsum[o] = (colv[tid] + colv[64 + tid]) + (colv[128 + tid] + colv[192 + tid]);
-      }
-    }
+    prev_b = b; prev_h = h;
+  }
+  if (p.dk_colsum != nullptr && prev_b >= 0) {   // the last item's column sums
+    __syncthreads();
+    if (tid < 64) write_colsums();
   }
 }
 
