@@ -524,19 +524,23 @@ __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int ti
     const int id = tid + 256 * i;
     const int row = id >> 3, c = id & 7;
     const int tq = row < p.Tq ? row : p.Tq - 1, tk = row < p.Tk ? row : p.Tk - 1;
-    const size_t rq = (size_t)b * p.Tq + tq, rk = (size_t)b * p.Tk + tk;
-    x.q[i] = *reinterpret_cast<const u32x4*>(p.Q + rq * p.ldq + h * HD + c * 8);
-    x.d[i] = *reinterpret_cast<const u32x4*>(p.dO + rq * p.lddo + h * HD + c * 8);
-    x.o[i] = *reinterpret_cast<const u32x4*>(p.O + rq * p.ldo + h * HD + c * 8);
-    x.k[i] = *reinterpret_cast<const u32x4*>(p.K + rk * p.ldk + h * HD + c * 8);
-    x.v[i] = *reinterpret_cast<const u32x4*>(p.V + rk * p.ldv + h * HD + c * 8);
-    x.lse[i] = p.lse[((size_t)b * p.H + h) * p.Tq + tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
+    // 32-bit BYTE offsets from the tensors' bases (the launcher sends shapes whose tensors reach 4 GB to the general kernel):
+    // 64-bit multiplies are quarter-rate, and there were forty-five of them per item and wave here
+    const uint32_t rq = (uint32_t)b * (uint32_t)p.Tq + (uint32_t)tq, rk = (uint32_t)b * (uint32_t)p.Tk + (uint32_t)tk;
+    const uint32_t hc = (uint32_t)(h * HD + c * 8);
+    auto at = [](const bf16_t* base, uint32_t elem) { return reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + elem * 2u); };
+    x.q[i] = *at(p.Q, rq * (uint32_t)p.ldq + hc);
+    x.d[i] = *at(p.dO, rq * (uint32_t)p.lddo + hc);
+    x.o[i] = *at(p.O, rq * (uint32_t)p.ldo + hc);
+    x.k[i] = *at(p.K, rk * (uint32_t)p.ldk + hc);
+    x.v[i] = *at(p.V, rk * (uint32_t)p.ldv + hc);
+    x.lse[i] = p.lse[((uint32_t)b * (uint32_t)p.H + (uint32_t)h) * (uint32_t)p.Tq + (uint32_t)tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
   }
   if (p.key_mask != nullptr) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = j * 16 + (tid & 15);
-      x.mk[j] = p.key_mask[(size_t)b * p.Tk + (key < p.Tk ? key : p.Tk - 1)];
+      x.mk[j] = p.key_mask[(uint32_t)b * (uint32_t)p.Tk + (uint32_t)(key < p.Tk ? key : p.Tk - 1)];
     }
   }
 }
@@ -699,15 +703,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     // sixteen 32-byte segments each.  Same bits; encoder shape 223 against 221 us, decoder self 173 against 140, cross 185 against
     // 173 at b = 1024: the stores were not what the in-order memory pipe waits for -- tools/attn_bwd_stamps.py.)
     if (q_ok) {
-      bf16_t* qr = p.dQ + ((size_t)b * p.Tq + row) * p.lddq + h * HD + g * 4;
+      bf16_t* qr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dQ) + (((uint32_t)b * (uint32_t)p.Tq + (uint32_t)row) * (uint32_t)p.lddq + (uint32_t)(h * HD + g * 4)) * 2u);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<u32x2*>(qr + j * 16) = u32x2{pack2bf(dq[j][0] * p.dq_scale, dq[j][1] * p.dq_scale),
                                                        pack2bf(dq[j][2] * p.dq_scale, dq[j][3] * p.dq_scale)};
     }
     if (k_ok) {
-      bf16_t* kr = p.dK + ((size_t)b * p.Tk + row) * p.lddk + h * HD + g * 4;
-      bf16_t* vr = p.dV + ((size_t)b * p.Tk + row) * p.lddv + h * HD + g * 4;
+      const uint32_t krow = (uint32_t)b * (uint32_t)p.Tk + (uint32_t)row;
+      bf16_t* kr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dK) + (krow * (uint32_t)p.lddk + (uint32_t)(h * HD + g * 4)) * 2u);
+      bf16_t* vr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dV) + (krow * (uint32_t)p.lddv + (uint32_t)(h * HD + g * 4)) * 2u);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         *reinterpret_cast<u32x2*>(kr + j * 16) = u32x2{pack2bf(dk[j][0], dk[j][1]), pack2bf(dk[j][2], dk[j][3])};
@@ -835,7 +840,12 @@ hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
 hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream) {
   const int nqt = (p.Tq + 63) / 64;
   static const bool small_ok = !(KMB_DIAG_ENV("KMB_ATTN_BWD_SMALL") && KMB_DIAG_ENV("KMB_ATTN_BWD_SMALL")[0] == '0');
-  if (small_ok && p.Tq <= 64 && p.Tk <= 64) {   // one query tile, one key tile: the persistent, software-pipelined form
+  // (its 32-bit byte offsets: every tensor below 4 GB)
+  const size_t rows_max = (size_t)p.B * (size_t)(p.Tq > p.Tk ? p.Tq : p.Tk);
+  int ld_max = p.ldq;
+  for (int l : {p.ldk, p.ldv, p.ldo, p.lddo, p.lddq, p.lddk, p.lddv}) ld_max = l > ld_max ? l : ld_max;
+  const bool fits32 = rows_max * (size_t)ld_max * 2 < ((size_t)1 << 32);
+  if (small_ok && p.Tq <= 64 && p.Tk <= 64 && fits32) {   // one query tile, one key tile: the persistent, software-pipelined form
     const size_t lds_s = 6 * TILE_BYTES + (128 + 768) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
