@@ -529,12 +529,19 @@ __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int ti
     const uint32_t rq = (uint32_t)b * (uint32_t)p.Tq + (uint32_t)tq, rk = (uint32_t)b * (uint32_t)p.Tk + (uint32_t)tk;
     const uint32_t hc = (uint32_t)(h * HD + c * 8);
     auto at = [](const bf16_t* base, uint32_t elem) { return reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + elem * 2u); };
-    x.q[i] = *at(p.Q, rq * (uint32_t)p.ldq + hc);
-    x.d[i] = *at(p.dO, rq * (uint32_t)p.lddo + hc);
-    x.o[i] = *at(p.O, rq * (uint32_t)p.ldo + hc);
-    x.k[i] = *at(p.K, rk * (uint32_t)p.ldk + hc);
-    x.v[i] = *at(p.V, rk * (uint32_t)p.ldv + hc);
-    x.lse[i] = p.lse[((uint32_t)b * (uint32_t)p.H + (uint32_t)h) * (uint32_t)p.Tq + (uint32_t)tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
+    // rows 32 .. 63 (i = 1) of a tile that holds at most 32 rows are never fetched (the decoder's 32-token shapes: five of a self-attention
+    // item's ten tile loads, three of a cross-attention item's): their registers keep the zeros they were initialised with -- finite, so that
+    // the zero probabilities / score gradients of those rows multiply to zero -- and so do their LDS rows
+    if (i == 0 || p.Tq > 32) {
+      x.q[i] = *at(p.Q, rq * (uint32_t)p.ldq + hc);
+      x.d[i] = *at(p.dO, rq * (uint32_t)p.lddo + hc);
+      x.o[i] = *at(p.O, rq * (uint32_t)p.ldo + hc);
+      x.lse[i] = p.lse[((uint32_t)b * (uint32_t)p.H + (uint32_t)h) * (uint32_t)p.Tq + (uint32_t)tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
+    }
+    if (i == 0 || p.Tk > 32) {
+      x.k[i] = *at(p.K, rk * (uint32_t)p.ldk + hc);
+      x.v[i] = *at(p.V, rk * (uint32_t)p.ldv + hc);
+    }
   }
   if (p.key_mask != nullptr) {
 #pragma unroll
@@ -574,6 +581,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
   BwdRegs x;
 #pragma unroll
   for (int j = 0; j < 4; ++j) x.mk[j] = 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    x.q[i] = x.d[i] = x.k[i] = x.v[i] = x.o[i] = u32x4{0u, 0u, 0u, 0u};
+    x.lse[i] = 0.f;
+  }
   bwd_load_item(p, item, tid, x);
   [[maybe_unused]] int astamp_iter = -1;
   int prev_b = -1, prev_h = 0;   // the item whose column-sum partials (colq / colk / colv) are complete but not yet written
