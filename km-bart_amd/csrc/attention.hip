@@ -517,12 +517,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
 // Same arithmetic as attn_bwd_kernel up to the summation order of delta and of the column sums (fp32, last bit).
 struct BwdRegs { u32x4 q[2], d[2], k[2], v[2], o[2]; float lse[2]; long long mk[4]; };   // lse, mk: see FwdRegs
 
+// PACK (Tq, Tk <= 32, even H: the decoder's self-attention): ONE 64 x 64 tile carries TWO heads of a batch item -- rows 0 .. 31 head 2 hp,
+// rows 32 .. 63 head 2 hp + 1 -- where a tile per head was half empty: half the items, the same work per item.
+template <bool PACK>
 __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int tid, BwdRegs& x) {
-  const int b = item / p.H, h = item % p.H;
+  const int HH = PACK ? (p.H >> 1) : p.H;
+  const int b = item / HH, h0 = PACK ? 2 * (item % HH) : item % HH;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + 256 * i;
-    const int row = id >> 3, c = id & 7;
+    const int row = PACK ? ((id >> 3) & 31) : (id >> 3), c = id & 7;   // PACK: i = 1 is the second head's rows 0 .. 31
+    const int h = PACK ? h0 + i : h0;
     const int tq = row < p.Tq ? row : p.Tq - 1, tk = row < p.Tk ? row : p.Tk - 1;
     // 32-bit BYTE offsets from the tensors' bases (the launcher sends shapes whose tensors reach 4 GB to the general kernel):
     // 64-bit multiplies are quarter-rate, and there were forty-five of them per item and wave here
@@ -532,13 +537,13 @@ __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int ti
     // rows 32 .. 63 (i = 1) of a tile that holds at most 32 rows are never fetched (the decoder's 32-token shapes: five of a self-attention
     // item's ten tile loads, three of a cross-attention item's): their registers keep the zeros they were initialised with -- finite, so that
     // the zero probabilities / score gradients of those rows multiply to zero -- and so do their LDS rows
-    if (i == 0 || p.Tq > 32) {
+    if (PACK || i == 0 || p.Tq > 32) {
       x.q[i] = *at(p.Q, rq * (uint32_t)p.ldq + hc);
       x.d[i] = *at(p.dO, rq * (uint32_t)p.lddo + hc);
       x.o[i] = *at(p.O, rq * (uint32_t)p.ldo + hc);
       x.lse[i] = p.lse[((uint32_t)b * (uint32_t)p.H + (uint32_t)h) * (uint32_t)p.Tq + (uint32_t)tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
     }
-    if (i == 0 || p.Tk > 32) {
+    if (PACK || i == 0 || p.Tk > 32) {
       x.k[i] = *at(p.K, rk * (uint32_t)p.ldk + hc);
       x.v[i] = *at(p.V, rk * (uint32_t)p.ldv + hc);
     }
@@ -546,12 +551,13 @@ __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int ti
   if (p.key_mask != nullptr) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int key = j * 16 + (tid & 15);
+      const int key = PACK ? ((j * 16 + (tid & 15)) & 31) : j * 16 + (tid & 15);
       x.mk[j] = p.key_mask[(uint32_t)b * (uint32_t)p.Tk + (uint32_t)(key < p.Tk ? key : p.Tk - 1)];
     }
   }
 }
 
+template <bool PACK>
 __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
@@ -567,7 +573,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
   float* colv = colk + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int nitems = p.B * p.H;
+  const int HH = PACK ? (p.H >> 1) : p.H;   // items per batch element
+  const int nitems = p.B * HH;
   typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
   auto row16_sum = [](float v) {   // inclusive prefix sums by row_shr 1, 2, 4, 8 (zeros shifted in): lane 15 = total
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
@@ -586,17 +593,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     x.q[i] = x.d[i] = x.k[i] = x.v[i] = x.o[i] = u32x4{0u, 0u, 0u, 0u};
     x.lse[i] = 0.f;
   }
-  bwd_load_item(p, item, tid, x);
+  bwd_load_item<PACK>(p, item, tid, x);
   [[maybe_unused]] int astamp_iter = -1;
   int prev_b = -1, prev_h = 0;   // the item whose column-sum partials (colq / colk / colv) are complete but not yet written
   auto write_colsums = [&]() {   // 64 threads: the four waves' partials of the previous item -> its row of the bias-gradient partials
     const size_t o = (size_t)prev_b * p.ld_colsum + prev_h * HD + tid;
+    if (PACK) {   // waves 0, 1 hold the first head's rows, waves 2, 3 the second head's ((a + b) + (0 + 0) == a + b: the unpacked sums' bits)
+      if (p.dq_colsum != nullptr) { p.dq_colsum[o] = colq[tid] + colq[64 + tid]; p.dq_colsum[o + HD] = colq[128 + tid] + colq[192 + tid]; }
+      p.dk_colsum[o] = colk[tid] + colk[64 + tid]; p.dk_colsum[o + HD] = colk[128 + tid] + colk[192 + tid];
+      p.dv_colsum[o] = colv[tid] + colv[64 + tid]; p.dv_colsum[o + HD] = colv[128 + tid] + colv[192 + tid];
+      return;
+    }
     if (p.dq_colsum != nullptr) p.dq_colsum[o] = (colq[tid] + colq[64 + tid]) + (colq[128 + tid] + colq[192 + tid]);
     p.dk_colsum[o] = (colk[tid] + colk[64 + tid]) + (colk[128 + tid] + colk[192 + tid]);
     p.dv_colsum[o] = (colv[tid] + colv[64 + tid]) + (colv[128 + tid] + colv[192 + tid]);
   };
   for (; item < nitems; item += gridDim.x) {
-    const int b = item / p.H, h = item % p.H;
+    const int b = item / HH, h = PACK ? 2 * (item % HH) : item % HH;   // PACK: h = the first of the tile's two heads
     ++astamp_iter;
     ASTAMP(0);
     __syncthreads();   // everyone is done with the previous item's LDS images (and its column-sum partials are complete)
@@ -635,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     for (int j = 0; j < 4; ++j) key_on[j] = x.mk[j] != 0;
     // ---- next item's loads go out now and land while this item is computed ----
     const int nxt = item + (int)gridDim.x;
-    if (nxt < nitems) bwd_load_item(p, nxt, tid, x);
+    if (nxt < nitems) bwd_load_item<PACK>(p, nxt, tid, x);
     ASTAMP(4);
     // ---- S = Q K^T and dP = dO V^T for this wave's 16 query rows x 64 keys ----
     f32x4 s4[4], dp[4];
@@ -659,12 +672,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = j * 16 + r;
-      const bool kv = key < p.Tk && key_on[j];
+      const int keyl = PACK ? (key & 31) : key;                 // the key's position inside its head
+      const bool kv = keyl < p.Tk && key_on[j];
       float pv[4], ds[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int lrow = wave * 16 + g * 4 + q;
-        const bool ok = kv && lrow < p.Tq && (!p.causal || key <= lrow);
+        const int rowl = PACK ? (lrow & 31) : lrow;
+        const bool ok = kv && rowl < p.Tq && (!p.causal || keyl <= rowl) && (!PACK || (key >> 5) == (lrow >> 5));   // PACK: a query only sees its own head's keys
         pv[q] = (ok && lse4[q] != -INFINITY) ? __expf(s4[j][q] - lse4[q]) : 0.f;
         ds[q] = pv[q] * (dp[j][q] - del4[q]);
       }
@@ -693,7 +708,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     }
     ASTAMP(7);
     const int row = wave * 16 + r;   // query row of dQ, key row of dK / dV
-    const bool q_ok = row < p.Tq, k_ok = row < p.Tk;
+    const int rowl = PACK ? (row & 31) : row, hrow = PACK ? h + (row >> 5) : h;   // the row inside its head, and that head
+    const bool q_ok = rowl < p.Tq, k_ok = rowl < p.Tk;
     if (p.dk_colsum != nullptr) {   // uniform branch
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -715,16 +731,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     // sixteen 32-byte segments each.  Same bits; encoder shape 223 against 221 us, decoder self 173 against 140, cross 185 against
     // 173 at b = 1024: the stores were not what the in-order memory pipe waits for -- tools/attn_bwd_stamps.py.)
     if (q_ok) {
-      bf16_t* qr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dQ) + (((uint32_t)b * (uint32_t)p.Tq + (uint32_t)row) * (uint32_t)p.lddq + (uint32_t)(h * HD + g * 4)) * 2u);
+      bf16_t* qr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dQ) + (((uint32_t)b * (uint32_t)p.Tq + (uint32_t)rowl) * (uint32_t)p.lddq + (uint32_t)(hrow * HD + g * 4)) * 2u);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<u32x2*>(qr + j * 16) = u32x2{pack2bf(dq[j][0] * p.dq_scale, dq[j][1] * p.dq_scale),
                                                        pack2bf(dq[j][2] * p.dq_scale, dq[j][3] * p.dq_scale)};
     }
     if (k_ok) {
-      const uint32_t krow = (uint32_t)b * (uint32_t)p.Tk + (uint32_t)row;
-      bf16_t* kr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dK) + (krow * (uint32_t)p.lddk + (uint32_t)(h * HD + g * 4)) * 2u);
-      bf16_t* vr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dV) + (krow * (uint32_t)p.lddv + (uint32_t)(h * HD + g * 4)) * 2u);
+      const uint32_t krow = (uint32_t)b * (uint32_t)p.Tk + (uint32_t)rowl;
+      bf16_t* kr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dK) + (krow * (uint32_t)p.lddk + (uint32_t)(hrow * HD + g * 4)) * 2u);
+      bf16_t* vr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dV) + (krow * (uint32_t)p.lddv + (uint32_t)(hrow * HD + g * 4)) * 2u);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         *reinterpret_cast<u32x2*>(kr + j * 16) = u32x2{pack2bf(dk[j][0], dk[j][1]), pack2bf(dk[j][2], dk[j][3])};
@@ -861,13 +877,18 @@ hipError_t kmb_attn_bwd_launch(const KmbAttn& p, hipStream_t stream) {
     const size_t lds_s = 6 * TILE_BYTES + (128 + 768) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
       if (e != hipSuccess) return e;
       attr_set = true;
     }
-    const int items = p.B * p.H;
+    // two heads per tile for the 32-token self-attention shapes (KMB_ATTN_PACK=0 in the diagnostic build: one head per tile, as before round 5)
+    static const bool pack_ok = !(KMB_DIAG_ENV("KMB_ATTN_PACK") && KMB_DIAG_ENV("KMB_ATTN_PACK")[0] == '0');
+    const bool pack = pack_ok && p.Tq <= 32 && p.Tk <= 32 && (p.H & 1) == 0;
+    const int items = pack ? p.B * (p.H >> 1) : p.B * p.H;
     const int grid = items < 768 ? items : 768;   // three workgroups per CU (165 VGPRs, 52.6 KB of LDS each)
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(grid), dim3(256), lds_s, stream, p);
+    if (pack) hipLaunchKernelGGL(attn_bwd_small_kernel<true>, dim3(grid), dim3(256), lds_s, stream, p);
+    else hipLaunchKernelGGL(attn_bwd_small_kernel<false>, dim3(grid), dim3(256), lds_s, stream, p);
     return hipGetLastError();
   }
   const size_t lds = 6 * TILE_BYTES + (128 + 512) * sizeof(float) + (size_t)nqt * 64 * 64 * sizeof(float);

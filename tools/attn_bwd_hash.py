@@ -15,7 +15,8 @@ from kmbart._lib import check, ptr  # noqa: E402
 
 lib = _lib.load()
 B, H, d = int(os.environ.get("B", "256")), 12, 768
-for name, Tq, Tk, causal in (("enc self", 64, 64, 0), ("dec self", 32, 32, 1), ("cross", 32, 64, 0), ("ragged", 23, 51, 0)):
+for name, Tq, Tk, causal in (("enc self", 64, 64, 0), ("dec self", 32, 32, 1), ("cross", 32, 64, 0), ("ragged", 23, 51, 0), ("self 32 non-causal", 32, 32, 0),
+                            ("self 23 causal", 23, 23, 1), ("self 9", 9, 9, 0)):
     g = torch.Generator(device=DEV).manual_seed(1)
     qkv = (torch.randn(B * Tq, 3 * d, device=DEV, generator=g) * 0.5).bfloat16()
     kv = (torch.randn(B * Tk, 3 * d, device=DEV, generator=g) * 0.5).bfloat16() if Tk != Tq else qkv
