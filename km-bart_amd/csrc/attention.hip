@@ -203,16 +203,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const KmbAttn p) {
 // whenever a padding mask was given).
 struct FwdRegs { u32x4 q[2], k[2], v[2]; long long mk[4]; };
 
+// PACK (Tq, Tk <= 32, even H): two heads of a batch item per tile, as in the backward (bwd_load_item)
+template <bool PACK>
 __device__ __forceinline__ void fwd_load_item(const KmbAttn& p, int item, int tid, FwdRegs& x) {
-  const int b = item / p.H, h = item % p.H;
+  const int HH = PACK ? (p.H >> 1) : p.H;
+  const int b = item / HH, h0 = PACK ? 2 * (item % HH) : item % HH;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + 256 * i;
-    const int row = id >> 3, c = id & 7;
+    const int row = PACK ? ((id >> 3) & 31) : (id >> 3), c = id & 7;
+    const int h = PACK ? h0 + i : h0;
     const int tq = row < p.Tq ? row : p.Tq - 1, tk = row < p.Tk ? row : p.Tk - 1;
     // rows 32 .. 63 (i = 1) of a tile that holds at most 32 rows are never fetched: their LDS rows stay zero
-    if (i == 0 || p.Tq > 32) x.q[i] = *reinterpret_cast<const u32x4*>(p.Q + ((size_t)b * p.Tq + tq) * p.ldq + h * HD + c * 8);
-    if (i == 0 || p.Tk > 32) {
+    if (PACK || i == 0 || p.Tq > 32) x.q[i] = *reinterpret_cast<const u32x4*>(p.Q + ((size_t)b * p.Tq + tq) * p.ldq + h * HD + c * 8);
+    if (PACK || i == 0 || p.Tk > 32) {
       x.k[i] = *reinterpret_cast<const u32x4*>(p.K + ((size_t)b * p.Tk + tk) * p.ldk + h * HD + c * 8);
       x.v[i] = *reinterpret_cast<const u32x4*>(p.V + ((size_t)b * p.Tk + tk) * p.ldv + h * HD + c * 8);
     }
@@ -220,12 +224,13 @@ __device__ __forceinline__ void fwd_load_item(const KmbAttn& p, int item, int ti
   if (p.key_mask != nullptr) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int key = j * 16 + (tid & 15);
+      const int key = PACK ? ((j * 16 + (tid & 15)) & 31) : j * 16 + (tid & 15);
       x.mk[j] = p.key_mask[(size_t)b * p.Tk + (key < p.Tk ? key : p.Tk - 1)];
     }
   }
 }
 
+template <bool PACK>
 __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p) {
   __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES + 4 * 2048];
   char* Qs = smem;
@@ -234,7 +239,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   char* Ps = smem + 3 * TILE_BYTES + wave * 2048;
-  const int nitems = p.B * p.H;
+  const int HH = PACK ? (p.H >> 1) : p.H;
+  const int nitems = p.B * HH;
   const int q0 = wave * 16;
   int item = blockIdx.x;
   if (item >= nitems) return;
@@ -246,9 +252,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) x.mk[j] = 1;
-  fwd_load_item(p, item, tid, x);
+  fwd_load_item<PACK>(p, item, tid, x);
   for (; item < nitems; item += gridDim.x) {
-    const int b = item / p.H, h = item % p.H;
+    const int b = item / HH, h = PACK ? 2 * (item % HH) : item % HH;   // PACK: the first of the tile's two heads
     __syncthreads();   // everyone is done with the previous item's LDS images
 #pragma unroll
     for (int i = 0; i < 2; ++i) {   // (the never-fetched halves are rewritten with their zeros: LDS stores are not the limit)
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) key_on[j] = x.mk[j] != 0;
     const int nxt = item + (int)gridDim.x;   // the next item's loads go out now and land while this one is computed
-    if (nxt < nitems) fwd_load_item(p, nxt, tid, x);
-    if (q0 >= p.Tq) continue;   // wave-uniform: this wave has no query rows (both barriers are at the loop head)
+    if (nxt < nitems) fwd_load_item<PACK>(p, nxt, tid, x);
+    if ((PACK ? (q0 & 31) : q0) >= p.Tq) continue;   // wave-uniform: this wave has no query rows (both barriers are at the loop head)
     f32x4 s[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -278,11 +284,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = j * 16 + r;
-      const bool kv = key < p.Tk && key_on[j];
+      const int keyl = PACK ? (key & 31) : key;
+      const bool kv = keyl < p.Tk && key_on[j];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int qi = q0 + g * 4 + q;
-        const bool ok = kv && (!p.causal || key <= qi);
+        const bool ok = kv && (!p.causal || keyl <= (PACK ? (qi & 31) : qi)) && (!PACK || (key >> 5) == (qi >> 5));   // PACK: own head's keys only
         s[j][q] = ok ? s[j][q] : -INFINITY;
       }
     }
@@ -324,13 +331,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
     for (int q = 0; q < 4; ++q) {
       const float l = group16_sum(l_run[q]);
       const float inv = l > 0.f ? 1.f / l : 0.f;
-      const int qi = q0 + g * 4 + q;
+      const int qt = q0 + g * 4 + q;                                   // row of the tile
+      const int qi = PACK ? (qt & 31) : qt, hq = PACK ? h + (qt >> 5) : h;   // the query inside its head, and that head
       if (qi < p.Tq) {
-        bf16_t* orow = p.O + ((size_t)b * p.Tq + qi) * p.ldo + h * HD;
+        bf16_t* orow = p.O + ((size_t)b * p.Tq + qi) * p.ldo + hq * HD;
 #pragma unroll
         for (int j = 0; j < 4; ++j) orow[j * 16 + r] = f2bf(o[j][q] * inv);
         if (r == 0 && p.lse != nullptr)
-          p.lse[((size_t)b * p.H + h) * p.Tq + qi] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
+          p.lse[((size_t)b * p.H + hq) * p.Tq + qi] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
       }
     }
   }
@@ -856,8 +864,11 @@ const char* kmb_attn_check(const KmbAttn& p, int backward) {
 hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
   static const bool small_ok = !(KMB_DIAG_ENV("KMB_ATTN_FWD_SMALL") && KMB_DIAG_ENV("KMB_ATTN_FWD_SMALL")[0] == '0');
   if (small_ok && p.Tq <= 64 && p.Tk <= 64 && p.B * p.H >= 1024) {   // one query tile, one key tile, enough items to pipeline
-    const int items = p.B * p.H;
-    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(items < 1024 ? items : 1024), dim3(256), 0, stream, p);   // four workgroups per CU
+    static const bool pack_ok = !(KMB_DIAG_ENV("KMB_ATTN_PACK") && KMB_DIAG_ENV("KMB_ATTN_PACK")[0] == '0');
+    const bool pack = pack_ok && p.Tq <= 32 && p.Tk <= 32 && (p.H & 1) == 0;   // two heads per tile (32-token self-attention)
+    const int items = pack ? p.B * (p.H >> 1) : p.B * p.H;
+    if (pack) hipLaunchKernelGGL(attn_fwd_small_kernel<true>, dim3(items < 1024 ? items : 1024), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(attn_fwd_small_kernel<false>, dim3(items < 1024 ? items : 1024), dim3(256), 0, stream, p);   // four workgroups per CU
     return hipGetLastError();
   }
   dim3 grid(p.B * p.H, (p.Tq + 63) / 64), block(256);

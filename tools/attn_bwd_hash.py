@@ -1,4 +1,4 @@
-"""md5 of attention backward's outputs (dQ | dK | dV and the bias-gradient column sums) at the three training shapes: run with two
+"""md5 of attention forward's (O, log-sum-exp) and backward's outputs (dQ | dK | dV and the bias-gradient column sums) at the three training shapes: run with two
 builds (KMB_LIB_PATH) to check that a kernel change returns the same bits.  B=256 python tools/attn_bwd_hash.py"""
 import ctypes as C
 import hashlib
@@ -38,6 +38,6 @@ for name, Tq, Tk, causal in (("enc self", 64, 64, 0), ("dec self", 32, 32, 1), (
     check(lib.kmb_op_attn_bwd(C.byref(a), stream()))
     torch.cuda.synchronize()
     hh = hashlib.md5()
-    for t in (dqkv, dkv, cs):
+    for t in (O, lse, dqkv, dkv, cs):   # the forward's outputs too
         hh.update(t.cpu().view(torch.uint8).numpy().tobytes())
     print(name, Tq, Tk, hh.hexdigest())
