@@ -162,6 +162,10 @@ ATTN_CASES = [
     dict(B=2, H=3, Tq=32, Tk=64, causal=False, mask=True, fused=False),
     dict(B=2, H=1, Tq=40, Tk=100, causal=False, mask=True, fused=False),
     dict(B=1, H=2, Tq=130, Tk=130, causal=True, mask=False, fused=True),
+    # two heads per tile (Tq, Tk <= 32, even H; round 5): ragged length, per-sample key masks; and odd H, which keeps one head per tile
+    dict(B=4, H=4, Tq=23, Tk=23, causal=True, mask=True, fused=True),
+    dict(B=5, H=6, Tq=32, Tk=32, causal=False, mask=True, fused=True),
+    dict(B=2, H=3, Tq=32, Tk=32, causal=True, mask=True, fused=True),
 ]
 
 
