@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
 // and its read-modify-write pass are gone -- dQ leaves from registers as transposed MFMA tiles (8-byte stores), like
 // dK / dV; delta = rowsum(dO * O) comes from the staged registers (no second global read of dO).
 // Same arithmetic as attn_bwd_kernel up to the summation order of delta and of the column sums (fp32, last bit).
-struct BwdRegs { u32x4 q[2], d[2], k[2], v[2], o[2]; float lse[2]; long long mk[4]; };   // lse, mk: see FwdRegs
+struct BwdRegs { u32x4 q[2], d[2], k[2], v[2]; float lse[2]; long long mk[4]; };   // lse, mk: see FwdRegs
 
 // PACK (Tq, Tk <= 32, even H: the decoder's self-attention): ONE 64 x 64 tile carries TWO heads of a batch item -- rows 0 .. 31 head 2 hp,
 // rows 32 .. 63 head 2 hp + 1 -- where a tile per head was half empty: half the items, the same work per item.
@@ -548,7 +548,6 @@ __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int ti
     if (PACK || i == 0 || p.Tq > 32) {
       x.q[i] = *at(p.Q, rq * (uint32_t)p.ldq + hc);
       x.d[i] = *at(p.dO, rq * (uint32_t)p.lddo + hc);
-      x.o[i] = *at(p.O, rq * (uint32_t)p.ldo + hc);
       x.lse[i] = p.lse[((uint32_t)b * (uint32_t)p.H + (uint32_t)h) * (uint32_t)p.Tq + (uint32_t)tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
     }
     if (PACK || i == 0 || p.Tk > 32) {
@@ -598,7 +597,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
   for (int j = 0; j < 4; ++j) x.mk[j] = 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    x.q[i] = x.d[i] = x.k[i] = x.v[i] = x.o[i] = u32x4{0u, 0u, 0u, 0u};
+    x.q[i] = x.d[i] = x.k[i] = x.v[i] = u32x4{0u, 0u, 0u, 0u};
     x.lse[i] = 0.f;
   }
   bwd_load_item<PACK>(p, item, tid, x);
@@ -625,7 +624,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     // the previous item's column sums leave behind THIS barrier (round 5: a barrier of their own per item was 0.7 of its 16 us);
     // the partials are next written at the end of this iteration, two barriers further on
     if (p.dk_colsum != nullptr && prev_b >= 0 && tid < 64) write_colsums();
-    // ---- staged registers -> LDS; delta = rowsum(dO * O) from the same registers ----
+    // ---- staged registers -> LDS ----
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int id = tid + 256 * i;
@@ -634,19 +633,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
       *reinterpret_cast<u32x4*>(dOs + tile_off(row, c)) = x.d[i];
       *reinterpret_cast<u32x4*>(Ks + tile_off(row, c)) = x.k[i];
       *reinterpret_cast<u32x4*>(Vs + tile_off(row, c)) = x.v[i];
-      float a8[8], b8[8];
-      unpack8(x.o[i], a8);
-      unpack8(x.d[i], b8);
-      float acc = 0.f;   // this thread's 8 columns, then a tree over the row's eight chunk-lanes
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += a8[e] * b8[e];
-      acc += __shfl_xor(acc, 4, 64);
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      if (c == 0) {
-        del_s[row] = acc;
-        lse_s[row] = x.lse[i];
-      }
+      if (c == 0) lse_s[row] = x.lse[i];
     }
     ASTAMP(2);
     __syncthreads();
@@ -676,23 +663,41 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     // contiguous bytes of the transposed image -- 8 stores of 8 bytes per lane where the [query][key] image took 32 of 2 bytes -- and
     // the readers below swap roles (the operand that read rows reads columns and vice versa: same fragments, same bits)
     const float lse4[4] = {lse_s[wave * 16 + g * 4], lse_s[wave * 16 + g * 4 + 1], lse_s[wave * 16 + g * 4 + 2], lse_s[wave * 16 + g * 4 + 3]};
-    const float del4[4] = {del_s[wave * 16 + g * 4], del_s[wave * 16 + g * 4 + 1], del_s[wave * 16 + g * 4 + 2], del_s[wave * 16 + g * 4 + 3]};
+    // delta[q] = sum over the keys of P[q][k] * dP[q][k] (= rowsum(dO * O), the softmax backward's correction term) from the probabilities
+    // and dP this wave holds in registers -- the saved output O is not read at all (an eighth of an item's bytes, two of its sixteen loads)
+    float del4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = j * 16 + r;
       const int keyl = PACK ? (key & 31) : key;                 // the key's position inside its head
       const bool kv = keyl < p.Tk && key_on[j];
-      float pv[4], ds[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int lrow = wave * 16 + g * 4 + q;
         const int rowl = PACK ? (lrow & 31) : lrow;
         const bool ok = kv && rowl < p.Tq && (!p.causal || keyl <= rowl) && (!PACK || (key >> 5) == (lrow >> 5));   // PACK: a query only sees its own head's keys
-        pv[q] = (ok && lse4[q] != -INFINITY) ? __expf(s4[j][q] - lse4[q]) : 0.f;
-        ds[q] = pv[q] * (dp[j][q] - del4[q]);
+        const float pvq = (ok && lse4[q] != -INFINITY) ? __expf(s4[j][q] - lse4[q]) : 0.f;
+        s4[j][q] = pvq;
+        del4[q] += pvq * dp[j][q];
       }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // the row's keys sit in the 16 lanes of a DPP row: four rotate-and-add steps leave the total in every lane
+      float v = del4[q];
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+      del4[q] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = j * 16 + r;
+      float ds[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ds[q] = s4[j][q] * (dp[j][q] - del4[q]);
       const int off = elem_off(key, wave * 16 + g * 4);
-      *reinterpret_cast<uint2*>(Ps + off) = uint2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+      *reinterpret_cast<uint2*>(Ps + off) = uint2{pack2bf(s4[j][0], s4[j][1]), pack2bf(s4[j][2], s4[j][3])};
       *reinterpret_cast<uint2*>(dSs + off) = uint2{pack2bf(ds[0], ds[1]), pack2bf(ds[2], ds[3])};
     }
     ASTAMP(5);
