@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const KmbAttn p, int nqt)
 // and its read-modify-write pass are gone -- dQ leaves from registers as transposed MFMA tiles (8-byte stores), like
 // dK / dV; delta = rowsum(dO * O) comes from the staged registers (no second global read of dO).
 // Same arithmetic as attn_bwd_kernel up to the summation order of delta and of the column sums (fp32, last bit).
-struct BwdRegs { u32x4 q[2], d[2], k[2], v[2]; float lse[2]; long long mk[4]; };   // lse, mk: see FwdRegs
+struct BwdRegs { u32x4 q[2], d[2], k[2], v[2]; float lse; long long mk; };   // lse, mk: row / key `tid` of the tile, threads 0 .. 63 only   // lse, mk: see FwdRegs
 
 // PACK (Tq, Tk <= 32, even H: the decoder's self-attention): ONE 64 x 64 tile carries TWO heads of a batch item -- rows 0 .. 31 head 2 hp,
 // rows 32 .. 63 head 2 hp + 1 -- where a tile per head was half empty: half the items, the same work per item.
@@ -548,19 +548,20 @@ __device__ __forceinline__ void bwd_load_item(const KmbAttn& p, int item, int ti
     if (PACK || i == 0 || p.Tq > 32) {
       x.q[i] = *at(p.Q, rq * (uint32_t)p.ldq + hc);
       x.d[i] = *at(p.dO, rq * (uint32_t)p.lddo + hc);
-      x.lse[i] = p.lse[((uint32_t)b * (uint32_t)p.H + (uint32_t)h) * (uint32_t)p.Tq + (uint32_t)tq];   // (every chunk-lane of the row reads the same word; c == 0 uses it)
     }
     if (PACK || i == 0 || p.Tk > 32) {
       x.k[i] = *at(p.K, rk * (uint32_t)p.ldk + hc);
       x.v[i] = *at(p.V, rk * (uint32_t)p.ldv + hc);
     }
   }
-  if (p.key_mask != nullptr) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = PACK ? ((j * 16 + (tid & 15)) & 31) : j * 16 + (tid & 15);
-      x.mk[j] = p.key_mask[(uint32_t)b * (uint32_t)p.Tk + (uint32_t)(key < p.Tk ? key : p.Tk - 1)];
-    }
+  // the tile's 64 log-sum-exps and 64 key-mask words: ONE load each, by the first wave only (row / key = tid; PACK: rows / keys 32 .. 63 are the
+  // second head's).  Every thread used to load its row's word (2 loads) and its four keys' words (4 loads): sixteen loads a wave and item kept the
+  // wave from issuing for 4 us -- in-kernel stamps, profiles/r05_attn_bwd_stamps.txt -- fourteen for 1.1
+  if (tid < 64) {
+    const int rl = PACK ? (tid & 31) : tid, hh = PACK ? h0 + (tid >> 5) : h0;
+    const int tq = rl < p.Tq ? rl : p.Tq - 1, tk = rl < p.Tk ? rl : p.Tk - 1;
+    x.lse = p.lse[((uint32_t)b * (uint32_t)p.H + (uint32_t)hh) * (uint32_t)p.Tq + (uint32_t)tq];
+    if (p.key_mask != nullptr) x.mk = p.key_mask[(uint32_t)b * (uint32_t)p.Tk + (uint32_t)tk];
   }
 }
 
@@ -594,12 +595,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
   if (item >= nitems) return;
   BwdRegs x;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) x.mk[j] = 1;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    x.q[i] = x.d[i] = x.k[i] = x.v[i] = u32x4{0u, 0u, 0u, 0u};
-    x.lse[i] = 0.f;
-  }
+  for (int i = 0; i < 2; ++i) x.q[i] = x.d[i] = x.k[i] = x.v[i] = u32x4{0u, 0u, 0u, 0u};
+  x.lse = 0.f;
+  x.mk = 1;
   bwd_load_item<PACK>(p, item, tid, x);
   [[maybe_unused]] int astamp_iter = -1;
   int prev_b = -1, prev_h = 0;   // the item whose column-sum partials (colq / colk / colv) are complete but not yet written
@@ -633,14 +631,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
       *reinterpret_cast<u32x4*>(dOs + tile_off(row, c)) = x.d[i];
       *reinterpret_cast<u32x4*>(Ks + tile_off(row, c)) = x.k[i];
       *reinterpret_cast<u32x4*>(Vs + tile_off(row, c)) = x.v[i];
-      if (c == 0) lse_s[row] = x.lse[i];
+    }
+    if (tid < 64) {
+      lse_s[tid] = x.lse;
+      del_s[tid] = x.mk != 0 ? 1.f : 0.f;   // (the delta slots: free since delta comes from registers) key-mask flags
     }
     ASTAMP(2);
     __syncthreads();
     ASTAMP(3);
     bool key_on[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) key_on[j] = x.mk[j] != 0;
+    for (int j = 0; j < 4; ++j) key_on[j] = del_s[j * 16 + r] != 0.f;
     // ---- next item's loads go out now and land while this item is computed ----
     const int nxt = item + (int)gridDim.x;
     if (nxt < nitems) bwd_load_item<PACK>(p, nxt, tid, x);
