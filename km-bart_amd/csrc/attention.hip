@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
     }
     ASTAMP(7);
     const int row = wave * 16 + r;   // query row of dQ, key row of dK / dV
-    const int rowl = PACK ? (row & 31) : row, hrow = PACK ? h + (row >> 5) : h;   // the row inside its head, and that head
+    const int rowl = PACK ? (row & 31) : row;   // the row inside its head
     const bool q_ok = rowl < p.Tq, k_ok = rowl < p.Tk;
     if (p.dk_colsum != nullptr) {   // uniform branch
 #pragma unroll
@@ -740,27 +740,34 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_small_kernel(const KmbAttn p)
         }
     }
     ASTAMP(8);
-    // (Round 5, measured and dropped: dQ / dK / dV through wave-private rows of the Q / K / V images after one more barrier and out
-    // as whole 128-byte rows, 16 bytes per lane -- six store instructions per wave instead of these twelve 8-byte ones that touch
-    // sixteen 32-byte segments each.  Same bits; encoder shape 223 against 221 us, decoder self 173 against 140, cross 185 against
-    // 173 at b = 1024: the stores were not what the in-order memory pipe waits for -- tools/attn_bwd_stamps.py.)
-    if (q_ok) {
-      bf16_t* qr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dQ) + (((uint32_t)b * (uint32_t)p.Tq + (uint32_t)rowl) * (uint32_t)p.lddq + (uint32_t)(hrow * HD + g * 4)) * 2u);
+    // dQ / dK / dV leave through this wave's 2 KB of the V image (free since the barrier behind the S / dP phase, and 16 rows x 64 columns are
+    // exactly one result tile of the wave): a lane holds four consecutive columns of a row per MFMA tile, i.e. 8-byte pieces of rows 4608 bytes
+    // apart -- twelve store instructions per wave and item, sixteen 32-byte segments each; staged, the wave stores whole 128-byte rows, 16 bytes per
+    // lane: six instructions.  (The first attempt at this -- through the Q / K / V images behind an extra workgroup barrier, at a time when sixteen
+    // loads per wave were what the memory pipe waited for -- measured nothing; with eight loads per wave the stores are the longest phase left.)
+    auto out_tile = [&](const f32x4 (&t)[4], float scale, bf16_t* base, uint32_t ld, int T) {
+      const int srow = wave * 16 + r;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<u32x2*>(qr + j * 16) = u32x2{pack2bf(dq[j][0] * p.dq_scale, dq[j][1] * p.dq_scale),
-                                                       pack2bf(dq[j][2] * p.dq_scale, dq[j][3] * p.dq_scale)};
-    }
-    if (k_ok) {
-      const uint32_t krow = (uint32_t)b * (uint32_t)p.Tk + (uint32_t)rowl;
-      bf16_t* kr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dK) + (krow * (uint32_t)p.lddk + (uint32_t)(hrow * HD + g * 4)) * 2u);
-      bf16_t* vr = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.dV) + (krow * (uint32_t)p.lddv + (uint32_t)(hrow * HD + g * 4)) * 2u);
+        *reinterpret_cast<uint2*>(Vs + elem_off(srow, j * 16 + g * 4)) = uint2{pack2bf(t[j][0] * scale, t[j][1] * scale), pack2bf(t[j][2] * scale, t[j][3] * scale)};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the rows are this wave's own: no workgroup barrier
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<u32x2*>(kr + j * 16) = u32x2{pack2bf(dk[j][0], dk[j][1]), pack2bf(dk[j][2], dk[j][3])};
-        *reinterpret_cast<u32x2*>(vr + j * 16) = u32x2{pack2bf(dv[j][0], dv[j][1]), pack2bf(dv[j][2], dv[j][3])};
+      for (int i = 0; i < 2; ++i) {
+        const int lrow = wave * 16 + (lane >> 3) + 8 * i, c = lane & 7;
+        const int rl = PACK ? (lrow & 31) : lrow, hr = PACK ? h + (lrow >> 5) : h;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Vs + tile_off(lrow, c));
+        if (rl < T)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + (((uint32_t)b * (uint32_t)T + (uint32_t)rl) * ld + (uint32_t)(hr * HD + c * 8)) * 2u) = v;
       }
-    }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next tile overwrites the rows just read)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    out_tile(dq, p.dq_scale, p.dQ, (uint32_t)p.lddq, p.Tq);
+    out_tile(dk, 1.f, p.dK, (uint32_t)p.lddk, p.Tk);
+    out_tile(dv, 1.f, p.dV, (uint32_t)p.lddv, p.Tk);
     ASTAMP(9);
     prev_b = b; prev_h = h;
   }
