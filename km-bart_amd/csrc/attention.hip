@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const KmbAttn p) {
 // are used -- after the next item's loads have been issued -- each of them queued behind those loads in the in-order return
 // path, and the compute of item i waited for the operands of item i + 1 (rounds 2-3: the software pipeline hid nothing
 // whenever a padding mask was given).
-struct FwdRegs { u32x4 q[2], k[2], v[2]; long long mk[4]; };
+struct FwdRegs { u32x4 q[2], k[2], v[2]; long long mk; };   // mk: the key-mask word of key `tid` of the tile (threads 0 .. 63 only)
 
 // PACK (Tq, Tk <= 32, even H): two heads of a batch item per tile, as in the backward (bwd_load_item)
 template <bool PACK>
@@ -221,18 +221,16 @@ __device__ __forceinline__ void fwd_load_item(const KmbAttn& p, int item, int ti
       x.v[i] = *reinterpret_cast<const u32x4*>(p.V + ((size_t)b * p.Tk + tk) * p.ldv + h * HD + c * 8);
     }
   }
-  if (p.key_mask != nullptr) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = PACK ? ((j * 16 + (tid & 15)) & 31) : j * 16 + (tid & 15);
-      x.mk[j] = p.key_mask[(size_t)b * p.Tk + (key < p.Tk ? key : p.Tk - 1)];
-    }
+  if (p.key_mask != nullptr && tid < 64) {   // one load per tile (first wave; key = tid, PACK: keys 32 .. 63 are the second head's = the same batch item's)
+    const int key = PACK ? (tid & 31) : tid;
+    x.mk = p.key_mask[(size_t)b * p.Tk + (key < p.Tk ? key : p.Tk - 1)];
   }
 }
 
 template <bool PACK>
 __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p) {
   __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES + 4 * 2048];
+  __shared__ float msk_s[64];   // key-mask flags of the tile's 64 keys
   char* Qs = smem;
   char* Ks = smem + TILE_BYTES;
   char* Vs = smem + 2 * TILE_BYTES;
@@ -250,8 +248,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
     const u32x4 z = {0u, 0u, 0u, 0u};
     x.q[i] = z; x.k[i] = z; x.v[i] = z;
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) x.mk[j] = 1;
+  x.mk = 1;
   fwd_load_item<PACK>(p, item, tid, x);
   for (; item < nitems; item += gridDim.x) {
     const int b = item / HH, h = PACK ? 2 * (item % HH) : item % HH;   // PACK: the first of the tile's two heads
@@ -264,10 +261,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
       *reinterpret_cast<u32x4*>(Ks + tile_off(row, c)) = x.k[i];
       *reinterpret_cast<u32x4*>(Vs + tile_off(row, c)) = x.v[i];
     }
+    if (tid < 64) msk_s[tid] = x.mk != 0 ? 1.f : 0.f;
     __syncthreads();
     bool key_on[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) key_on[j] = x.mk[j] != 0;
+    for (int j = 0; j < 4; ++j) key_on[j] = msk_s[j * 16 + r] != 0.f;
     const int nxt = item + (int)gridDim.x;   // the next item's loads go out now and land while this one is computed
     if (nxt < nitems) fwd_load_item<PACK>(p, nxt, tid, x);
     if ((PACK ? (q0 & 31) : q0) >= p.Tq) continue;   // wave-uniform: this wave has no query rows (both barriers are at the loop head)
@@ -327,19 +325,32 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
       for (int j = 0; j < 4; ++j)
         o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_cols(Vs, j, kk, r, g), o[j], 0, 0, 0);
     }
+    // O leaves through the wave's own P image (free now): whole 128-byte rows, 16 bytes per lane -- two store instructions per wave where the
+    // accumulator layout (a lane holds ONE column of four rows per MFMA tile) needed sixteen 2-byte ones (round 5, as in the backward)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the P fragments have been read
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float l = group16_sum(l_run[q]);
       const float inv = l > 0.f ? 1.f / l : 0.f;
       const int qt = q0 + g * 4 + q;                                   // row of the tile
       const int qi = PACK ? (qt & 31) : qt, hq = PACK ? h + (qt >> 5) : h;   // the query inside its head, and that head
-      if (qi < p.Tq) {
-        bf16_t* orow = p.O + ((size_t)b * p.Tq + qi) * p.ldo + hq * HD;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) orow[j * 16 + r] = f2bf(o[j][q] * inv);
-        if (r == 0 && p.lse != nullptr)
-          p.lse[((size_t)b * p.H + hq) * p.Tq + qi] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
-      }
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16_t*>(Ps + elem_off(g * 4 + q, j * 16 + r)) = f2bf(o[j][q] * inv);
+      if (qi < p.Tq && r == 0 && p.lse != nullptr)
+        p.lse[((size_t)b * p.H + hq) * p.Tq + qi] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = (lane >> 3) + 8 * i, c = lane & 7;   // row of the wave's 16, 16-byte chunk of its 128 bytes
+      const int qt = q0 + lr;
+      const int qi = PACK ? (qt & 31) : qt, hq = PACK ? h + (qt >> 5) : h;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Ps + tile_off(lr, c));
+      if (qi < p.Tq) *reinterpret_cast<u32x4*>(p.O + ((size_t)b * p.Tq + qi) * p.ldo + hq * HD + c * 8) = v;
     }
   }
 }
