@@ -26,9 +26,9 @@ from kmbart._lib import check, ptr  # noqa: E402
 lib = _lib.load()
 lib.kmb_debug_set_attn_stamps.restype = C.c_int
 lib.kmb_debug_set_attn_stamps.argtypes = [C.c_void_p]
-NAMES = ["wait: previous item's LDS free (barrier)", "registers -> LDS, delta", "barrier", "next item's loads issued",
-         "S, dP MFMAs + softmax gradient + P / dS to LDS", "barrier", "dQ, dK, dV MFMAs", "column sums (DPP)", "dQ / dK / dV stores",
-         "barrier + column-sum write"]
+NAMES = ["wait: previous item's LDS free (barrier; + previous item's column-sum write)", "registers -> LDS", "barrier", "next item's loads issued",
+         "S, dP MFMAs + softmax gradient (+ delta) + P / dS to LDS", "barrier", "dQ, dK, dV MFMAs", "column sums (DPP)",
+         "dQ / dK / dV: staging + stores"]
 B, H, d = int(os.environ.get("B", "1024")), 12, 768
 for name, Tq, Tk, causal in (("enc self", 64, 64, 0), ("dec self", 32, 32, 1), ("cross", 32, 64, 0)):
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -66,7 +66,7 @@ for name, Tq, Tk, causal in (("enc self", 64, 64, 0), ("dec self", 32, 32, 1), (
     for w in range(4096):
         n = int(per_wg[w])
         for it in range(1, n - 1):   # steady state
-            rows.append(s[w, it, :11])
+            rows.append(s[w, it, :10])
     rows = np.array(rows, dtype=np.float64)
     dt = (rows[:, 1:] - rows[:, :-1]) * 0.01
     item = np.array([s[w, it + 1, 0] - s[w, it, 0] for w in range(4096) for it in range(1, int(per_wg[w]) - 1)], dtype=np.float64) * 0.01
