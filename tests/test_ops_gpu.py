@@ -315,10 +315,11 @@ def test_layernorm_fwd_bwd(M, D):
     assert rel_err(db, bfp.grad) < 1e-4
 
 
-def test_layernorm_bwd_dropout_paths():
-    """dy_drop masks the incoming gradient (embedding LN output dropout); out2 is dz under a second mask."""
+@pytest.mark.parametrize("M,D", [(48, 256), (200, 768), (4100, 768)])
+def test_layernorm_bwd_dropout_paths(M, D):
+    """dy_drop masks the incoming gradient (embedding LN output dropout); out2 is dz under a second mask.  (d = 768 with an even row count: the
+    two-rows-per-wave kernel of round 5; 4100 rows: several rows per wave and a ragged last block)"""
     lib = _lib.load()
-    M, D = 48, 256
     z = bf(rnd(M, D, seed=44))
     gamma = torch.ones(D, device=DEV)
     mean, rstd = z.float().mean(-1), (z.float().var(-1, unbiased=False) + 1e-5).rsqrt()
