@@ -182,8 +182,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       }
       nmu = mean[nrow]; nrs = rstd[nrow];
     }
+    // (round 5) the element-wise arithmetic on float2: v_pk_add / v_pk_mul / v_pk_fma do two elements per instruction, and this kernel is bound by
+    // its vector-ALU work (~40 instructions per element: 64 rows per SIMD at ~1 us each are the launch's 70 us), not by its memory instructions
+    // (tools/experiments/ln_bwd_two_rows_per_wave.patch).  Written two-wide by hand: the SLP vectoriser is off for this file's sake (build.py).
+    // The row sums run as (even columns, odd columns) pairs that are added at the end: a different summation order than before (last bits).
     float g[NQ][4], xh[NQ][4];
-    float s1 = 0.f, s2 = 0.f;
+    kmb_f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+    const kmb_f32x2 mu2 = {mu, mu}, rs2 = {rs, rs};
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int c = lane + 64 * i;
@@ -191,33 +196,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const float d4[4] = {lo_bf(cd[i][0]), hi_bf(cd[i][0]), lo_bf(cd[i][1]), hi_bf(cd[i][1])};
         const float z4[4] = {lo_bf(cz[i][0]), hi_bf(cz[i][0]), lo_bf(cz[i][1]), hi_bf(cz[i][1])};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float d = d4[e];
-          if (dy_drop.thr16 != 0u)
-            d = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e), dy_drop.thr16) ? d * dy_drop.scale : 0.f;
-          const float x = (z4[e] - mu) * rs;
-          xh[i][e] = x;
-          dg[i][e] += d * x;
-          db[i][e] += d;
-          const float gg = d * gm[i][e];
-          g[i][e] = gg;
-          s1 += gg;
-          s2 += gg * x;
+        for (int e = 0; e < 4; e += 2) {
+          kmb_f32x2 d = {d4[e], d4[e + 1]};
+          if (dy_drop.thr16 != 0u) {
+            d[0] = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e), dy_drop.thr16) ? d[0] * dy_drop.scale : 0.f;
+            d[1] = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e + 1), dy_drop.thr16) ? d[1] * dy_drop.scale : 0.f;
+          }
+          const kmb_f32x2 x = (kmb_f32x2{z4[e], z4[e + 1]} - mu2) * rs2;
+          xh[i][e] = x[0]; xh[i][e + 1] = x[1];
+          kmb_f32x2 acc = {dg[i][e], dg[i][e + 1]};
+          acc = __builtin_elementwise_fma(d, x, acc);
+          dg[i][e] = acc[0]; dg[i][e + 1] = acc[1];
+          db[i][e] += d[0]; db[i][e + 1] += d[1];
+          const kmb_f32x2 gg = d * kmb_f32x2{gm[i][e], gm[i][e + 1]};
+          g[i][e] = gg[0]; g[i][e + 1] = gg[1];
+          s1v += gg;
+          s2v = __builtin_elementwise_fma(gg, x, s2v);
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { g[i][e] = 0.f; xh[i][e] = 0.f; }
       }
     }
-    const float c1 = wave_sum(s1) / (float)D;
-    const float c2 = wave_sum(s2) / (float)D;
+    const float c1 = wave_sum(s1v[0] + s1v[1]) / (float)D;
+    const float c2 = wave_sum(s2v[0] + s2v[1]) / (float)D;
+    const kmb_f32x2 c1v = {c1, c1}, nc2v = {-c2, -c2};
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int c = lane + 64 * i;
       if (c < nq) {
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        for (int e = 0; e < 4; e += 2) {
+          const kmb_f32x2 t = __builtin_elementwise_fma(kmb_f32x2{xh[i][e], xh[i][e + 1]}, nc2v, kmb_f32x2{g[i][e], g[i][e + 1]} - c1v) * rs2;
+          o[e] = t[0]; o[e + 1] = t[1];
+        }
         u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         *reinterpret_cast<u32x2*>(dz + (size_t)row * D + c * 4) = pk;
         if (out2 != nullptr) {
