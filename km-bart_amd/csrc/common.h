@@ -164,6 +164,14 @@ __device__ __forceinline__ uint32_t kmb_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// the same decision for a PAIR of columns (col even, col + 1) from the pieces a row loop can keep: rowterm = row * 0x9E3779B1u (wave-uniform),
+// colterm = (col >> 1) * 0x85EBCA77u + 0x165667B1u (loop-invariant per lane) -- one hash, no multiply outside it
+__device__ __forceinline__ uint32_t drop_colterm(uint32_t col) { return (col >> 1) * 0x85EBCA77u + 0x165667B1u; }
+__device__ __forceinline__ void drop_keep_pair(uint32_t site_seed, uint32_t rowterm, uint32_t colterm, uint32_t thr16, bool& k0, bool& k1) {
+  const uint32_t h = kmb_hash32(rowterm ^ colterm ^ site_seed);
+  k0 = (h & 0xffffu) >= thr16;
+  k1 = (h >> 16) >= thr16;
+}
 __device__ __forceinline__ bool drop_keep(uint32_t site_seed, uint32_t row, uint32_t col, uint32_t thr16) {
   // one 32-bit hash per PAIR of columns (16 random bits each): callers that walk consecutive columns share it
   const uint32_t h = kmb_hash32((row * 0x9E3779B1u) ^ ((col >> 1) * 0x85EBCA77u + 0x165667B1u) ^ site_seed);

@@ -151,6 +151,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       gm[i][e] = (c < nq) ? gamma[c * 4 + e] : 0.f;
     }
   }
+  uint32_t colterm[NQ][2];   // dropout hash: the column part of each of this lane's column pairs (loop-invariant)
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    colterm[i][0] = drop_colterm((uint32_t)((lane + 64 * i) * 4));
+    colterm[i][1] = drop_colterm((uint32_t)((lane + 64 * i) * 4 + 2));
+  }
+  const float inv_d = 1.0f / (float)D;
   u32x2 nd[NQ], nz[NQ];
   float nmu = 0.f, nrs = 0.f;
   int row = r_begin + wave;
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NQ; ++i) { cd[i] = nd[i]; cz[i] = nz[i]; }
     const float mu = nmu, rs = nrs;
+    const uint32_t rowterm = (uint32_t)row * 0x9E3779B1u;
     const int nrow = row + 4;
     if (nrow < r_end) {
 #pragma unroll
@@ -199,8 +207,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         for (int e = 0; e < 4; e += 2) {
           kmb_f32x2 d = {d4[e], d4[e + 1]};
           if (dy_drop.thr16 != 0u) {
-            d[0] = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e), dy_drop.thr16) ? d[0] * dy_drop.scale : 0.f;
-            d[1] = drop_keep(dy_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e + 1), dy_drop.thr16) ? d[1] * dy_drop.scale : 0.f;
+            bool ka, kb;
+            drop_keep_pair(dy_drop.seed, rowterm, colterm[i][e >> 1], dy_drop.thr16, ka, kb);
+            d[0] = ka ? d[0] * dy_drop.scale : 0.f;
+            d[1] = kb ? d[1] * dy_drop.scale : 0.f;
           }
           const kmb_f32x2 x = (kmb_f32x2{z4[e], z4[e + 1]} - mu2) * rs2;
           xh[i][e] = x[0]; xh[i][e + 1] = x[1];
@@ -218,8 +228,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         for (int e = 0; e < 4; ++e) { g[i][e] = 0.f; xh[i][e] = 0.f; }
       }
     }
-    const float c1 = wave_sum(s1v[0] + s1v[1]) / (float)D;
-    const float c2 = wave_sum(s2v[0] + s2v[1]) / (float)D;
+    const float c1 = wave_sum(s1v[0] + s1v[1]) * inv_d;   // (a multiply by 1 / d, not a division sequence: last bit)
+    const float c2 = wave_sum(s2v[0] + s2v[1]) * inv_d;
     const kmb_f32x2 c1v = {c1, c1}, nc2v = {-c2, -c2};
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -236,9 +246,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         if (out2 != nullptr) {
           if (out2_drop.thr16 != 0u) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              o[e] = drop_keep(out2_drop.seed, (uint32_t)row, (uint32_t)(c * 4 + e), out2_drop.thr16)
-                         ? o[e] * out2_drop.scale : 0.f;
+            for (int e = 0; e < 4; e += 2) {
+              bool ka, kb;
+              drop_keep_pair(out2_drop.seed, rowterm, colterm[i][e >> 1], out2_drop.thr16, ka, kb);
+              o[e] = ka ? o[e] * out2_drop.scale : 0.f;
+              o[e + 1] = kb ? o[e + 1] * out2_drop.scale : 0.f;
+            }
           }
           pk[0] = pack2bf(o[0], o[1]); pk[1] = pack2bf(o[2], o[3]);
           *reinterpret_cast<u32x2*>(out2 + (size_t)row * D + c * 4) = pk;
