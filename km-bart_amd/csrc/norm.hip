@@ -429,7 +429,10 @@ hipError_t kmb_ln_fwd_slabs_launch(const float* slabs, int nslabs, size_t stride
 }
 
 static int ln_bwd_rows_per_block(int M) {
-  int rpb = (M + 1023) / 1024;  // <= 1024 blocks (four per CU; every wave keeps two rows in flight)
+  // <= 768 blocks: THREE per CU is what the kernel's 140 registers allow (round 5: the 1024 blocks of "four per CU" ran as one full round and
+  // a second one a third full -- 75.7 -> 70.7 us for 65536 rows without the second output, tools/ln_bwd_time.py; forcing 128 registers for four per CU
+  // spills and measured 114-137 us with the second output against 101-103); every wave keeps two rows in flight
+  int rpb = (M + 767) / 768;
   if (rpb < 4) rpb = 4;
   return rpb;
 }
