@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_fwd_slabs_kernel(const float* __restri
 // stream (2 reads + 1-2 writes of M x D bf16) and a wave with one row in flight at a time is latency-bound.
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 template <int NQ>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
+__global__ __launch_bounds__(256, NQ <= 3 ? 4 : 1) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, bf16_t* __restrict__ dz,
                                                      bf16_t* __restrict__ out2, KmbDrop dy_drop, KmbDrop out2_drop,
@@ -141,15 +141,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   const int nq = D >> 2;
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(M, r_begin + rows_per_block);
-  float dg[NQ][4], db[NQ][4], ds[NQ][4], gm[NQ][4];
+  float* gam_s = red + 12 * D;   // gamma lives in LDS, three ds_read_b128 per row: 12 registers less = four waves per SIMD (see ln_bwd_rows_per_block)
+  for (int idx = threadIdx.x; idx < D; idx += 256) gam_s[idx] = gamma[idx];
+  __syncthreads();
+  float dg[NQ][4], db[NQ][4], ds[NQ][4];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int c = lane + 64 * i;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dg[i][e] = 0.f; db[i][e] = 0.f; ds[i][e] = 0.f;
-      gm[i][e] = (c < nq) ? gamma[c * 4 + e] : 0.f;
-    }
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; ds[i][e] = 0.f; }
   }
   uint32_t colterm[NQ][2];   // dropout hash: the column part of each of this lane's column pairs (loop-invariant)
 #pragma unroll
@@ -203,6 +202,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       if (c < nq) {
         const float d4[4] = {lo_bf(cd[i][0]), hi_bf(cd[i][0]), lo_bf(cd[i][1]), hi_bf(cd[i][1])};
         const float z4[4] = {lo_bf(cz[i][0]), hi_bf(cz[i][0]), lo_bf(cz[i][1]), hi_bf(cz[i][1])};
+        const f32x4 gq = *reinterpret_cast<const f32x4*>(gam_s + c * 4);
+        const float gm4[4] = {gq[0], gq[1], gq[2], gq[3]};
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           kmb_f32x2 d = {d4[e], d4[e + 1]};
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
           acc = __builtin_elementwise_fma(d, x, acc);
           dg[i][e] = acc[0]; dg[i][e + 1] = acc[1];
           db[i][e] += d[0]; db[i][e + 1] += d[1];
-          const kmb_f32x2 gg = d * kmb_f32x2{gm[i][e], gm[i][e + 1]};
+          const kmb_f32x2 gg = d * kmb_f32x2{gm4[e], gm4[e + 1]};
           g[i][e] = gg[0]; g[i][e + 1] = gg[1];
           s1v += gg;
           s2v = __builtin_elementwise_fma(gg, x, s2v);
@@ -429,10 +430,11 @@ hipError_t kmb_ln_fwd_slabs_launch(const float* slabs, int nslabs, size_t stride
 }
 
 static int ln_bwd_rows_per_block(int M) {
-  // <= 768 blocks: THREE per CU is what the kernel's 140 registers allow (round 5: the 1024 blocks of "four per CU" ran as one full round and
-  // a second one a third full -- 75.7 -> 70.7 us for 65536 rows without the second output, tools/ln_bwd_time.py; forcing 128 registers for four per CU
-  // spills and measured 114-137 us with the second output against 101-103); every wave keeps two rows in flight
-  int rpb = (M + 767) / 768;
+  // <= 1024 blocks: FOUR per CU (16 waves).  The kernel keeps gamma in LDS instead of 12 registers per lane, which brings it to 128 registers
+  // (launch bounds (256, 4), no spills) and its LDS to 13 * D floats = 39 KB at D = 768: four blocks fit both.  Round 5, tools/ln_bwd_time.py,
+  // 65536 rows: 140 registers and 768 blocks (three per CU) 70.7 / 103.5 / 101.5 us (dz only / both masks / out2 mask), now 65.8 / 97.2 / 98.1;
+  // 32768 rows 40.2 / 48.5 / 47.1 -> 40.5 / 46.6 / 44.0.  (Forcing 128 registers WITH gamma in registers spilled: 114-137 us.)
+  int rpb = (M + 1023) / 1024;
   if (rpb < 4) rpb = 4;
   return rpb;
 }
@@ -448,9 +450,13 @@ hipError_t kmb_ln_bwd_launch(const bf16_t* dy, const bf16_t* z, const float* mea
   if ((D & 7) || D > 2048) return hipErrorInvalidValue;
   const int rpb = ln_bwd_rows_per_block(M);
   dim3 grid((M + rpb - 1) / rpb), block(256);
-  const size_t lds = (size_t)4 * 3 * D * sizeof(float);
+  const size_t lds = (size_t)(4 * 3 + 1) * D * sizeof(float);
   const int nq = (D / 4 + 63) / 64;
-#define KMB_LN_BWD(NQ) hipLaunchKernelGGL((ln_bwd_kernel<NQ>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb)
+#define KMB_LN_BWD(NQ)                                                                                                                  \
+  do {                                                                                                                                  \
+    if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((ln_bwd_kernel<NQ>), grid, block, lds, stream, dy, z, mean, rstd, gamma, dz, out2, dy_drop, out2_drop, partials, M, D, rpb); \
+  } while (0)
   if (nq <= 1) KMB_LN_BWD(1);
   else if (nq == 2) KMB_LN_BWD(2);
   else if (nq == 3) KMB_LN_BWD(3);

@@ -289,7 +289,7 @@ def test_attention_decode():
 
 
 # ----------------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize("M,D", [(70, 768), (33, 128), (16, 1024)])
+@pytest.mark.parametrize("M,D", [(70, 768), (33, 128), (16, 1024), (9, 2048)])   # 2048: the widest row the kernels take (106 KB of LDS in backward)
 def test_layernorm_fwd_bwd(M, D):
     lib = _lib.load()
     z = bf(rnd(M, D, seed=40) * 2 + 0.3)
