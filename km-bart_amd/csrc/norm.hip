@@ -67,6 +67,77 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// Training shapes (tens of thousands of rows): the same row arithmetic as ln_fwd_kernel (same operations in the same order: same bits), but
+// a wave keeps gamma / beta in registers and walks rows w, w + W, ... with the next row's load in flight.  ln_fwd_kernel gives every row its
+// own wave, and that wave issues 4 * NCH parameter loads beside its NCH row loads: ten loads and four stores to move 3 KB at d = 768 -- the
+// kernel sat at 4.1 TB/s with eight waves per SIMD (round 5: the count of memory instructions per wave is what such kernels are bound by,
+// DESIGN.md section 4, attention study).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_stream_kernel(const bf16_t* __restrict__ z, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int W = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = D >> 3;
+  int cc[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) cc[i] = lane + 64 * i < nch ? lane + 64 * i : 0;
+  u32x4 nxt[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) nxt[i] = *reinterpret_cast<const u32x4*>(z + (size_t)row * D + cc[i] * 8);
+  f32x4 gv[NCH][2], bv[NCH][2];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    gv[i][0] = *reinterpret_cast<const f32x4*>(gamma + cc[i] * 8); gv[i][1] = *reinterpret_cast<const f32x4*>(gamma + cc[i] * 8 + 4);
+    bv[i][0] = *reinterpret_cast<const f32x4*>(beta + cc[i] * 8); bv[i][1] = *reinterpret_cast<const f32x4*>(beta + cc[i] * 8 + 4);
+  }
+  for (; row < M; row += W) {
+    u32x4 raw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
+    if (row + W < M) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) nxt[i] = *reinterpret_cast<const u32x4*>(z + (size_t)(row + W) * D + cc[i] * 8);
+    }
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (lane + 64 * i < nch) {
+        unpack8(raw[i], v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+      }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * gv[i][e >> 2][e & 3] + bv[i][e >> 2][e & 3];
+        *reinterpret_cast<u32x4*>(y + (size_t)row * D + c * 8) = pack8(o);
+      }
+    }
+  }
+}
+
 // Decode path: the split-K slabs of a residual projection are summed, bias and residual added, the sum rounded to
 // bf16 (what the un-split GEMM epilogue stores and ln_fwd_kernel reads) and normalised -- one launch instead of the
 // GEMM epilogue + LayerNorm pair, and the 320-row GEMM in front of it gets nslabs times as many workgroups.
@@ -412,6 +483,10 @@ hipError_t kmb_ln_fwd_launch(const bf16_t* z, const float* gamma, const float* b
   if ((D & 7) || D > 2048) return hipErrorInvalidValue;
   if (((uintptr_t)z & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)y & 15)) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
+  if (M >= 8192 && D > 512 && D <= 1024) {   // rows streamed through resident waves (2048 workgroups = eight waves per SIMD), parameters in registers
+    hipLaunchKernelGGL((ln_fwd_stream_kernel<2>), dim3(grid.x < 2048 ? grid.x : 2048), block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
+    return hipGetLastError();
+  }
   if (D <= 512) hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
   else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);
   else hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, stream, z, gamma, beta, y, mean, rstd, M, D, eps);

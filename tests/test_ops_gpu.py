@@ -315,6 +315,28 @@ def test_layernorm_fwd_bwd(M, D):
     assert rel_err(db, bfp.grad) < 1e-4
 
 
+def test_layernorm_fwd_streamed_rows_same_bits():
+    """>= 8192 rows go through ln_fwd_stream_kernel (resident waves, parameters in registers): the same bits as the one-row-per-wave kernel
+    that the two halves of the same rows take."""
+    lib = _lib.load()
+    M, D = 8200 + 8192 * 3 + 5, 768   # some waves walk four rows, some five
+    z = bf(rnd(M, D, seed=44) * 3 - 0.2)
+    gamma, beta = rnd(D, seed=45) * 0.1 + 1.0, rnd(D, seed=46) * 0.1
+    outs = []
+    for pieces in (1, 8):
+        y = torch.zeros_like(z)
+        mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+        step = (M + pieces - 1) // pieces
+        assert pieces == 1 or step < 8192
+        for r0 in range(0, M, step):
+            n = min(step, M - r0)
+            check(lib.kmb_op_ln_fwd(ptr(z[r0:]), ptr(gamma), ptr(beta), ptr(y[r0:]), ptr(mean[r0:]), ptr(rstd[r0:]), n, D, 1e-5, stream()))
+        outs.append((y, mean, rstd))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert rel_err(outs[0][0], F.layer_norm(z.float(), (D,), gamma, beta, 1e-5)) < BF_TOL
+
+
 @pytest.mark.parametrize("M,D", [(48, 256), (200, 768), (4100, 768)])
 def test_layernorm_bwd_dropout_paths(M, D):
     """dy_drop masks the incoming gradient (embedding LN output dropout); out2 is dz under a second mask.  (d = 768 with an even row count: the

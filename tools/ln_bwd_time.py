@@ -1,4 +1,4 @@
-"""Time the LayerNorm backward (csrc/norm.hip ln_bwd_kernel) at the training shapes: rows = batch x 64 / 32 tokens, d = 768, with and without the second
+"""Time the LayerNorm forward and backward (csrc/norm.hip ln_fwd_stream_kernel, ln_bwd_kernel) at the training shapes: rows = batch x 64 / 32 tokens, d = 768, with and without the second
 (dropout-masked) output; prints microseconds and TB/s of the bytes it has to move (dy, z in; dz [, out2] out).  B=1024 python tools/ln_bwd_time.py"""
 import ctypes as C
 import os
@@ -26,6 +26,20 @@ for rows in (B * 64, B * 32):
     dg, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
     scratch = torch.empty(int(lib.kmb_op_ln_bwd_scratch(rows, D)), device=DEV)
     d1, d2 = KmbDrop(thr, 77, sc), KmbDrop(thr, 99, sc)
+    beta = torch.zeros(D, device=DEV)
+    zs = [z] + [z.clone() for _ in range(3)]   # four row sets in turn: 800 MB at 65536 rows, so the rows come from HBM and not from the 256 MB Infinity Cache
+    ys = [torch.empty_like(z) for _ in range(4)]
+    for k in range(4):
+        check(lib.kmb_op_ln_fwd(ptr(zs[k]), ptr(gamma), ptr(beta), ptr(ys[k]), ptr(mean), ptr(rstd), rows, D, 1e-5, stream()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(20):
+        check(lib.kmb_op_ln_fwd(ptr(zs[k & 3]), ptr(gamma), ptr(beta), ptr(ys[k & 3]), ptr(mean), ptr(rstd), rows, D, 1e-5, stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 50.0
+    print(f"rows {rows:6d}  {'forward (four row sets in turn)':32s} {us:7.1f} us  {rows * D * 4 / us * 1e-6:.2f} TB/s")
+    del zs, ys
     for name, o2, dr1, dr2 in (("dz only, no dropout", None, None, None), ("dz + out2, both dropout masks", out2, d1, d2), ("dz + out2, out2 mask only", out2, None, d2)):
         def run():
             check(lib.kmb_op_ln_bwd(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), ptr(o2), C.byref(dr1) if dr1 else None,
