@@ -208,22 +208,29 @@ template <bool PACK>
 __device__ __forceinline__ void fwd_load_item(const KmbAttn& p, int item, int tid, FwdRegs& x) {
   const int HH = PACK ? (p.H >> 1) : p.H;
   const int b = item / HH, h0 = PACK ? 2 * (item % HH) : item % HH;
+  // The mask word FIRST, and 32-bit byte offsets as in bwd_load_item (the launcher sends tensors that reach 4 GB to the general kernel).  Late
+  // round 5: with 64-bit per-lane addresses the one-head kernel sat at 128 registers with the mask's lane address spilled, and its reload in
+  // front of the mask load -- the LAST load of this function -- came with `s_waitcnt vmcnt(0)`: the first wave waited there for the Q / K / V
+  // loads it had just issued for the NEXT item before it started the current one, and the other three waited for it at the next barrier.
+  if (p.key_mask != nullptr && tid < 64) {   // one load per tile (first wave; key = tid, PACK: keys 32 .. 63 are the second head's = the same batch item's)
+    const int key = PACK ? (tid & 31) : tid;
+    x.mk = p.key_mask[(uint32_t)b * (uint32_t)p.Tk + (uint32_t)(key < p.Tk ? key : p.Tk - 1)];
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + 256 * i;
     const int row = PACK ? ((id >> 3) & 31) : (id >> 3), c = id & 7;
     const int h = PACK ? h0 + i : h0;
     const int tq = row < p.Tq ? row : p.Tq - 1, tk = row < p.Tk ? row : p.Tk - 1;
+    const uint32_t rq = (uint32_t)b * (uint32_t)p.Tq + (uint32_t)tq, rk = (uint32_t)b * (uint32_t)p.Tk + (uint32_t)tk;
+    const uint32_t hc = (uint32_t)(h * HD + c * 8);
+    auto at = [](const bf16_t* base, uint32_t elem) { return reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + elem * 2u); };
     // rows 32 .. 63 (i = 1) of a tile that holds at most 32 rows are never fetched: their LDS rows stay zero
-    if (PACK || i == 0 || p.Tq > 32) x.q[i] = *reinterpret_cast<const u32x4*>(p.Q + ((size_t)b * p.Tq + tq) * p.ldq + h * HD + c * 8);
+    if (PACK || i == 0 || p.Tq > 32) x.q[i] = *at(p.Q, rq * (uint32_t)p.ldq + hc);
     if (PACK || i == 0 || p.Tk > 32) {
-      x.k[i] = *reinterpret_cast<const u32x4*>(p.K + ((size_t)b * p.Tk + tk) * p.ldk + h * HD + c * 8);
-      x.v[i] = *reinterpret_cast<const u32x4*>(p.V + ((size_t)b * p.Tk + tk) * p.ldv + h * HD + c * 8);
+      x.k[i] = *at(p.K, rk * (uint32_t)p.ldk + hc);
+      x.v[i] = *at(p.V, rk * (uint32_t)p.ldv + hc);
     }
-  }
-  if (p.key_mask != nullptr && tid < 64) {   // one load per tile (first wave; key = tid, PACK: keys 32 .. 63 are the second head's = the same batch item's)
-    const int key = PACK ? (tid & 31) : tid;
-    x.mk = p.key_mask[(size_t)b * p.Tk + (key < p.Tk ? key : p.Tk - 1)];
   }
 }
 
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
   const int HH = PACK ? (p.H >> 1) : p.H;
   const int nitems = p.B * HH;
   const int q0 = wave * 16;
+  const bool lse_vec = (p.Tq & 3) == 0 && ((uintptr_t)p.lse & 15) == 0;   // a lane's four log-sum-exps are one aligned 16-byte piece
   int item = blockIdx.x;
   if (item >= nitems) return;
   FwdRegs x;
@@ -330,16 +338,26 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_small_kernel(const KmbAttn p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the P fragments have been read
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 lv;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float l = group16_sum(l_run[q]);
       const float inv = l > 0.f ? 1.f / l : 0.f;
-      const int qt = q0 + g * 4 + q;                                   // row of the tile
-      const int qi = PACK ? (qt & 31) : qt, hq = PACK ? h + (qt >> 5) : h;   // the query inside its head, and that head
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16_t*>(Ps + elem_off(g * 4 + q, j * 16 + r)) = f2bf(o[j][q] * inv);
-      if (qi < p.Tq && r == 0 && p.lse != nullptr)
-        p.lse[((size_t)b * p.H + hq) * p.Tq + qi] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
+      lv[q] = l > 0.f ? m_run[q] + __logf(l) : -INFINITY;
+    }
+    if (r == 0 && p.lse != nullptr) {   // the log-sum-exps of this lane's four rows (consecutive queries of one head): ONE 16-byte store where the
+      const int qt = q0 + g * 4;        // layout allows it instead of four 4-byte ones (a wave issued 4 + 2 stores per item, now 1 + 2)
+      const int qi = PACK ? (qt & 31) : qt, hq = PACK ? h + (qt >> 5) : h;   // the first query inside its head, and that head
+      float* dst = p.lse + ((size_t)b * p.H + hq) * p.Tq + qi;
+      if (lse_vec) {
+        if (qi < p.Tq) *reinterpret_cast<f32x4*>(dst) = lv;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (qi + q < p.Tq) dst[q] = lv[q];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -887,7 +905,11 @@ const char* kmb_attn_check(const KmbAttn& p, int backward) {
 
 hipError_t kmb_attn_fwd_launch(const KmbAttn& p, hipStream_t stream) {
   static const bool small_ok = !(KMB_DIAG_ENV("KMB_ATTN_FWD_SMALL") && KMB_DIAG_ENV("KMB_ATTN_FWD_SMALL")[0] == '0');
-  if (small_ok && p.Tq <= 64 && p.Tk <= 64 && p.B * p.H >= 1024) {   // one query tile, one key tile, enough items to pipeline
+  // (the single-tile kernel's 32-bit byte offsets: every tensor below 4 GB)
+  int ld_max = p.ldq;
+  for (int l : {p.ldk, p.ldv, p.ldo}) ld_max = l > ld_max ? l : ld_max;
+  const bool fits32 = (size_t)p.B * (size_t)(p.Tq > p.Tk ? p.Tq : p.Tk) * (size_t)ld_max * 2 < ((size_t)1 << 32);
+  if (small_ok && p.Tq <= 64 && p.Tk <= 64 && p.B * p.H >= 1024 && fits32) {   // one query tile, one key tile, enough items to pipeline
     static const bool pack_ok = !(KMB_DIAG_ENV("KMB_ATTN_PACK") && KMB_DIAG_ENV("KMB_ATTN_PACK")[0] == '0');
     const bool pack = pack_ok && p.Tq <= 32 && p.Tk <= 32 && (p.H & 1) == 0;   // two heads per tile (32-token self-attention)
     const int items = pack ? p.B * (p.H >> 1) : p.B * p.H;
