@@ -319,7 +319,7 @@ def test_layernorm_fwd_streamed_rows_same_bits():
     """>= 8192 rows go through ln_fwd_stream_kernel (resident waves, parameters in registers): the same bits as the one-row-per-wave kernel
     that the two halves of the same rows take."""
     lib = _lib.load()
-    M, D = 8200 + 8192 * 3 + 5, 768   # some waves walk four rows, some five
+    M, D = 8200 + 8192 * 3 + 5, 768   # the resident waves walk six or seven rows each
     z = bf(rnd(M, D, seed=44) * 3 - 0.2)
     gamma, beta = rnd(D, seed=45) * 0.1 + 1.0, rnd(D, seed=46) * 0.1
     outs = []
