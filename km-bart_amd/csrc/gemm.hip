@@ -170,7 +170,39 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const u32x4 (&reg
 }
 
 // fragment for MFMA 16x16x32: 16 rows (r = lane&15) x 32 k (8 per lane group g = lane>>4)
-template <bool KC>
+// The transposing LDS reads (`ds_read_b64_tr_b16`, the token-major operand of the data- and weight-gradient layouts) as INLINE ASM (late round 5).
+// hipcc puts `s_waitcnt vmcnt(0)` in front of the first __builtin_amdgcn_ds_read_tr16_b64 behind an LDS-DMA issue: the intrinsic carries no memory
+// operand, so the wait-count pass assumes it may read what the DMA is writing.  The K loops issue the NEXT stage's DMA pieces and then read fragments
+// of the CURRENT one -- so in every kernel with a token-major operand the stage requested a moment ago was waited for at once: prefetch distance
+// zero, two such stalls per K step in the weight-gradient kernel (found on the ISA: one counted wait per step in the K-contiguous kernels, two or
+// three vmcnt(0) in the others; their matrix pipes were busy 29-40 % against 42 %).  As asm the compiler sees neither an LDS read (no wait in
+// front) nor its result's latency (no wait before the use): the consumers' wait is an explicit `s_waitcnt lgkmcnt(0)` at the top of every
+// sub-phase (KMB_TR_SYNC, fenced by sched_barriers: fragments are always consumed one sub-phase after they are requested) and behind the K loop of
+// the persistent kernels (the next tile's first fragments live across the epilogue).  Sound only if no instruction names such a register between
+// the read and the wait -- a property of the compiled code: tools/gemm_tr_asm_hazards.py walks the ISA's control-flow graph, and
+// tests/test_cabi_cpu.py::test_gemm_asm_transposing_reads_are_waited_for runs it on every build.  Same arithmetic in the same order: outputs
+// bit-identical to the intrinsic's (tools/gemm_tr_asm_ab.py: md5 per shape).  Kernels: v7 (+ the grouped weight gradients), v8, v11 with 256-wide
+// tiles (four and eight waves) -- the ones compared on the GPU when this went in; v7d, the 128- / 192-wide v11 tiles and gemm_lean.hip keep the
+// intrinsic (gemm_lean.hip: with asm reads the allocator hands out v255, which its L2 touch owns -- outputs that changed from run to run in
+// tools/gemm_tr_asm_ab.py; tests/test_cabi_cpu.py::test_lean_gemm_never_allocates_v255 is the check for that).
+// -DKMB_TR_BUILTIN: the intrinsic everywhere (A/B builds).  profiles/r05_gemm_transposing_reads_asm.md.
+#ifndef KMB_TR_BUILTIN
+__device__ __forceinline__ s16x4 kmb_tr_read_asm(const char* ptr) {
+  s16x4 t;
+  const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)ptr;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(t) : "v"(a));
+  return t;
+}
+#define KMB_TR_SYNC()                                   \
+  do {                                                  \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+#else
+#define KMB_TR_SYNC() do { } while (0)
+#endif
+template <bool KC, bool ASM = false>
 __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int kk, int r, int g) {
   if (KC) {
     const int row = rowtile16 * 16 + r;
@@ -182,8 +214,12 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowtile16, int 
     for (int hh = 0; hh < 2; ++hh) {
       const int krow = kk * 32 + g * 8 + hh * 4 + (r >> 2);
       const int off = krow * 256 + ((rowtile16 ^ swz_nkc(krow)) << 5) + ((r & 3) << 3);
+#ifndef KMB_TR_BUILTIN
+      const s16x4 t = ASM ? kmb_tr_read_asm(lds + off) : __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + off));
+#else
       const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) s16x4*)(lds + off));
+#endif
       out[hh * 4 + 0] = t[0]; out[hh * 4 + 1] = t[1]; out[hh * 4 + 2] = t[2]; out[hh * 4 + 3] = t[3];
     }
     return out;
@@ -645,19 +681,20 @@ __device__ __forceinline__ void v7_tile(const KmbGemm& p, char* smem, int block,
   __syncthreads();
   KMB_STAMP(1);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(smem, wm * 4 + i, 0, r, g);
+  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC, true>(smem, wm * 4 + i, 0, r, g);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(smem + A_TILE, wn * 4 + j, 0, r, g);
+  for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC, true>(smem + A_TILE, wn * 4 + j, 0, r, g);
 
   constexpr int NDS = (A_KC ? 4 : 8) + (B_KC ? 4 : 8);  // ds_read instructions per fragment set
   auto kstep = [&](int t, auto do_dma, auto do_next) {
     const char* cur = smem + (t & 1) * STAGE_BYTES;
     const char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
     // ---- phase A ----
+    if constexpr (!(A_KC && B_KC)) KMB_TR_SYNC();   // the (asm-read) fragments requested in phase B of the previous step have arrived
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa1[i] = read_frag<A_KC>(cur, wm * 4 + i, 1, r, g);
+    for (int i = 0; i < 4; ++i) fa1[i] = read_frag<A_KC, true>(cur, wm * 4 + i, 1, r, g);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb1[j] = read_frag<B_KC>(cur + A_TILE, wn * 4 + j, 1, r, g);
+    for (int j = 0; j < 4; ++j) fb1[j] = read_frag<B_KC, true>(cur + A_TILE, wn * 4 + j, 1, r, g);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -679,9 +716,9 @@ __device__ __forceinline__ void v7_tile(const KmbGemm& p, char* smem, int block,
     // ---- phase B ----  (the DMA overwrites LDS the fragment reads may alias: reads first, DMA pieces behind them)
     if (decltype(do_next)::value) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(nxt, wm * 4 + i, 0, r, g);
+      for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC, true>(nxt, wm * 4 + i, 0, r, g);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(nxt + A_TILE, wn * 4 + j, 0, r, g);
+      for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC, true>(nxt + A_TILE, wn * 4 + j, 0, r, g);
     }
     if (decltype(do_dma)::value) dma_stage(t + 2, t & 1);
 #pragma unroll
@@ -936,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_wgrad_kernel(const KmbGemmG
 // ------------------------------------------------------------------------------------------
 // fragment reads for tiles that are 256 rows (columns) tall (v8)
 
-template <bool KC, int ROWS>
+template <bool KC, int ROWS, bool ASM = false>
 __device__ __forceinline__ bf16x8 read_frag3(const char* lds, int rowtile16, int kk, int r, int g) {
   if (KC) {
     const int row = rowtile16 * 16 + r;
@@ -948,8 +985,12 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* lds, int rowtile16, int
     for (int hh = 0; hh < 2; ++hh) {
       const int krow = kk * 32 + g * 8 + hh * 4 + (r >> 2);
       const int off = krow * (ROWS * 2) + ((rowtile16 ^ swz_nkc(krow)) << 5) + ((r & 3) << 3);
+#ifndef KMB_TR_BUILTIN
+      const s16x4 t = ASM ? kmb_tr_read_asm(lds + off) : __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + off));
+#else
       const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) s16x4*)(lds + off));
+#endif
       out[hh * 4 + 0] = t[0]; out[hh * 4 + 1] = t[1]; out[hh * 4 + 2] = t[2]; out[hh * 4 + 3] = t[3];
     }
     return out;
@@ -1059,11 +1100,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
   [[maybe_unused]] uint64_t kmb_wait_ticks = 0;  // diagnostic build only
   auto read_a = [&](const char* stage, int kk, int half, bf16x8 (&dst)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * 8 + half * 4 + i, kk, r, g);
+    for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4, true>(stage, wm * 8 + half * 4 + i, kk, r, g);
   };
   auto read_b = [&](const char* stage, int kk, bf16x8 (&dst)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dst[j] = read_frag3<B_KC, BN4>(stage + A_BYTES, wn * 4 + j, kk, r, g);
+    for (int j = 0; j < 4; ++j) dst[j] = read_frag3<B_KC, BN4, true>(stage + A_BYTES, wn * 4 + j, kk, r, g);
   };
   auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
 #pragma unroll
@@ -1090,6 +1131,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
     const char* cur = smem + (t & 1) * ST4;
     const char* nxt = smem + ((t + 1) & 1) * ST4;
     // ---- sub-phase 0 ----
+    if constexpr (!(A_KC && B_KC)) KMB_TR_SYNC();   // the (asm-read) fragments requested in the previous sub-phase have arrived
     read_a(cur, 0, 1, fa[1]);
     if (decltype(do_next)::value) dma_b(t + 1, (t + 1) & 1);   // B half of stage t+1 (its A half: previous sub-phase 3)
     mma(0, fa[0], fb[0]);
@@ -1115,6 +1157,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- sub-phase 1 ----
+    if constexpr (!(A_KC && B_KC)) KMB_TR_SYNC();
     read_b(cur, 1, fb[1]);
     read_a(cur, 1, 0, fa[0]);
     mma(1, fa[1], fb[0]);
@@ -1124,6 +1167,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- sub-phase 2 ----
+    if constexpr (!(A_KC && B_KC)) KMB_TR_SYNC();
     read_a(cur, 1, 1, fa[1]);
     mma(0, fa[0], fb[1]);
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
@@ -1907,7 +1951,18 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   const int rm_l = (g * 8 + (r >> 2)) * (BIMG * 2) + ((r & 3) << 3);
   const int rm_nb = rm_l | (rm_sw << 5);                                                   // bits 5-8 of rm_l are zero
   const int rm_na = ((g * 8 + (r >> 2)) * (BM4 * 2) + ((r & 3) << 3)) | (rm_sw << 5);
+  // inline-asm transposing reads (kmb_tr_read_asm): the 256-wide tiles only -- the kernels whose outputs were compared bit for bit with the
+  // intrinsic's on the GPU when this went in (tools/gemm_tr_asm_ab.py, launch variants 11 and 14); 128 / 192 keep the intrinsic
+#ifndef KMB_TR_BUILTIN
+  constexpr bool TRASM = BNT == 256 && !(A_KC && B_KC);
+#else
+  constexpr bool TRASM = false;
+#endif
   auto tr_read = [&](const char* ptr) {
+#ifndef KMB_TR_BUILTIN
+    if constexpr (TRASM) return kmb_tr_read_asm(ptr);
+    else
+#endif
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
   };
   auto read_a = [&](const char* stage, int kk, int half, bf16x8 (&dst)[4]) {
@@ -1931,7 +1986,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4>(stage, wm * (MH * 4) + half * 4 + i, kk, r, g);
+      for (int i = 0; i < 4; ++i) dst[i] = read_frag3<A_KC, BM4, TRASM>(stage, wm * (MH * 4) + half * 4 + i, kk, r, g);
     }
   };
   auto read_b = [&](const char* stage, int kk, bf16x8 (&dst)[NJ]) {
@@ -1955,7 +2010,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) dst[j] = read_frag3<B_KC, BIMG>(stage + A_BYTES, wn * NJ + j, kk, r, g);
+      for (int j = 0; j < NJ; ++j) dst[j] = read_frag3<B_KC, BIMG, TRASM>(stage + A_BYTES, wn * NJ + j, kk, r, g);
     }
   };
 #ifdef KMB_V11_MFMA32_TIMING
@@ -2035,6 +2090,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
       if (dyn && t == 1 && tid == 0) *next_slot = dyn_base + (int)fetched;
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): k0 fragments of this stage (needed now anyway; a known-empty
                                            // LDS queue here lets the compiler count the waits below exactly)
+      if constexpr (TRASM) KMB_TR_SYNC();
       const char* cur = smem + (it & 1) * STG;
       const char* nxt = smem + ((it + 1) & 1) * STG;
       if constexpr (MH == 2) {
@@ -2056,6 +2112,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- sub-phase 1: A(k0, rows 64-127) x B(k0)  ||  read B(k1), A(k1, rows 0-63) ----
+      if constexpr (TRASM) KMB_TR_SYNC();
       read_b(cur, 1, fb[1]);
       read_a(cur, 1, 0, fa[0]);
       dma_b((it + 1) & 1, NB3 + NB0, NPB);
@@ -2103,6 +2160,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- sub-phase 2: A(k1, rows 0-63) x B(k1)  ||  read A(k1, rows 64-127); stage it+1 landed, barrier ----
+      if constexpr (TRASM) KMB_TR_SYNC();
       read_a(cur, 1, 1, fa[1]);
       mma(0, fa[0], fb[1]);
       __builtin_amdgcn_sched_group_barrier(0x008, KMB_MF(8), 2);
@@ -2182,6 +2240,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
         for (int e = 0; e < 4; ++e) acc[i][j][e] = acc32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + e];
 #endif
     // ---- epilogue of this tile (the next tile's first two stages are in flight / resident meanwhile) ----
+    if constexpr (TRASM) KMB_TR_SYNC();   // the next tile's first fragments (asm reads of the last sub-phase) live across the epilogue: arrived before anything moves them
     [[maybe_unused]] const uint64_t kmb_t_epi = KMB_NOW();
     int tm, tn;
     decode_tile(tile, tm, tn);

@@ -176,3 +176,23 @@ def test_lean_gemm_never_allocates_v255(tmp_path):
         elif use.search(code):
             others.append(code)
     assert kernels >= 6, "expected the lean GEMM kernels with their touches, found %d" % kernels
+
+
+def test_gemm_asm_transposing_reads_are_waited_for(tmp_path):
+    """csrc/gemm.hip reads its token-major operands with `ds_read_b64_tr_b16` as INLINE ASM in the 128 x 128, 256 x 256 and persistent 256-wide
+    kernels (kmb_tr_read_asm: the intrinsic makes hipcc wait with vmcnt(0) behind every LDS-DMA issue, i.e. for the stage requested a moment ago).
+    The compiler then does not know that those registers arrive later: between such a read and the next `s_waitcnt lgkmcnt(0)` no instruction may
+    name them (KMB_TR_SYNC at the top of every sub-phase).  A property of the COMPILED code: compile to ISA (no GPU) and walk every kernel's
+    control-flow graph (tools/gemm_tr_asm_hazards.py)."""
+    import subprocess
+    import sys
+    src = os.path.join(ROOT, "km-bart_amd", "csrc", "gemm.hip")
+    out = str(tmp_path / "gemm.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-I" + os.path.join(ROOT, "km-bart_amd", "csrc"), "-I" + os.path.join(ROOT, "include")]
+    subprocess.check_call(["hipcc", "-x", "hip"] + flags + ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_tr_asm_hazards.py"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    checked = [l for l in r.stdout.splitlines() if "transposing reads" in l]
+    assert len(checked) >= 9, "expected the kernels with inline-asm reads, found %d:\n%s" % (len(checked), r.stdout[-2000:])
+    assert "total violations 0" in r.stdout
