@@ -186,6 +186,12 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const u32x4 (&reg
 // intrinsic (gemm_lean.hip: with asm reads the allocator hands out v255, which its L2 touch owns -- outputs that changed from run to run in
 // tools/gemm_tr_asm_ab.py; tests/test_cabi_cpu.py::test_lean_gemm_never_allocates_v255 is the check for that).
 // -DKMB_TR_BUILTIN: the intrinsic everywhere (A/B builds).  profiles/r05_gemm_transposing_reads_asm.md.
+// -DKMB_TR_ASM_ALL (experiment build for round 6, statically checked, never run on a GPU yet): also the four-stage kernel and the 128- / 192-wide v11 tiles.
+#if defined(KMB_TR_ASM_ALL) && !defined(KMB_TR_BUILTIN)
+constexpr bool KMB_TR_ALL = true;
+#else
+constexpr bool KMB_TR_ALL = false;
+#endif
 #ifndef KMB_TR_BUILTIN
 __device__ __forceinline__ s16x4 kmb_tr_read_asm(const char* ptr) {
   s16x4 t;
@@ -844,9 +850,9 @@ __device__ __forceinline__ void v7d_tile(const KmbGemm& p, char* smem, int block
   __builtin_amdgcn_s_barrier();   // (not __syncthreads(): its fence is a vmcnt(0) -- the three younger stages stay in flight here)
   KMB_STAMP(1);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(smem, wm * 4 + i, 0, r, g);
+  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC, KMB_TR_ALL>(smem, wm * 4 + i, 0, r, g);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(smem + A_TILE, wn * 4 + j, 0, r, g);
+  for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC, KMB_TR_ALL>(smem + A_TILE, wn * 4 + j, 0, r, g);
 
   constexpr int NDS = (A_KC ? 4 : 8) + (B_KC ? 4 : 8);  // ds_read instructions per fragment set
   // in_flight: stages younger than t + 1 that may still be outstanding at this step's wait (2, 1 or 0)
@@ -854,10 +860,11 @@ __device__ __forceinline__ void v7d_tile(const KmbGemm& p, char* smem, int block
     const char* cur = smem + (t & 3) * STAGE_BYTES;
     const char* nxt = smem + ((t + 1) & 3) * STAGE_BYTES;
     // ---- phase A ----
+    if constexpr (KMB_TR_ALL && !(A_KC && B_KC)) KMB_TR_SYNC();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa1[i] = read_frag<A_KC>(cur, wm * 4 + i, 1, r, g);
+    for (int i = 0; i < 4; ++i) fa1[i] = read_frag<A_KC, KMB_TR_ALL>(cur, wm * 4 + i, 1, r, g);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb1[j] = read_frag<B_KC>(cur + A_TILE, wn * 4 + j, 1, r, g);
+    for (int j = 0; j < 4; ++j) fb1[j] = read_frag<B_KC, KMB_TR_ALL>(cur + A_TILE, wn * 4 + j, 1, r, g);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -882,9 +889,9 @@ __device__ __forceinline__ void v7d_tile(const KmbGemm& p, char* smem, int block
     // ---- phase B ----  (the DMA overwrites LDS the fragment reads may alias: reads first, DMA pieces behind them)
     if (decltype(do_next)::value) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC>(nxt, wm * 4 + i, 0, r, g);
+      for (int i = 0; i < 4; ++i) fa0[i] = read_frag<A_KC, KMB_TR_ALL>(nxt, wm * 4 + i, 0, r, g);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC>(nxt + A_TILE, wn * 4 + j, 0, r, g);
+      for (int j = 0; j < 4; ++j) fb0[j] = read_frag<B_KC, KMB_TR_ALL>(nxt + A_TILE, wn * 4 + j, 0, r, g);
     }
     if (decltype(do_dma)::value) dma_stage(t + 4, t & 3);   // into the buffer this step has just read for the last time
 #pragma unroll
@@ -1954,7 +1961,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   // inline-asm transposing reads (kmb_tr_read_asm): the 256-wide tiles only -- the kernels whose outputs were compared bit for bit with the
   // intrinsic's on the GPU when this went in (tools/gemm_tr_asm_ab.py, launch variants 11 and 14); 128 / 192 keep the intrinsic
 #ifndef KMB_TR_BUILTIN
-  constexpr bool TRASM = BNT == 256 && !(A_KC && B_KC);
+  constexpr bool TRASM = (BNT == 256 || KMB_TR_ALL) && !(A_KC && B_KC);
 #else
   constexpr bool TRASM = false;
 #endif
