@@ -93,6 +93,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- LDS-DMA: kernel-constant lane offsets (interior tiles), scalar tile bases; the cursor runs two steps ahead ----
   constexpr int NPW = 4;
+  // -DKMB_TR_ASM_ALL (experiment build for round 6; gemm.hip, kmb_tr_read_asm): the token-major B's transposing reads as inline asm.  With them the
+  // allocator hands out v255, which the L2 touch owns (outputs changed from run to run, profiles/r05_gemm_transposing_reads_asm.md), so that build
+  // drops the touch in the token-major kernels (their waits then leave nothing outstanding).  Never run on a GPU yet; the product build is unchanged.
+  constexpr bool TRASM = KMB_TR_ALL && !B_KC;
+  constexpr bool TOUCH = !TRASM;
   uint32_t offA[NPW], offB[NPW];
   dma_offsets256w4<true, 4>(offA, p.lda, 0, 1 << 30, wave, lane);
   dma_offsets256w4<B_KC, 4>(offB, p.ldb, 0, 1 << 30, wave, lane);
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 4; ++i) dma_piece(gA_d, offA[i], da + i * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_piece(gB_d, offB[i], db + i * 1024);
-    {
+    if constexpr (TOUCH) {
       const int ps = td + LN_PFD;
       const bool nx = ps >= nt;
       const char* sbase = ln_uniform((nx ? gA_nx : gA_tile) + (size_t)(nx ? ps - nt : ps) * (BK * 2));
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   auto read_b = [&](const char* st, int kk, bf16x8 (&d)[NJ]) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) d[j] = read_frag3<B_KC, 256>(st + LN_A, wn * NJ + j, kk, r, g);
+    for (int j = 0; j < NJ; ++j) d[j] = read_frag3<B_KC, 256, TRASM>(st + LN_A, wn * NJ + j, kk, r, g);
   };
   auto mma = [&](int half, const bf16x8 (&a)[4], const bf16x8 (&b)[NJ]) {
 #pragma unroll
@@ -177,23 +182,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   //   3: A(k1, rows 64-127) x B(k1)  || read k0 of stage `nxt` (not in a tile's LAST step), fetch the cursor's stage into `cur`
   auto kstep = [&](char* cur, const char* nxt, auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
+    if constexpr (TRASM) KMB_TR_SYNC();
     read_a(cur, 0, 1, fa[1]);
     mma(0, fa[0], fb[0]);
 #pragma unroll
     for (int q = 0; q < NDA; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TRASM) KMB_TR_SYNC();
     read_b(cur, 1, fb[1]);
     read_a(cur, 1, 0, fa[0]);
     mma(1, fa[1], fb[0]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 1); __builtin_amdgcn_sched_group_barrier(0x100, (NDB + NDA + 7) / 8, 1); }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TRASM) KMB_TR_SYNC();
     read_a(cur, 1, 1, fa[1]);
     mma(0, fa[0], fb[1]);
 #pragma unroll
     for (int q = 0; q < NDA; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); __builtin_amdgcn_sched_group_barrier(0x100, 1, 2); __builtin_amdgcn_sched_group_barrier(0x008, 2, 2); }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0071);   // vmcnt(1) lgkmcnt(0): the pieces have landed, the touch behind them may still be out
+    if constexpr (TOUCH) __builtin_amdgcn_s_waitcnt(0x0071);   // vmcnt(1) lgkmcnt(0): the pieces have landed, the touch behind them may still be out
+    else __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!LAST) {
@@ -215,7 +224,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   set_dma_tile(tile_d);
   dma_stage(smem);
   dma_stage(smem + LN_STG);
-  __builtin_amdgcn_s_waitcnt(0x0F7A);   // vmcnt(10) = touch, stage 1, touch: stage 0 has landed
+  if constexpr (TOUCH) __builtin_amdgcn_s_waitcnt(0x0F7A);   // vmcnt(10) = touch, stage 1, touch: stage 0 has landed
+  else __builtin_amdgcn_s_waitcnt(0x0F78);
   __builtin_amdgcn_s_barrier();
   read_b(smem, 0, fb[0]);
   read_a(smem, 0, 0, fa[0]);
@@ -238,6 +248,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     kstep(smem + (it & 1) * LN_STG, smem + ((it + 1) & 1) * LN_STG, Yes{});
     ++it;
+    if constexpr (TRASM) KMB_TR_SYNC();
     if (KMB_DIAG_BIT(p.tile_order, 512)) {   // epilogue ablation (diagnostic build only, tools/kloop_time.py): keep the accumulators alive
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -262,6 +273,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     read_b(smem + (it & 1) * LN_STG, 0, fb[0]);
     read_a(smem + (it & 1) * LN_STG, 0, 0, fa[0]);
   }
+  if constexpr (TRASM) KMB_TR_SYNC();   // (the last tile's look-ahead fragments are never used: their registers must not be handed out before they land)
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this workgroup is in flight when it ends
   retire();
 }
