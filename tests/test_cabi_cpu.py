@@ -196,3 +196,28 @@ def test_gemm_asm_transposing_reads_are_waited_for(tmp_path):
     checked = [l for l in r.stdout.splitlines() if "transposing reads" in l]
     assert len(checked) >= 9, "expected the kernels with inline-asm reads, found %d:\n%s" % (len(checked), r.stdout[-2000:])
     assert "total violations 0" in r.stdout
+
+
+def test_tr_asm_hazard_checker_sees_a_violation(tmp_path):
+    """The checker itself: a synthetic kernel in which an inline-asm transposing read's register is used before the next full LDS wait (directly,
+    and along a branch that skips the wait) must be flagged; the same kernel with the wait in front of the use must pass."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "gemm_tr_asm_hazards.py")
+    head = "_ZN4test11gemm_kernelEv: ; @x\n"
+    read = "\t;;#ASMSTART\n\tds_read_b64_tr_b16 v[10:11], v3\n\t;;#ASMEND\n"
+    tail = "\ts_endpgm\n.Lfunc_end0:\n"
+    cases = {
+        "use_before_wait": (head + read + "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[10:13], v[20:23], a[0:3]\n\ts_waitcnt lgkmcnt(0)\n" + tail, 1),
+        "overwritten_before_wait": (head + read + "\tv_mov_b32_e32 v11, 0\n\ts_waitcnt lgkmcnt(0)\n" + tail, 1),
+        "branch_around_the_wait": (head + read + "\ts_cbranch_scc1 .LBB0_2\n\ts_waitcnt lgkmcnt(0)\n.LBB0_2:\n\tv_add_u32_e32 v1, v10, v2\n" + tail, 1),
+        "partial_wait_is_not_enough": (head + read + "\ts_waitcnt lgkmcnt(1)\n\tv_add_u32_e32 v1, v10, v2\n" + tail, 1),
+        "waited": (head + read + "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[4:7], v[20:23], a[0:3]\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n"
+                   "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[10:13], v[20:23], a[0:3]\n" + tail, 0),
+        "intrinsic_reads_are_the_compilers": (head + "\tds_read_b64_tr_b16 v[10:11], v3\n\tv_add_u32_e32 v1, v10, v2\n" + tail, 0),
+    }
+    for name, (text, want) in cases.items():
+        p = tmp_path / (name + ".s")
+        p.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+        assert r.returncode == want, "%s: rc %d, expected %d\n%s" % (name, r.returncode, want, r.stdout + r.stderr)

@@ -11,7 +11,8 @@ import re
 import sys
 
 src = open(sys.argv[1]).read()
-names = re.findall(r"^(_ZN\S*gemm\S*): ", src, re.M)
+starts_at = {m.group(1): m.start() for m in re.finditer(r"^(_ZN\S*gemm\S*): ", src, re.M)}
+names = list(starts_at)
 SKIP = ()
 
 
@@ -27,7 +28,7 @@ total = 0
 for name in names:
     if any(k in name for k in SKIP):
         continue
-    i = src.index("\n" + name + ": ") + 1
+    i = starts_at[name]
     j = src.index(".Lfunc_end", i)
     lines = [l.strip() for l in src[i:j].splitlines()]
     # only the reads hipcc did not write itself: inline asm is bracketed by ";;#ASMSTART" / ";;#ASMEND" (the intrinsic's reads are covered by the compiler's own waits)
