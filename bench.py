@@ -32,6 +32,20 @@ GFLOP_PER_TOKEN = 0.3822          # 36.69 GFLOP per tra
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def gemm_sources_sha16():
+    """Fingerprint of the GEMM kernel sources in this tree (csrc/gemm*.hip + the headers they include).  A committed PMC traffic file
+    (profiles/r*_pmc_traffic.json) records the fingerprint of the code it was measured on; `roofline.traffic` is only quoted from a
+    file whose fingerprint is this tree's (the r05 line carried the traffic of the kernels BEFORE the round's last change)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "km-bart_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(csrc, "gemm*.hip"))) + [os.path.join(csrc, n) for n in ("common.h", "kernels.h", "diag.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def usable_cores():
     """Cores this process may run on (cgroup / affinity aware; os.cpu_count() reports the whole host)."""
     try:
@@ -145,14 +159,23 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
             os.remove(dump)
         lib.kmb_profile_gemm(0)
     lib.kmb_set_side_stream(model._engine.h, 1)
-    traffic, traffic_src = None, None
-    # HBM bytes come from rocprofv3 --pmc passes of this workload (tools/r3_profile.sh): the newest committed round
+    traffic, traffic_src, traffic_sha = None, None, None
+    # HBM bytes are NOT measured in this run (PMC counters need rocprofv3 around the process): they come from the newest committed
+    # rocprofv3 --pmc passes of this workload (tools/r6_profile.sh) -- and only if that file was measured on THIS tree's GEMM sources
+    # (gemm_sources_sha16); otherwise traffic is null and traffic_source says which file was refused.
+    here = gemm_sources_sha16()
     for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         rec = json.load(open(pmc))
-        if rec.get("per_gpu_batch") == per_gpu_batch:
+        if rec.get("per_gpu_batch") != per_gpu_batch:
+            continue
+        traffic_sha = rec.get("gemm_sources_sha16")
+        if traffic_sha == here:
             traffic = rec["gemm_hbm_bytes_per_launch"]
             traffic_src = "profiles/%s: %s" % (os.path.basename(pmc), rec["method"])
-            break
+        else:
+            traffic_src = ("refused: profiles/%s was measured on GEMM sources %s, this tree's are %s (re-run tools/r6_profile.sh)"
+                           % (os.path.basename(pmc), traffic_sha or "unrecorded (before round 6)", here))
+        break
     tot_ms = sum(a[1] for a in agg.values())
     tot_fl = sum(a[2] for a in agg.values())
     launches = sum(a[0] for a in agg.values())
@@ -160,7 +183,8 @@ def gemm_roofline(model, step, per_gpu_batch, n_prof=3):
     return {
         "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per GEMM launch",
-        "traffic_source": traffic_src,
+        "traffic_source": traffic_src, "traffic_measured_in_run": False, "traffic_gemm_sources_sha16": traffic_sha,
+        "gemm_sources_sha16": here,
         "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_n, 1)),
         "kernel": "gemm_kernel_v7 / v8 / v11 / v14 (all GEMM launches of a step, timed serially on their stream)",
         "per_gpu_batch": per_gpu_batch,

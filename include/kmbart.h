@@ -373,7 +373,8 @@ int kmb_op_gemm(const KmbGemm* p, void* stream);
  * only, fp32 output): what a generation decode step's vocabulary projection runs; bit-identical to kmb_op_gemm */
 int kmb_op_gemm_allrows(const KmbGemm* p, void* stream);
 /* n (1 .. 8) independent weight-gradient products dW_i = dY_i^T X_i (both operands token-major, fp32 output, no split-K) as ONE
- * launch walking all their 128 x 128 tiles: what kmb_backward issues per layer when the batch is short (<= 8192 tokens; torch
+ * launch walking all their 128 x 128 tiles: what kmb_backward issues per layer when the batch is short (<= 3072 tokens: `group_tokens`,
+ * csrc/engine.cpp::backward_impl; torch
  * autograd's per-Linear weight gradients behind the reference's loss.backward(), src/training.py:55-59, 138-142); every output
  * bit-identical to the same problem through kmb_op_gemm */
 int kmb_op_gemm_group(const KmbGemm* probs, int32_t n, void* stream);

@@ -1866,6 +1866,10 @@ int kmb_comm_destroy(kmb_handle* h) {
   if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
   if (h->comm_ev) { (void)hipEventDestroy(h->comm_ev); h->comm_ev = nullptr; }
   h->comm_world = 0; h->comm_rank = 0;
+  //  without a communicator nothing can gather the moment shards any more: the flag must not outlive it, or a later plain
+  // AdamW.step() / state_dict() would ask for a collective on a destroyed communicator.  The Python wrapper gathers BEFORE it destroys
+  // (kmbart/engine.py::comm_destroy); a caller of the C-ABI that destroys with sharded moments keeps this rank's shard only.
+  h->moments_sharded = false;
   return 0;
 }
 

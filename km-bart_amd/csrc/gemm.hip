@@ -94,12 +94,6 @@ extern "C" int kmb_debug_set_stamps(void* p) {
 __device__ __forceinline__ unsigned kmb_lds_addr(const void* p) {   // the 32-bit LDS address of a (generic) pointer into shared memory, in a scalar register
   return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
 }
-// gemm_lean.hip keeps the register form: its LDS is full WHILE a touch is in flight (the cross-tile touch lands during the epilogue,
-// which owns the staging images -- the LDS form corrupted its outputs, caught by the bitwise test), and its forward kernels use 242-244
-// registers, so v255 is free.  That is a property of the compiled code, not of the source: tests/test_cabi_cpu.py::
-// test_lean_gemm_never_allocates_v255 compiles gemm_lean.hip to ISA and fails if any instruction but the touch names v255.
-#define KMB_L2_TOUCH_V255(voff, sbase) asm volatile("global_load_dword v255, %0, %1" ::"v"(voff), "s"(sbase) : "memory", "v255")
-
 namespace {
 
 int g_shared_device = 0;   // kmb_gemm_shared_device(): other kernels (RCCL) hold CUs while the GEMMs run
@@ -182,12 +176,13 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const u32x4 (&reg
 // the read and the wait -- a property of the compiled code: tools/gemm_tr_asm_hazards.py walks the ISA's control-flow graph, and
 // tests/test_cabi_cpu.py::test_gemm_asm_transposing_reads_are_waited_for runs it on every build.  Same arithmetic in the same order: outputs
 // bit-identical to the intrinsic's (tools/gemm_tr_asm_ab.py: md5 per shape).  Kernels: v7 (+ the grouped weight gradients), v8, v11 with 256-wide
-// tiles (four and eight waves) -- the ones compared on the GPU when this went in; v7d, the 128- / 192-wide v11 tiles and gemm_lean.hip keep the
-// intrinsic (gemm_lean.hip: with asm reads the allocator hands out v255, which its L2 touch owns -- outputs that changed from run to run in
-// tools/gemm_tr_asm_ab.py; tests/test_cabi_cpu.py::test_lean_gemm_never_allocates_v255 is the check for that).
+// tiles (four and eight waves) -- the ones compared on the GPU when this went in (round 5); v7d, the 128- / 192-wide v11 tiles and gemm_lean.hip:
+// KMB_TR_ALL (round 6; gemm_lean.hip's L2 touch moved off v255 first -- with asm reads the allocator hands that register out).
 // -DKMB_TR_BUILTIN: the intrinsic everywhere (A/B builds).  profiles/r05_gemm_transposing_reads_asm.md.
-// -DKMB_TR_ASM_ALL (experiment build for round 6, statically checked, never run on a GPU yet): also the four-stage kernel and the 128- / 192-wide v11 tiles.
-#if defined(KMB_TR_ASM_ALL) && !defined(KMB_TR_BUILTIN)
+// Round 6: EVERY kernel (KMB_TR_ALL: also the four-stage kernel, the 128- / 192-wide persistent tiles and gemm_lean.hip) -- one GPU call compared
+// the md5 of seven shapes x nine launch variants between the intrinsic build, round 5's partial build and this one: all identical and stable
+// (profiles/r06_gemm_transposing_reads_all_variants.txt; the four-stage kernel's lone workgroups -33 %, the 128- / 192-wide weight gradients -12...-21 %).
+#ifndef KMB_TR_BUILTIN
 constexpr bool KMB_TR_ALL = true;
 #else
 constexpr bool KMB_TR_ALL = false;
@@ -199,10 +194,19 @@ __device__ __forceinline__ s16x4 kmb_tr_read_asm(const char* ptr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(t) : "v"(a));
   return t;
 }
+// the same read at `addr` (32-bit LDS address in a register) + a compile-time byte offset in the instruction's offset field: one address
+// register serves every (kk, hh) of a fragment column (gemm_lean.hip: without it each of the 16 reads of a stage kept its own hoisted address)
+template <int OFF>
+__device__ __forceinline__ s16x4 kmb_tr_read_asm_off(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  s16x4 t;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "n"(OFF));
+  return t;
+}
 #define KMB_TR_SYNC()                                   \
   do {                                                  \
     __builtin_amdgcn_sched_barrier(0);                  \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0); the builtin, not asm: hipcc's own wait tracking then knows the LDS queue is empty (as asm it re-waited, lgkmcnt(0), in front of the next use of a plain fragment read -- right behind the asm reads just issued) */ \
     __builtin_amdgcn_sched_barrier(0);                  \
   } while (0)
 #else
@@ -940,7 +944,7 @@ __device__ __forceinline__ void v7d_tile(const KmbGemm& p, char* smem, int block
 constexpr int LDS_DEEP = 4 * STAGE_BYTES;   // 128 KB (the epilogue's fp32 image + column sums fit in it)
 static_assert(LDS_DEEP >= LDS_BYTES, "the deep variant's epilogue uses the stage buffers");
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 1) void gemm_kernel_v7d(const KmbGemm p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v7d(const KmbGemm p) {   // (2: the register budget of gemm_kernel_v7 -- 128 KB of LDS keep it at one workgroup per CU; with the 512-register budget of (256, 1) hipcc rotated the accumulators through ~100 v_accvgpr moves per K step)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v7d_tile<A_KC, B_KC>(p, smem, (int)blockIdx.x, (int)gridDim.x);
 }
@@ -1719,7 +1723,7 @@ __device__ __forceinline__ void v11_epilogue_lean(const KmbGemm& p, f32x4 (&acc)
 // an 18.8 us K loop -- and the second wave halves exactly that part.  The K loop is v8's (same fragments, same
 // accumulation order: bit-identical), MFMA-paced either way.
 template <bool A_KC, bool B_KC, int BNT, int NW = 4>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) __attribute__((amdgpu_num_vgpr(255)))   // (255: the allocation the round-4 kernels were tuned with; it does NOT reserve v255, see KMB_L2_TOUCH)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))   // (round 6: no amdgpu_num_vgpr(255) any more -- it capped the accumulator file at 252 registers, so two of the four-wave 256 x 256 kernels' 64 accumulator tiles lived in VGPRs and were swapped through a[0:3] / a[232:235] behind s_nop 5 stalls: 32-56 v_accvgpr moves per K step)
 void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   static_assert(NW == 4 || (NW == 8 && (BNT == 256 || BNT == 192)), "eight waves: 256 x 256 and 256 x 192 tiles only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1958,8 +1962,7 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
   const int rm_l = (g * 8 + (r >> 2)) * (BIMG * 2) + ((r & 3) << 3);
   const int rm_nb = rm_l | (rm_sw << 5);                                                   // bits 5-8 of rm_l are zero
   const int rm_na = ((g * 8 + (r >> 2)) * (BM4 * 2) + ((r & 3) << 3)) | (rm_sw << 5);
-  // inline-asm transposing reads (kmb_tr_read_asm): the 256-wide tiles only -- the kernels whose outputs were compared bit for bit with the
-  // intrinsic's on the GPU when this went in (tools/gemm_tr_asm_ab.py, launch variants 11 and 14); 128 / 192 keep the intrinsic
+  // inline-asm transposing reads (kmb_tr_read_asm) in every tile width since round 6 (KMB_TR_ALL)
 #ifndef KMB_TR_BUILTIN
   constexpr bool TRASM = (BNT == 256 || KMB_TR_ALL) && !(A_KC && B_KC);
 #else
@@ -2179,6 +2182,11 @@ void gemm_kernel_v11(const KmbGemm p, uint32_t* sched, int dyn_first) {
         if (PF_ON && pf_pending) __builtin_amdgcn_s_waitcnt(0x0071);  // vmcnt(1): this step's L2 touch stays in flight
         else __builtin_amdgcn_s_waitcnt(0x0070);                       // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        // lgkmcnt(0) once more, in straight-line code (round 6).  It already holds on both paths into the barrier, but hipcc's wait tracking
+        // loses it at the join of the branch above and put its own lgkmcnt(0) in front of sub-phase 3's first MFMA -- i.e. BEHIND the eight
+        // to twenty fragment reads of the next stage that sub-phase 3 issues first: their whole LDS latency was exposed in every K step of
+        // every persistent kernel (ISA: `s_barrier, ds_read x 8, s_waitcnt lgkmcnt(0), v_mfma`; tools/gemm_kloop_audit.py --sig).
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         KMB_WAIT_END(kmb_wait_ticks);
       }
       __builtin_amdgcn_sched_barrier(0);

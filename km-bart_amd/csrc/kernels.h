@@ -57,7 +57,7 @@ struct KmbDecodeLayers {
   const bf16_t* x_in;             // [R, 768] rows entering L[0]
   bf16_t *o, *z, *hh;             // exchange buffers [R, 768], [R, 768] (also the output: the last layer's pre-LayerNorm sums), [R, F]
   unsigned* bars;                 // kmb_decode_layers_bar_words() counters, zeroed by the launcher
-  int32_t* status;                // bit 8: a group barrier gave up
+  int32_t* status;                // status VALUE 8 (bit 3): a group barrier gave up
   int R, F, H, Tmax, Tk, S, ldc, kv_group;
   const int64_t* key_mask; int mask_ld;
   float eps, q_scale;

@@ -226,6 +226,14 @@ class Engine:
                 out.append(t)
         return tuple(out)
 
+    def encoder_last_state(self):
+        """[B, S, d] bf16: the encoder output of the forward still in the workspace (what want_encoder=True copies eagerly)."""
+        B, _ = self._last_bt
+        t = torch.empty((B, self._last_S, int(self.config.d_model)), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.kmb_hidden_state(self.h, 0, int(self.config.encoder_layers), ptr(t), _stream()))
+        return t
+
     def encoder_states_grad(self):
         """dL / d(encoder output) of the backward that just ran, bf16 [B, S, d]: what autograd hands to a tensor passed as
         `encoder_outputs` (src/model/model.py:76-83)."""
@@ -449,8 +457,12 @@ class Engine:
 
     def comm_destroy(self):
         """Drops the library's communicator (the data-parallel wrapper's fallback to torch.distributed when the native
-        bootstrap failed on another rank)."""
+        bootstrap failed on another rank).  If a reduce-scatter exchange left exp_avg / exp_avg_sq sharded, they are gathered first
+        (a COLLECTIVE: teardown runs on every rank; after a failed bootstrap nothing is sharded) -- kmb_comm_destroy clears the flag."""
         with torch.cuda.device(self.device):
+            if self.moments_sharded:
+                check(self.lib.kmb_comm_gather_moments(self.h, _stream()))
+                torch.cuda.synchronize(self.device)
             check(self.lib.kmb_comm_destroy(self.h))
         self.comm_world = 0
 

@@ -127,6 +127,20 @@ class LazyLogits:
         return self.tensor()[idx]
 
 
+class LazyEncoderStates(LazyLogits):
+    """The encoder_last_hidden_state entry of a TRAINING forward's tuple (reference src/model/model.py:100-103 returns it; no
+    training loop reads it): copied out of the engine's workspace on first use (kmb_hidden_state) instead of a [B, S, d]
+    allocation + copy in every step (~100 MB at 1024 samples).  Same lifetime as LazyLogits."""
+
+    def tensor(self):
+        if self._t is None:
+            if self._eng.fwd_serial != self._serial:
+                raise RuntimeError("the encoder states of this forward are gone: the model has run another forward / generate "
+                                   "or an optimizer step since (read outputs[2] before optimizer.step())")
+            self._t = self._eng.encoder_last_state()
+        return self._t
+
+
 class BeamHypotheses:
     """transformers 3.0.2 BeamHypotheses (n-best list, score = sum_logprobs / len ** length_penalty)."""
 
@@ -366,9 +380,13 @@ class MultiModalBartForConditionalGeneration(nn.Module):
             decoder_attention_mask = decoder_input_ids.ne(self.config.pad_token_id).long()
         need_grad = labels is not None and torch.is_grad_enabled()
         want_logits = (labels is None) if return_logits is None else bool(return_logits)
+        # a training forward's encoder states leave the workspace only when somebody reads them (LazyEncoderStates)
+        lazy_enc = need_grad and enc_states is None and not eng.fp32_mode
         loss, logits, enc = eng.forward(input_ids, image_features, attention_mask, decoder_input_ids,
                                         decoder_attention_mask, labels, train=self.training, need_grad=need_grad,
-                                        want_logits=want_logits, encoder_states=enc_states)
+                                        want_logits=want_logits, encoder_states=enc_states, want_encoder=not lazy_enc)
+        if lazy_enc:
+            enc = LazyEncoderStates(eng)
         # output_hidden_states / output_attentions (src/model/modules.py:143-165, transformers 3.0.2 BartDecoder; the tuple
         # is decoder_outputs + encoder_outputs with empty entries filtered, src/model/model.py:100-103): decoder = the layers'
         # INPUTS and their self-attention weights, encoder = the layers' inputs + the final output and the attention weights.
@@ -427,21 +445,36 @@ class MultiModalBartForConditionalGeneration(nn.Module):
         cache = decoder_cached_states
         enc = encoder_outputs[0] if isinstance(encoder_outputs, (tuple, list)) else encoder_outputs
         pend = getattr(eng, "_gen_pending", None)
-        if cache is None and enc is not None and input_ids is None:
+        if cache is None and enc is not None:
             # the reference's flow (mixins.py:281-324, :386-398): get_encoder()(...) ran, its states -- possibly expanded
-            # num_beams-fold with index_select(0, arange(B).repeat_interleave(k)) -- come back as encoder_outputs
+            # num_beams-fold with index_select(0, arange(B).repeat_interleave(k)) -- come back as encoder_outputs.  When input_ids
+            # are passed TOO the reference uses encoder_outputs as given and never runs its encoder (src/model/model.py:76-83): so
+            # does this path.  Encoder states this model did not just compute cannot be honoured (the cross-attention keys / values
+            # are the library's): that raises instead of silently re-running the encoder on input_ids.
             if pend is None or pend["cache"].serial != eng.fwd_serial or pend["cache"].length != 0:
                 raise ValueError("the first cached step needs input_ids / image_features, or encoder_outputs made by "
-                                 "model.get_encoder()(...) of THIS model with no other forward in between")
+                                 "model.get_encoder()(...) of THIS model with no other forward in between"
+                                 + ("" if input_ids is None else " (input_ids were passed together with encoder_outputs: the "
+                                    "reference uses the given encoder_outputs, which are not this model's pending ones)"))
             cache = pend["cache"]
             rows = decoder_input_ids.shape[0]
+            ids0, feats0, mask0, cap0 = pend["inputs"]
+            if rows % ids0.shape[0] != 0 or enc.shape[0] != rows:
+                raise ValueError("decoder_input_ids has %d rows; the encoder ran on %d items" % (rows, ids0.shape[0]))
+            k = rows // ids0.shape[0]
+            # the given states must BE the pending ones, row i = item i // k (the reference's expansion order): states expanded in
+            # another order or edited by the caller would otherwise be silently replaced by the library's own
+            mine = eng.gen_encoder_states()
+            if k > 1:
+                mine = mine.repeat_interleave(k, dim=0)
+            given = enc.to(device=mine.device)
+            if given.shape != mine.shape or not torch.equal(given.to(mine.dtype), mine):
+                raise ValueError("encoder_outputs are not the states model.get_encoder()(...) returned (repeated item-major %d-fold): "
+                                 "the cached decoder step cannot take edited or re-ordered encoder states" % k)
             if rows != cache.rows:
-                ids0, feats0, mask0, cap0 = pend["inputs"]
-                if rows % ids0.shape[0] != 0 or enc.shape[0] != rows:
-                    raise ValueError("decoder_input_ids has %d rows; the encoder ran on %d items" % (rows, ids0.shape[0]))
-                # rows expanded k-fold: row i belongs to item i // k (the reference's expansion order); the encoder side
-                # is rebuilt with k rows per item (one more encoder pass; generate() itself never takes this route)
-                eng.gen_begin(ids0, feats0, mask0, rows // ids0.shape[0], cap0)
+                # rows expanded k-fold: row i belongs to item i // k; the encoder side is rebuilt with k rows per item (one more
+                # encoder pass; generate() itself never takes this route)
+                eng.gen_begin(ids0, feats0, mask0, k, cap0)
                 cache = DecoderCache(eng, rows, cap0)
             eng._gen_pending = None
         new_cache = cache is None
@@ -992,11 +1025,14 @@ class MultiModalBartForPreTraining(MultiModalBartForConditionalGeneration):
         need_grad = torch.is_grad_enabled()
         factors = (float(cfg.lm_loss_factor), float(cfg.mrm_loss_factor), float(cfg.attribute_loss_factor),
                    float(cfg.relation_loss_factor))
-        losses, logits, enc = eng.forward_pretrain(input_ids, image_features, attention_mask, decoder_input_ids,
-                                                   decoder_attention_mask, lm_labels, mrm=mrm, attr=attr, rel=rel,
-                                                   factors=factors, train=self.training, need_grad=need_grad,
-                                                   want_logits=bool(return_logits), encoder_states=enc_states,
-                                                   want_encoder=True)
+        lazy_enc = need_grad and enc_states is None and not eng.fp32_mode   # (the benchmarked pre-training step copied ~100 MB of encoder states nobody read)
+        res = eng.forward_pretrain(input_ids, image_features, attention_mask, decoder_input_ids,
+                                   decoder_attention_mask, lm_labels, mrm=mrm, attr=attr, rel=rel,
+                                   factors=factors, train=self.training, need_grad=need_grad,
+                                   want_logits=bool(return_logits), encoder_states=enc_states,
+                                   want_encoder=not lazy_enc)
+        losses, logits = res[0], res[1]
+        enc = LazyEncoderStates(eng) if lazy_enc else res[2]
         dec_extra, enc_extra = (), ()
         if output_hidden_states:
             dec_extra += (eng.hidden_states(1)[:-1],)

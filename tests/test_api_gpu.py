@@ -121,12 +121,23 @@ def test_lazy_logits_are_the_training_logits_and_expire():
     lazy = out[1]
     out[0].backward()                       # backward leaves the saved decoder states alone
     assert torch.equal(lazy[:, :, :], eager)          # same dropout masks: the ACTUAL training logits
+    # the encoder states of a training forward are lazy too (round 6: no [B, S, d] copy per step): read after backward they are
+    # the states an eager copy of the same forward (same dropout seed) holds
+    from src.model.model import LazyEncoderStates
+    assert isinstance(out[2], LazyEncoderStates)
+    lazy_enc = out[2][:, :, :].clone()
+    model._engine.set_seed(5)
+    with torch.no_grad():
+        eager_enc = run_fwd(model, b)[2]
+    assert torch.is_tensor(eager_enc) and torch.equal(lazy_enc, eager_enc)
     opt = AdamW(model.parameters(), lr=1e-3)
     out2 = run_fwd(model, b)
     out2[0].backward()
     opt.step()
     with pytest.raises(RuntimeError, match="gone"):
         out2[1].shape
+    with pytest.raises(RuntimeError, match="gone"):
+        out2[2].shape
 
 
 def test_beam_search_min_length_and_sampling_follow_the_oracle():
@@ -361,6 +372,22 @@ def test_cached_forward_returns_logits_cache_and_encoder_states():
     assert tuple(lg.shape) == (4 * k, 1, V) and cache.rows == 4 * k
     one = model(decoder_input_ids=start[:4], use_cache=True, **kw)[0]
     assert rel(lg[::k], one) < 1e-3 and rel(lg[1::k], one) < 1e-3     # every copy of an item decodes that item
+    # (g) ADVICE r5: encoder states expanded in ANOTHER order (or edited) are refused, not silently replaced by a recomputed encoder;
+    # input_ids passed together with encoder_outputs: the given encoder_outputs win (reference src/model/model.py:76-83) when they
+    # are this model's pending ones, and raise when they are not
+    enc_out = model.get_encoder()(kw["input_ids"], kw["image_features"], kw["attention_mask"])
+    wrong = (enc_out[0].repeat(k, 1, 1),)                            # batch-major instead of item-major
+    with pytest.raises(ValueError, match="not the states"):
+        model(input_ids=None, image_features=None, encoder_outputs=wrong, decoder_input_ids=start, use_cache=True)
+    enc_out = model.get_encoder()(kw["input_ids"], kw["image_features"], kw["attention_mask"])
+    edited = (enc_out[0] * 2,)
+    with pytest.raises(ValueError, match="not the states"):
+        model(input_ids=None, image_features=None, encoder_outputs=edited, decoder_input_ids=start[:4], use_cache=True)
+    enc_out = model.get_encoder()(kw["input_ids"], kw["image_features"], kw["attention_mask"])
+    both = model(encoder_outputs=enc_out, decoder_input_ids=start[:4], use_cache=True, **kw)
+    assert torch.equal(both[0], one)
+    with pytest.raises(ValueError, match="encoder_outputs"):          # no pending get_encoder() call any more
+        model(encoder_outputs=enc_out, decoder_input_ids=start[:4], use_cache=True, **kw)
 
 
 def test_bare_model_cached_step_and_taps():

@@ -143,39 +143,43 @@ def test_no_cpu_fallback():
         assert "oracle" not in text.replace("# oracle", ""), "product file %s mentions the oracle" % f
 
 
-def test_lean_gemm_never_allocates_v255(tmp_path):
-    """csrc/gemm_lean.hip's L2 touch is a load into v255 whose result nobody reads and which stays in flight across the tile's
-    epilogue (KMB_L2_TOUCH_V255, csrc/gemm.hip).  That is only sound while the register allocator never hands v255 to a value:
-    a property of the COMPILED code, which no attribute guarantees (round 5 found the other persistent kernels compiled with all
-    256 registers despite amdgpu_num_vgpr(255); they now touch through LDS-DMA).  So: compile the file to ISA (no GPU needed)
-    and require that inside every kernel that contains a touch no other instruction names v255, alone or as the top of a range."""
+def _compile_to_isa(src_name, out, defines=()):
+    """hipcc -S with the PRODUCT flags (imported from km-bart_amd/build.py, not copied) -- no GPU needed"""
     import subprocess
-    src = os.path.join(ROOT, "km-bart_amd", "csrc", "gemm_lean.hip")
-    out = str(tmp_path / "gemm_lean.s")
-    flags = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
-             "-I" + os.path.join(ROOT, "km-bart_amd", "csrc"), "-I" + os.path.join(ROOT, "include")]
-    subprocess.check_call(["hipcc", "-x", "hip"] + flags + ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
-    use = re.compile(r"\bv255\b|v\[\d+:255\]")
-    name, touches, others, kernels = None, 0, [], 0
-    for line in open(out):
-        m = re.match(r"^(_Z\w+):", line)
-        if m:
-            name, touches, others = m.group(1), 0, []
-            continue
-        if name is None:
-            continue
-        if line.startswith(".Lfunc_end"):
-            if touches:
-                kernels += 1
-                assert not others, "%s: v255 is used by the allocator (%d instructions, e.g. %s)" % (name, len(others), others[0].strip())
-            name = None
-            continue
-        code = line.split(";")[0]
-        if "global_load_dword v255" in code:
-            touches += 1
-        elif use.search(code):
-            others.append(code)
-    assert kernels >= 6, "expected the lean GEMM kernels with their touches, found %d" % kernels
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "km-bart_amd"))
+    from build import CSRC, FLAGS
+    cmd = ["hipcc", "-x", "hip"] + FLAGS + list(defines) + ["-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out,
+                                                             os.path.join(CSRC, src_name)]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    return out
+
+
+def test_l2_touches_have_no_register_destination(tmp_path):
+    """The persistent GEMMs' L2 touch is a load whose result nobody reads and which stays in flight across a K step's counted wait.  Rounds 2-5 gave
+    it a register (a fresh one, one register web, v255) and each form broke once the allocator reused that register; since round 6 EVERY touch -- also
+    csrc/gemm_lean.hip's, whose cross-tile touches used to be in flight during the epilogue -- is a 4-byte LDS-DMA into the issuing wave's staging
+    image (KMB_L2_TOUCH).  A property of the compiled code: no inline-asm load with a register destination in any GEMM kernel, touches present in the
+    lean kernels, and nothing spilled to scratch in them with the intrinsic reads."""
+    for src, min_kernels in (("gemm_lean.hip", 12), ("gemm_pair.hip", 6)):
+        text = open(_compile_to_isa(src, str(tmp_path / (src + ".s")))).read()
+        kernels = 0
+        for m in re.finditer(r"^(_Z\w*gemm_kernel_(?:lean|pair)\w*):", text, re.M):
+            body = text[m.start():text.index(".Lfunc_end", m.start())]
+            kernels += 1
+            in_asm = False
+            for line in body.splitlines():
+                t = line.strip()
+                if t.startswith(";;#ASMSTART"):
+                    in_asm = True
+                elif t.startswith(";;#ASMEND"):
+                    in_asm = False
+                elif in_asm:
+                    # (an LDS-DMA's first operand is its address offset, not a destination)
+                    assert "_lds_" in t or not re.match(r"(global|buffer|flat)_load_\w+\s+v", t), \
+                        "%s: inline-asm load into a register: %s" % (m.group(1), t)
+            assert "global_load_lds_dword " in body, "%s has no L2 touch" % m.group(1)
+        assert kernels >= min_kernels, (src, kernels)
 
 
 def test_gemm_asm_transposing_reads_are_waited_for(tmp_path):
@@ -186,16 +190,13 @@ def test_gemm_asm_transposing_reads_are_waited_for(tmp_path):
     control-flow graph (tools/gemm_tr_asm_hazards.py)."""
     import subprocess
     import sys
-    src = os.path.join(ROOT, "km-bart_amd", "csrc", "gemm.hip")
-    out = str(tmp_path / "gemm.s")
-    flags = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
-             "-I" + os.path.join(ROOT, "km-bart_amd", "csrc"), "-I" + os.path.join(ROOT, "include")]
-    subprocess.check_call(["hipcc", "-x", "hip"] + flags + ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_tr_asm_hazards.py"), out], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]
-    checked = [l for l in r.stdout.splitlines() if "transposing reads" in l]
-    assert len(checked) >= 9, "expected the kernels with inline-asm reads, found %d:\n%s" % (len(checked), r.stdout[-2000:])
-    assert "total violations 0" in r.stdout
+    for src, least in (("gemm.hip", 9), ("gemm_lean.hip", 0)):   # (gemm_lean.hip: its token-major kernels once KMB_TR_ALL is the default)
+        out = _compile_to_isa(src, str(tmp_path / (src + ".s")))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_tr_asm_hazards.py"), out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-3000:]
+        checked = [l for l in r.stdout.splitlines() if "transposing reads" in l]
+        assert len(checked) >= least, "%s: expected the kernels with inline-asm reads, found %d:\n%s" % (src, len(checked), r.stdout[-2000:])
+        assert "total violations 0" in r.stdout
 
 
 def test_tr_asm_hazard_checker_sees_a_violation(tmp_path):

@@ -1,4 +1,5 @@
 # Turn the outputs of tools/r3_profile.sh (r2_profile.sh for round 2) (gpurun_out/$R/, merged back by gpurun) into the committed files under profiles/.
+# (kernel-stats tables: the step count comes from the run itself -- summarize_rocprof.py auto -- not from a constant)
 # Run from the repo root on the build container:  bash tools/refresh_profiles.sh [r02] [1024] [r02]
 #   $1 = the R tag the evidence run wrote under (gpurun_out/$1), $2 = its per-GPU batch, $3 = prefix of the committed files
 I=${1:-r02}
@@ -9,10 +10,10 @@ set -e
 tail -1 $O/bench_default.log > profiles/${R}_bench_b${B}.json
 cp $O/prof/p_kernel_stats.csv profiles/${R}_kernel_stats_b${B}.csv
 cp $O/profs/s_kernel_stats.csv profiles/${R}_kernel_stats_b${B}_serial.csv
-python tools/summarize_rocprof.py $O/prof/p_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b${B}.md
-python tools/summarize_rocprof.py $O/profs/s_kernel_stats.csv 25 > profiles/${R}_kernel_stats_b${B}_serial.md
+python tools/summarize_rocprof.py $O/prof/p_kernel_stats.csv auto > profiles/${R}_kernel_stats_b${B}.md
+python tools/summarize_rocprof.py $O/profs/s_kernel_stats.csv auto > profiles/${R}_kernel_stats_b${B}_serial.md
 python tools/summarize_pmc.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv \
-    --json profiles/${R}_b${B}_pmc_traffic.json --batch ${B} > profiles/${R}_pmc_hbm_traffic_b${B}.md
+    --json profiles/${R}_b${B}_pmc_traffic.json --batch ${B} --gemm-sha $(cat $O/gemm_sources.sha) > profiles/${R}_pmc_hbm_traffic_b${B}.md
 python tools/summarize_pmc_mfma.py $O/pmc_mfma/m_counter_collection.csv > profiles/${R}_pmc_mfma_util_b${B}.md
 cp $O/gemm_shapes.txt profiles/${R}_gemm_shape_table_b${B}.txt
 cp $O/yardstick.txt profiles/${R}_gemm_library_yardstick_b${B}.txt

@@ -43,7 +43,10 @@ print(f"\nGEMM kernels: {gemm_n} launches, {gemm_bytes / max(gemm_n, 1):.1f} MB 
 if "--json" in sys.argv:
     out = sys.argv[sys.argv.index("--json") + 1]
     batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else None
-    json.dump({"per_gpu_batch": batch, "gemm_launches": gemm_n,
+    # fingerprint of the GEMM sources the passes ran on: written by the evidence run ON THE GPU BOX (tools/r6_profile.sh -> gemm_sources.sha);
+    # bench.py quotes this file's traffic only when it matches the tree it runs from
+    sha = sys.argv[sys.argv.index("--gemm-sha") + 1] if "--gemm-sha" in sys.argv else None
+    json.dump({"per_gpu_batch": batch, "gemm_sources_sha16": sha, "gemm_launches": gemm_n,
                "gemm_hbm_bytes_per_launch": round(gemm_bytes / max(gemm_n, 1) * 1e6),
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (each with --kernel-trace "
                          "only) over `bench.py --steps 2 --warmup 2 --serial` with the GEMM tuning preloaded; counters "

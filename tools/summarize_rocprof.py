@@ -1,12 +1,25 @@
 """Turns `rocprofv3 --kernel-trace --stats --output-format csv` output into the table committed under profiles/.
 
     python tools/summarize_rocprof.py gpurun_out/prof_X/X_kernel_stats.csv STEPS > profiles/rNN_kernel_stats.md
+
+STEPS: a number, or `auto` (training runs): taken FROM THE RUN -- `embed_bwd_kernel` is launched exactly twice per training step (encoder and decoder
+embedding), so steps = its calls / 2 (`auto:<kernel substring>:<launches per step>` for another anchor).  Round 5's committed tables divided a
+65-step run (bench.py times three windows: warm-up + 3 x --steps) by a hard-coded 25 and were wrong per step by 2.6 x (Weak 4).
 """
 import csv
 import sys
 
-path, steps = sys.argv[1], int(sys.argv[2])
+path = sys.argv[1]
 rows = [r for r in csv.DictReader(open(path))]
+if sys.argv[2].startswith("auto"):
+    parts = sys.argv[2].split(":")
+    anchor, per_step = (parts[1], int(parts[2])) if len(parts) == 3 else ("embed_bwd_kernel", 2)
+    calls = sum(int(r["Calls"]) for r in rows if anchor in r["Name"])
+    if calls == 0 or calls % per_step:
+        raise SystemExit("cannot derive the step count: %d launches of %s, %d expected per step" % (calls, anchor, per_step))
+    steps = calls // per_step
+else:
+    steps = int(sys.argv[2])
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("| kernel | calls | calls/step | total ms | avg us | min us | max us | share |")
 print("|---|---|---|---|---|---|---|---|")
