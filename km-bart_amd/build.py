@@ -113,6 +113,11 @@ if __name__ == "__main__":
             # for its timing-only builds); KMB_GEMM_VARIANT=10 KMB_LIB_PATH=lib/libkmbart_hip_rolesplit.so selects it
             defs = list(defs) + ["KMB_WITH_ROLESPLIT"]
             srcs, extra = ("gemm.hip",), ("gemm_rolesplit.hip",)
+        if sys.argv[i + 1].startswith("resident"):
+            # the resident decoder-layers kernel (tools/experiments/decode_resident.hip; measured 17 % slower than the six-launch blocks):
+            # `--variant resident`; KMB_GEN_FUSED=2 KMB_LIB_PATH=lib/libkmbart_hip_resident.so selects it (tools/experiments/test_decode_resident.py)
+            defs = list(defs) + ["KMB_WITH_RESIDENT_DECODE"]
+            srcs, extra = ("engine.cpp",), ("decode_resident.hip",)
         if any(d.startswith("KMB_DEC_") for d in defs):   # decode-block A/B builds
             srcs = ("decode.hip",)
         if any(d.startswith("KMB_PR_") for d in defs):   # ... of the two-workgroups-per-CU kernel

@@ -2028,7 +2028,9 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
     for (int l = 0; l < Ld; ++l)
       for (int i = 0; i < 6; ++i) g.wp.push_back(bp.act(sizes[i]));
   }
+#ifdef KMB_WITH_RESIDENT_DECODE   // experiment build only (tools/experiments/decode_resident.hip): the group-barrier counters
   g.bars = bp.take<uint32_t>(kmb_decode_layers_bar_words((int)R, Ld > 0 ? Ld : 1) + 64);
+#endif
   g.hist[0] = bp.take<int32_t>(R * Tmax); g.hist[1] = bp.take<int32_t>(R * Tmax);
   if (out) *out = g;
   return bp.used();
@@ -2168,7 +2170,8 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       HIPCHK(kmb_decode_block_launch(b, s));
       return 0;
     };
-    // Resident form (decode.hip "resident decoder-layers kernel", round 5; KMB_GEN_FUSED=2): ALL the layers in one launch
+#ifdef KMB_WITH_RESIDENT_DECODE
+    // Resident form (tools/experiments/decode_resident.hip, round 5; experiment build `build.py --variant resident`, KMB_GEN_FUSED=2): ALL the layers in one launch
     // (KMB_GEN_LAYERS of them per launch), twelve co-resident workgroups per row tile behind counter barriers.  Bit-identical to the
     // six-launches-per-layer blocks and MEASURED SLOWER than them (12.0 against 10.3 ms per generate at batch 64 x 5 beams: an
     // in-kernel hand-off costs ~3.5 us where a kernel boundary costs ~1.7, and what a layer streams is bound by the CU's request
@@ -2210,6 +2213,9 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
       }
       zin = G.z; lg = h->pf(h->dec[Ld - 1].ln_g); lb = h->pf(h->dec[Ld - 1].ln_b);
     }
+#else
+    const bool resident = false;   // (the resident decoder-layers kernel is an experiment build since round 6: measured 17 % slower)
+#endif
     for (int l = 0; !resident && l < h->cfg.decoder_layers; ++l) {
       const LayerP& L = h->dec[l];
       KmbDecodeBlock b;

@@ -178,57 +178,6 @@ def _teacher_forced_logits(model, b, nb, T, fused):
         os.environ.pop("KMB_GEN_FUSED", None)
 
 
-def test_resident_decoder_layers_kernel_is_bit_identical_to_the_blocks():
-    """The resident decoder-layers kernel (csrc/decode.hip, KMB_GEN_FUSED=2: all layers of a decode step in one launch, twelve
-    co-resident workgroups per row tile behind counter barriers, sc1 hand-offs) repeats the arithmetic of the six-launch blocks:
-    teacher-forced logits of every step are BIT-identical for every layers-per-launch grouping, the status word stays clean, and
-    a beam-5 generate returns the same ids.  (It is opt-in: measured slower than the blocks)"""
-    torch.manual_seed(0)
-    model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(BASE)).to(DEV).eval()
-    with torch.no_grad():
-        model._engine.view(model._engine.params, "model.shared.weight").mul_(8.0)
-    model._engine.sync_params()
-    eng = model._engine
-    B, nb, T = 7, 5, 6          # 35 rows: three row tiles, the last one ragged (3 rows), items straddling tiles
-    b = make_batch(B, seed=77, regions=(36, 20, 36, 7, 12, 36, 30), event_lens=(23, 7, 15, 23, 9, 20, 4), label_lens=(32,) * B)
-    ids, am = b["input_ids"].to(DEV), b["attention_mask"].to(DEV)
-    feats = [f.to(DEV) for f in b["image_features"]]
-    g = torch.Generator().manual_seed(7)
-    toks = torch.randint(3, 50000, (T, B * nb), generator=g).to(DEV)
-
-    def run(mode, layers=None):
-        os.environ["KMB_GEN_FUSED"] = mode
-        if layers:
-            os.environ["KMB_GEN_LAYERS"] = str(layers)
-        try:
-            out = []
-            eng.gen_begin(ids, feats, am, nb, 12)
-            for t in range(T):
-                out.append(eng.gen_step(toks[t], t)[:, : model.config.vocab_size].clone())
-                eng.gen_reorder(torch.randperm(B * nb, generator=torch.Generator().manual_seed(t)).to(DEV, torch.int32)
-                                if t == 2 else torch.arange(B * nb, dtype=torch.int32, device=DEV), t)
-            torch.cuda.synchronize()
-            return torch.stack(out), eng.read_status()
-        finally:
-            os.environ.pop("KMB_GEN_FUSED", None)
-            os.environ.pop("KMB_GEN_LAYERS", None)
-
-    ref, st = run("1")
-    assert st == 0 and bool(torch.isfinite(ref).all())
-    for layers in (6, 2, 1):
-        got, st = run("2", layers)
-        assert st == 0, "a group barrier gave up (status %d)" % st
-        assert torch.equal(got, ref), "resident kernel, %d layers per launch: logits differ from the six-launch blocks" % layers
-    kw = dict(input_ids=ids, image_features=feats, attention_mask=am, num_beams=nb, max_length=10, early_stopping=True)
-    want = model.generate(**kw)
-    os.environ["KMB_GEN_FUSED"] = "2"
-    try:
-        got = model.generate(**kw)
-    finally:
-        os.environ.pop("KMB_GEN_FUSED", None)
-    assert torch.equal(got, want)
-
-
 def test_decode_steps_match_oracle_and_unfused_path():
     ocfg = O.OracleConfig.from_dict(BASE)
     sd = G.golden_state_dict(ocfg, seed=5)
@@ -321,3 +270,31 @@ def test_full_size_beam5_search_matches_the_oracle(fused, sublayer_scale):
             best = _oracle_sequence_score(sd, ocfg, b, r, ref_ids[r].tolist())
             assert abs(best - float(ref_sc[r])) < 1e-3, "the test's scorer must reproduce the oracle's own score"
             assert alt >= best - 2e-2, "row %d: the product's hypothesis is not a tie for the oracle (%.4f vs %.4f)" % (r, alt, best)
+
+
+def test_physical_cache_reorder_fallback_equals_the_history_index():
+    """KMB_GEN_HIST=0 (the documented fallback: a beam reorder gathers every layer's self-attention K / V cache into the other copy instead
+    of permuting the history index, csrc/engine.cpp::kmb_gen_reorder) must keep returning what the default returns: same ids, same scores
+    (nothing exercised the old path any more).  The flag is read by kmb_gen_begin, i.e. per generate call."""
+    ocfg = O.OracleConfig.from_dict(BASE)
+    sd = G.golden_state_dict(ocfg, seed=11)      # re-scaled as in the full-size beam test above: searches that depend on item and position
+    sd["model.shared.weight"] = sd["model.shared.weight"] * 8.0
+    sd["model.decoder.embed_positions.weight"] = sd["model.decoder.embed_positions.weight"] * 40.0
+    for k_ in list(sd):
+        if k_.endswith("out_proj.weight") or k_.endswith("fc2.weight"):
+            sd[k_] = sd[k_] * 3.0
+    model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(BASE))
+    model.load_state_dict(sd, strict=False)
+    model.to(DEV).eval()
+    b = make_batch(5, seed=91, regions=(36, 20, 7, 36, 12), event_lens=(23, 7, 15, 9, 20), label_lens=(32,) * 5)
+    kw = dict(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
+              attention_mask=b["attention_mask"].to(DEV), num_beams=5, max_length=12, early_stopping=True)
+    want, want_sc = model.generate(return_scores=True, **kw)
+    os.environ["KMB_GEN_HIST"] = "0"
+    try:
+        got, got_sc = model.generate(return_scores=True, **kw)
+    finally:
+        os.environ.pop("KMB_GEN_HIST", None)
+    assert torch.equal(got, want)
+    assert torch.equal(got_sc, want_sc)
+    assert len({tuple(r) for r in want.tolist()}) > 1     # the searches differ by item: the reorders were not identities

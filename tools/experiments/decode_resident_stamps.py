@@ -1,21 +1,21 @@
-"""In-kernel timeline of the resident decoder-layers kernel (csrc/decode.hip; diagnostic build -DKMB_DECODE_STAMP, never the product
+"""In-kernel timeline of the resident decoder-layers kernel (tools/experiments/decode_resident.hip; diagnostic build -DKMB_DECODE_STAMP, never the product
 library): per-workgroup s_memrealtime stamps (10 ns ticks) at the phase boundaries of layer KMB_DL_STAMP_LAYER (default 1: a layer
 whose first weights were prefetched) of the last decode step of one beam-5 generate (batch 64).
 
-    python tools/decode_resident_stamps.py --build      (no GPU needed)
-    python tools/decode_resident_stamps.py
+    python tools/experiments/decode_resident_stamps.py --build      (no GPU needed)
+    python tools/experiments/decode_resident_stamps.py
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, "km-bart_amd")
-LIB = os.path.join(PKG, "lib", "libkmbart_hip_dstamp.so")
+LIB = os.path.join(PKG, "lib", "libkmbart_hip_dstampres.so")
 sys.path.insert(0, PKG)
 sys.path.insert(0, ROOT)
 if "--build" in sys.argv:
     import build as b
-    print(b.build_variant("dstamp", ["KMB_DECODE_STAMP"], sources=("decode.hip",)))
+    print(b.build_variant("dstampres", ["KMB_DECODE_STAMP", "KMB_WITH_RESIDENT_DECODE"], sources=("decode.hip", "engine.cpp"), extra_sources=("decode_resident.hip",)))
     sys.exit(0)
 os.environ["KMB_LIB_PATH"] = LIB
 import ctypes as C  # noqa: E402

@@ -1,16 +1,17 @@
-"""Resident decoder-layers kernel (csrc/decode.hip, round 5) against the six-launches-per-layer blocks (KMB_GEN_FUSED=1), whose
+"""Resident decoder-layers kernel (tools/experiments/decode_resident.hip, round 5; experiment library `python km-bart_amd/build.py --variant resident`) against the six-launches-per-layer blocks (KMB_GEN_FUSED=1), whose
 arithmetic it repeats: teacher-forced logits of every decode step must be bit-identical; then the time of a beam-5 generate
 (batch 64, 20 tokens) on each path, KMB_GEN_LAYERS = layers per launch.
 
-    python tools/gen_resident_check.py [batch=64] [beams=5]
+    python tools/experiments/gen_resident_check.py [batch=64] [beams=5]
 """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "km-bart_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+os.environ.setdefault("KMB_LIB_PATH", os.path.join(ROOT, "km-bart_amd", "lib", "libkmbart_hip_resident.so"))   # the experiment library
 import torch  # noqa: E402
 
 from src.data.synthetic import make_batch  # noqa: E402

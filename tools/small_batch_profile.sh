@@ -10,6 +10,6 @@ B="python3 bench.py --batch 64 --steps 40 --warmup 8 --no-cpu-baseline --no-roof
 $B 2>/dev/null | tail -1 | cut -c1-200
 $B --serial 2>/dev/null | tail -1 | cut -c1-200
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profs -o s -- $B --serial > $O/profs.log 2>&1
-python tools/summarize_rocprof.py $O/profs/s_kernel_stats.csv 48 > $O/serial.md
+python tools/summarize_rocprof.py $O/profs/s_kernel_stats.csv auto > $O/serial.md
 python3 tools/one_step_gemm_trace.py 64 $O/launches.txt > $O/trace.log 2>&1
 rm -rf $O/prof/*trace* $O/profs/*trace*
