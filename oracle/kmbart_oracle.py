@@ -29,9 +29,13 @@ container.  The oracle is therefore pinned two ways, both run by
     src/generation.py:22-32), min_length included.  early_stopping=False differs by a
     documented algorithm change (4.x bounds the attainable score with max_length).
 What stays **parity unpinned**: everything is pinned to transformers 5.15 and to the
-reference's importable modules, not to transformers 3.0.2 itself (absent offline); the
-multinomial-sampling branch of beam search has no independent check (its draws are not
-reproducible across implementations) beyond the shared deterministic bookkeeping.
+reference's importable modules, not to transformers 3.0.2 itself (absent offline).  The
+multinomial-sampling branch of beam search (do_sample with num_beams > 1) is pinned where it
+can be made independent of the random stream: with top_k = 2 the 2 * num_beams draws without
+replacement take every non-zero entry, and ids + scores are identical to transformers 5.15
+`generate(do_sample=True, num_beams=k, top_k=2)` (oracle/make_golden_beam_sample.py, round 6);
+arbitrary draws are not reproducible across implementations and stay compared through a
+shared sampler only.
 
 Reference map (file:line into /root/reference)
 ----------------------------------------------

@@ -203,6 +203,25 @@ def test_generation_matches_golden(gold_dir):
             assert out.cpu().tolist() == case["ids"], kw
 
 
+def test_beam_sampling_matches_the_transformers_pinned_fixture(gold_dir):
+    """The product's beam-search SAMPLING branch on the HIP path (generate(do_sample=True, num_beams=k, top_k=2): a search that does not depend
+    on the random stream, see tests/test_oracle_golden.py) returns the ids oracle/make_golden_beam_sample.py verified identical to transformers
+    5.15; scores to bf16."""
+    gen = json.load(open(os.path.join(gold_dir, "tiny_generate_beam_sample.json")))
+    ocfg, sd = G.tiny_config(), G.trained_state_dict()
+    model = build(ocfg, sd).eval()
+    ids, am = torch.tensor(gen["input_ids"]), torch.tensor(gen["attention_mask"])
+    feats = G.golden_features(gen["regions"], seed=gen["seed"])
+    for case in gen["cases"]:
+        kw = case["kwargs"]
+        for seed in (3, 4):
+            torch.manual_seed(seed)
+            got, scores = model.generate(input_ids=ids.to(DEV), image_features=[f.to(DEV) for f in feats], attention_mask=am.to(DEV),
+                                         do_sample=True, return_scores=True, **kw)
+            assert got.cpu().tolist() == case["ids"], kw
+            assert np.allclose(scores.numpy(), case["scores"], atol=3e-2), (kw, scores, case["scores"])
+
+
 def test_cached_decode_steps_match_teacher_forced_oracle():
     """KV-cached decode (kmb_gen_begin / kmb_gen_step / kmb_gen_reorder) fed a FIXED token sequence reproduces the
     oracle's teacher-forced logits position by position: checks cache append, learned position (len-1)+2,

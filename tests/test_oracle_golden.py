@@ -98,6 +98,25 @@ def test_generation_matches_golden(gold_dir):
             assert r.tolist() == case["ids"], kw
 
 
+def test_beam_sampling_branch_matches_the_transformers_pinned_fixture(gold_dir):
+    """Beam-search SAMPLING (do_sample=True, num_beams > 1; reference src/model/mixins.py:336-361) with top_k=2: every beam keeps two tokens, the
+    2 * num_beams draws without replacement take all 2 * num_beams non-zero entries, so the search does not depend on the random stream -- and
+    oracle/make_golden_beam_sample.py verified ids and scores identical to transformers 5.15 `generate(do_sample=True, num_beams=k, top_k=2)` when it
+    wrote the fixture (round 6: the sampling branch had no independent check before)."""
+    gen = json.load(open(os.path.join(gold_dir, "tiny_generate_beam_sample.json")))
+    cfg, sd = G.tiny_config(), G.trained_state_dict()
+    ids, am = torch.tensor(gen["input_ids"]), torch.tensor(gen["attention_mask"])
+    feats = G.golden_features(gen["regions"], seed=gen["seed"])
+    assert len(gen["cases"]) >= 4 and all(c["identical_to_transformers_5_15"] for c in gen["cases"])
+    for case in gen["cases"]:
+        kw = case["kwargs"]
+        for seed in (1, 2):   # whatever the random stream
+            torch.manual_seed(seed)
+            got, sc = O.generate(sd, cfg, ids, feats, am, do_sample=True, return_scores=True, **kw)
+            assert got.tolist() == case["ids"], kw
+            assert np.allclose(sc.numpy(), case["scores"], atol=1e-5)
+
+
 def test_ragged_and_empty_regions():
     """R_i = 0 rows pass through as plain token rows; a count mismatch raises (modules.py:98-100)."""
     cfg = G.tiny_config()
