@@ -367,6 +367,14 @@ int kmb_profile_dump(const char* path);   /* one text line per profiled GEMM lau
  * (bench.py `clock_mhz`: a 3 % box difference shows as clock, not as a regression) */
 int kmb_clock_stamp(int64_t* out16, void* stream);
 
+/* The reference's batch carries the region features as a LIST of per-sample [R_i, image_feature_size] fp32 tensors
+ * (/root/reference/src/data/collation.py:73-76; /root/reference/src/model/modules.py:24-41 concatenates the non-empty ones).
+ * rows_dev_ptrs: HOST array of n DEVICE pointers (entry i may be NULL when rows[i] == 0), rows: HOST array of the R_i.
+ * packed_out (device, [sum R_i, feat_dim] fp32) receives them in list order -- kmb_batch.image_features -- in ceil(n / 128)
+ * kernel launches on `stream`, no host synchronisation; the caller keeps the source tensors alive until the stream has passed. */
+int kmb_pack_features(const float* const* rows_dev_ptrs, const int32_t* rows, int32_t n, int32_t feat_dim, float* packed_out,
+                      void* stream);
+
 /* ================= single operators (unit tests / profiling) ================= */
 int kmb_op_gemm(const KmbGemm* p, void* stream);
 /* the same product on the "all rows" kernel (one workgroup per 256 output columns holds every row: M <= 320, forward layout, bias

@@ -36,6 +36,25 @@ int kmb_clock_stamp(int64_t* out16, void* stream) {
   return hipfail(hipGetLastError(), "clock_stamp");
 }
 
+// n per-sample region-feature tensors (device pointers in a HOST array; rows[i] rows of feat_dim contiguous floats each, rows[i] may be 0)
+// -> packed_out [sum rows, feat_dim] in list order: the batch layout kmb_batch.image_features wants, in ceil(n / 128) launches
+int kmb_pack_features(const float* const* rows_dev_ptrs, const int32_t* rows, int32_t n, int32_t feat_dim, float* packed_out, void* stream) {
+  if (n < 0 || feat_dim <= 0 || (n > 0 && (!rows_dev_ptrs || !rows || !packed_out))) return kmb_set_error("kmb_pack_features: bad arguments");
+  int32_t off = 0;
+  for (int32_t i0 = 0; i0 < n; i0 += KMB_PACK_MAX) {
+    KmbPackList l;
+    l.n = 0;
+    for (int32_t i = i0; i < n && i < i0 + KMB_PACK_MAX; ++i) {
+      if (rows[i] < 0 || (rows[i] > 0 && !rows_dev_ptrs[i])) return kmb_set_error("kmb_pack_features: null tensor with rows > 0, or a negative row count");
+      l.src[l.n] = rows_dev_ptrs[i]; l.rows[l.n] = rows[i]; l.off[l.n] = off; ++l.n;
+      off += rows[i];
+    }
+    const int e = hipfail(kmb_pack_features_launch(l, feat_dim, packed_out, (hipStream_t)stream), "pack_features");
+    if (e) return e;
+  }
+  return 0;
+}
+
 int kmb_op_gemm(const KmbGemm* p, void* stream) {
   const char* why = kmb_gemm_check(*p);
   if (why) return kmb_set_error(why);

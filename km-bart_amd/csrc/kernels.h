@@ -111,6 +111,9 @@ hipError_t kmb_img_rowmap_launch(const int64_t* ids, const int32_t* feat_off, in
                                  int64_t cls_id, int32_t* img_src, int32_t* status, hipStream_t stream);
 // fp32 region features [N, Fin] -> bf16 [N, Fpad] (zero padded)
 hipError_t kmb_cast_pad_launch(const float* x, int N, int Fin, bf16_t* y, int Fpad, hipStream_t stream);
+constexpr int KMB_PACK_MAX = 128;   // per-sample feature tensors gathered by one launch (the list travels as a kernel argument: 2 KB)
+struct KmbPackList { const float* src[KMB_PACK_MAX]; int32_t rows[KMB_PACK_MAX]; int32_t off[KMB_PACK_MAX]; int n; };
+hipError_t kmb_pack_features_launch(const KmbPackList& l, int feat_dim, float* dst, hipStream_t stream);
 // z = (img_src>=0 ? img_emb[img_src] : E[id]) * scale + P[pos_base + (row % S)] ; y = dropout(LN(z))
 hipError_t kmb_embed_ln_fwd_launch(const int64_t* ids, const int32_t* img_src, const float* E, const float* img_emb,
                                    const float* P, int pos_base, int S, float scale, const float* gamma,

@@ -159,6 +159,7 @@ PROTOTYPES = {
     "kmb_profile_read": (C.c_int, [C.c_int, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
     "kmb_profile_dump": (C.c_int, [C.c_char_p]),
     "kmb_clock_stamp": (C.c_int, [c_p, c_p]),
+    "kmb_pack_features": (C.c_int, [c_p, c_p, C.c_int32, C.c_int32, c_p, c_p]),
     "kmb_op_gemm": (C.c_int, [C.POINTER(KmbGemm), c_p]),
     "kmb_op_gemm_allrows": (C.c_int, [C.POINTER(KmbGemm), c_p]),
     "kmb_op_gemm_group": (C.c_int, [C.POINTER(KmbGemm), C.c_int32, c_p]),

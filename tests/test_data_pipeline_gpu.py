@@ -123,3 +123,33 @@ def test_pretrain_batch_from_files_against_oracle(tmp_path):
     mean_loss = pretrain(0, model, loader, AdamW(model.parameters(), lr=1e-4), DEV,
                          types.SimpleNamespace(epochs=1, amp=False))
     assert mean_loss == mean_loss and mean_loss > 0
+
+
+def test_feature_list_is_packed_in_one_launch_like_a_concatenation():
+    """The reference's batch carries region features as a LIST of per-sample [R_i, 2052] tensors (src/data/collation.py:73-76; the model
+    concatenates the non-empty ones, src/model/modules.py:24-41).  kmbart.engine.pack_features gathers them with kmb_pack_features -- one
+    launch per 128 tensors instead of a concatenation that costs ~one blit per tensor on this stack -- and must return exactly the
+    concatenation: ragged counts, empty samples (torch.empty(0)), more than 128 tensors, a non-contiguous and a CPU-resident entry."""
+    from kmbart.engine import pack_features
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    for counts in ((36, 20, 0, 7, 36), (5,), (0, 0), tuple(int(x) for x in torch.randint(0, 9, (300,), generator=g))):
+        feats = []
+        for i, n in enumerate(counts):
+            if n == 0:
+                feats.append(torch.empty(0))
+                continue
+            t = torch.randn((n, 2052), generator=g)
+            if i % 5 == 1:
+                t = torch.randn((n, 4104), generator=g)[:, ::2]          # non-contiguous view
+            feats.append(t if i % 7 == 3 else t.to(dev))                # some stay on the host
+        packed, offsets, ntot = pack_features(feats, 2052, dev)
+        torch.cuda.synchronize()
+        non_empty = [f.to(dev).float() for f in feats if f.dim() == 2 and f.shape[0] > 0]
+        assert ntot == sum(counts)
+        assert offsets.cpu().tolist() == [sum(counts[:i]) for i in range(len(counts) + 1)]
+        if non_empty:
+            want = torch.cat(non_empty, 0)
+            assert packed.shape == want.shape and torch.equal(packed, want), counts[:8]
+    with pytest.raises(ValueError):
+        pack_features([torch.randn(3, 2048).to(dev), torch.randn(2, 2052).to(dev)], 2052, dev)
