@@ -404,6 +404,49 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+class PowerProbe:
+    """Board power (hwmon PPT, W) and the hwmon shader clock of THIS process's card, sampled every 10 ms by a daemon thread while the timed
+    windows run (best effort: silently absent where /sys is not readable).  Round 6 found that the b = 1024 step holds the MI355X at its
+    1400 W cap and that the clock -- hence `value` and `roofline.frac` -- follows the power a kernel draws (profiles/r06_power_and_clock.txt)."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.samples, self._stop, self.cap, self._thread = [], False, None, None
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            card = [c for c in glob.glob("/sys/class/drm/card*/device") if bus in os.path.realpath(c)][0]
+            self._pw = glob.glob(card + "/hwmon/hwmon*/power1_input")[0]
+            self._fq = glob.glob(card + "/hwmon/hwmon*/freq1_input")[0]
+            self.cap = int(open(glob.glob(card + "/hwmon/hwmon*/power1_cap")[0]).read()) / 1e6
+            self._thread = threading.Thread(target=self._run, daemon=True)
+        except Exception:
+            self._thread = None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.samples.append((int(open(self._pw).read()) / 1e6, int(open(self._fq).read()) / 1e6))
+            except Exception:
+                pass
+            time.sleep(0.01)
+
+    def start(self):
+        if self._thread is not None:
+            self._thread.start()
+
+    def report(self):
+        self._stop = True
+        if self._thread is None or len(self.samples) < 8:
+            return None
+        w = sorted(x[0] for x in self.samples)
+        f = sorted(x[1] for x in self.samples)
+        return {"cap_w": self.cap, "median_w": round(w[len(w) // 2]), "p90_w": round(w[int(0.9 * len(w))]),
+                "hwmon_clock_mhz_median": round(f[len(f) // 2]), "samples": len(w),
+                "source": "hwmon power1_input / freq1_input of this card, 10 ms period, over the timed windows"}
+
+
 class ClockProbe:
     """The shader clock the chip held between two points of the current stream (kmb_clock_stamp: s_memtime over
     s_memrealtime per XCD).  A box that runs the GEMMs 3 % slower shows it here, not as a regression of the code."""
@@ -524,6 +567,9 @@ def main():
     # MAX over ranks; `value` is the MEDIAN window, `value_min` / `value_max` and `clock_mhz` (shader clock held inside each
     # window) go beside it: a round whose gains are <= 3 % cannot be read off one window on one box
     probe = ClockProbe(_lib.load(), dev)
+    power = PowerProbe(dev) if rank == 0 else None
+    if power is not None:
+        power.start()
     windows = []
     for _w in range(args.windows):
         fence()
@@ -539,6 +585,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wdt = float(t)
         windows.append((wdt, probe.mhz()))
+    board_power = power.report() if power is not None else None
     order = sorted(range(len(windows)), key=lambda i: windows[i][0])
     dt, clock = windows[order[len(order) // 2]]
     last_loss = float(loss)
@@ -556,7 +603,7 @@ def main():
         "windows": len(windows), "value_min": round(tokens_per_step * args.steps / windows[order[-1]][0], 1),
         "value_max": round(tokens_per_step * args.steps / windows[order[0]][0], 1),
         "ms_per_step_windows": [round(w[0] / args.steps * 1e3, 3) for w in windows],
-        "clock_mhz": clock, "clock_mhz_windows": [w[1] for w in windows],
+        "clock_mhz": clock, "clock_mhz_windows": [w[1] for w in windows], "board_power": board_power,
         "final_loss": round(last_loss, 4),
         "model_tflops_per_gpu": round(value / world * GFLOP_PER_TOKEN / 1e3, 1),
         "mfma_frac_whole_step": round(value / world * GFLOP_PER_TOKEN / 1e3 / PEAK_BF16_TFLOPS, 4),

@@ -21,6 +21,7 @@ cp $O/attn_bwd.txt profiles/${R}_attn_bwd_time.txt
 [ -f $O/decode_stamps.txt ] && cp $O/decode_stamps.txt profiles/${R}_decode_stamps.txt
 [ -f $O/gen_host_wait.txt ] && cp $O/gen_host_wait.txt profiles/${R}_generation_host_wait.txt
 [ -f $O/traffic_by_shape.txt ] && cp $O/traffic_by_shape.txt profiles/${R}_gemm_traffic_by_shape_b${B}.txt
+[ -f $O/gen_trace_neighbours.txt ] && cp $O/gen_trace_neighbours.txt profiles/${R}_generation_trace_neighbours.txt
 cp $O/topk_time.txt profiles/${R}_topk_time.txt
 grep '^{' $O/gen_bench.log | tail -1 > profiles/${R}_generation_bench.json
 python tools/summarize_rocprof.py $O/prof_gen/g_kernel_stats.csv 6 > profiles/${R}_generation_kernel_stats.md
