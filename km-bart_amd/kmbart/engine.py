@@ -36,6 +36,8 @@ def pack_features(image_features, feat_dim, device):
         packed = torch.zeros((1, feat_dim), device=device)
     elif len(non_empty) == 1:
         packed = non_empty[0].contiguous()
+    elif torch.device(device).type != "cuda":
+        packed = torch.cat(non_empty, 0).contiguous()   # host-side use (tests of the batch layout): no kernel to launch
     else:
         # ONE launch per 128 tensors (kmb_pack_features) instead of torch.cat, which on this stack is a batched kernel plus ~one blit
         # per tensor (70 copy launches in front of a 64-sample generate); the sources are kept alive by the caller's `keep` list
