@@ -183,14 +183,14 @@ def test_l2_touches_have_no_register_destination(tmp_path):
 
 
 def test_gemm_asm_transposing_reads_are_waited_for(tmp_path):
-    """csrc/gemm.hip reads its token-major operands with `ds_read_b64_tr_b16` as INLINE ASM in the 128 x 128, 256 x 256 and persistent 256-wide
-    kernels (kmb_tr_read_asm: the intrinsic makes hipcc wait with vmcnt(0) behind every LDS-DMA issue, i.e. for the stage requested a moment ago).
+    """csrc/gemm.hip and csrc/gemm_lean.hip read their token-major operands with `ds_read_b64_tr_b16` as INLINE ASM in every kernel since round 6
+    (kmb_tr_read_asm / kmb_tr_read_asm_off: the intrinsic makes hipcc wait with vmcnt(0) behind every LDS-DMA issue, i.e. for the stage requested a moment ago).
     The compiler then does not know that those registers arrive later: between such a read and the next `s_waitcnt lgkmcnt(0)` no instruction may
     name them (KMB_TR_SYNC at the top of every sub-phase).  A property of the COMPILED code: compile to ISA (no GPU) and walk every kernel's
     control-flow graph (tools/gemm_tr_asm_hazards.py)."""
     import subprocess
     import sys
-    for src, least in (("gemm.hip", 9), ("gemm_lean.hip", 0)):   # (gemm_lean.hip: its token-major kernels once KMB_TR_ALL is the default)
+    for src, least in (("gemm.hip", 17), ("gemm_lean.hip", 6)):   # round 6: every kernel with a token-major operand (KMB_TR_ALL), gemm_lean.hip's six data-gradient kernels
         out = _compile_to_isa(src, str(tmp_path / (src + ".s")))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_tr_asm_hazards.py"), out], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-3000:]
