@@ -359,7 +359,11 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_
   // against 10.80 (256: 10.95), b = 32 5.99 with 256 against 6.17, b = 256 16.7 with 512 against 18.3 with 256.
   static const int fill_env = KMB_DIAG_ENV("KMB_WGRAD_FILL") ? atoi(KMB_DIAG_ENV("KMB_WGRAD_FILL")) : 0;   // A/B knob
   const int mmax = h->Me > h->Md ? h->Me : h->Md;   // tokens of the longer side: how busy the caller's stream keeps the chip
-  const int fill = fill_env > 0 ? fill_env : mmax <= 4096 ? 256 : mmax <= 8192 ? 384 : 512;
+  // Round 6: 768 slots from 16384 tokens on (was 512).  With the transposing reads as inline asm in every split-K kernel (no drained prefetch) a
+  // slice is cheaper than it was when 512 was measured: same box, alternating processes (KMB_WGRAD_FILL, diagnostic library, two rounds each):
+  // b = 256 14.17-14.20 ms with 768 against 14.30-14.38 with 512 (1024: 14.28-14.30, 1536: 15.2), b = 512 24.20-24.34 against 24.46-24.59,
+  // b = 1024 44.49-44.57 against 44.61-45.01; b = 128 (8192 tokens: stays at 384) 9.40-9.44 with 768 against 9.17-9.26.
+  const int fill = fill_env > 0 ? fill_env : mmax <= 4096 ? 256 : mmax <= 8192 ? 384 : 768;
   int S = fill / tiles;   // floor: a partial last round costs more than it fills
                          // (tools/wgrad_split_sweep.py: 36 tiles S14 59 us vs S11 70 us, 72 tiles S7 97 vs S6 104)
   if (S > 16) S = 16;
