@@ -291,6 +291,11 @@ int run_gemm(const KmbGemm& g, hipStream_t s) {
     const int nt = g.K / 64;
     static const int small_fill = KMB_DIAG_ENV("KMB_SMALL_FILL") ? atoi(KMB_DIAG_ENV("KMB_SMALL_FILL")) : 512;   // A/B knob
     int S = tiles > 0 ? small_fill / tiles : 1;
+    // Round 6: only for <= 48 tiles (M <= 1024 rows of N = 768: b <= 16 encoder rows, b <= 32 decoder rows).  Above that the four-stage 128 x 128
+    // kernel (variant 5) -- whose K loop lost its drained prefetch and its accumulator shuffles this round -- runs a lone workgroup's whole K loop
+    // faster than five slices + the reduction pass: same box, alternating processes, two rounds (KMB_SMALL_SPLIT=1 | 0): b = 48 6.35-6.37 -> 6.18-6.24 ms,
+    // b = 64 6.83-6.91 -> 6.57-6.74, b = 96 8.44-8.52 -> 8.13-8.15; b = 32 and 128 equal; b = 16 4.80-4.86 with the split, 5.05-5.11 without.
+    if (tiles > 48) S = 1;
     if (S > 8) S = 8;
     if (S > nt / 4) S = nt / 4;
     while (S > 1 && (size_t)S * g.M * g.N > g_small_floats) --S;
