@@ -378,9 +378,10 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_
   // per XCD under the slice-major enumeration -- measured 18 % slower on the weight gradients: 780 -> 638 TFLOP/s.)
   // (wider ranges gain what the longer slab reduction costs -- unless the reduction is very long: 2304x768 over 65536
   // tokens, 108 tiles: 9 slices of the 256x256 kernel 251 us against 4 of the 128x128 kernel 294)
+  static const int slots256 = KMB_DIAG_ENV("KMB_WG256_SLOTS") ? atoi(KMB_DIAG_ENV("KMB_WG256_SLOTS")) : 256;   // A/B knob: workgroup slots the 256 x 256 slices fill
   if (tiles >= 96 && tiles <= 160) {
     const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    const int s256 = 256 / tiles256;
+    const int s256 = slots256 / tiles256;
     if (s256 > S && ((tiles >= 128 && nt >= 512) || nt / s256 >= 100)) S = s256;
   }
   // More 256x256 tiles than CUs and a poorly filled last round (the tied 50320x768 matrix: 591 tiles = 2.31 rounds, 77 %
@@ -400,7 +401,7 @@ int run_wgrad(kmb_handle* h, KmbGemm g, hipStream_t s, float* slab, size_t slab_
   // 108 tiles): two or more slices so that the 256x256 kernel covers the chip once
   if (S <= 1 && nt >= 128) {
     const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    if (tiles256 >= 64 && tiles256 <= 128) S = 256 / tiles256;
+    if (tiles256 >= 64 && tiles256 <= 128) S = slots256 / tiles256;
   }
   if (S > nt / 2) S = nt / 2;
   while (S > 1 && (size_t)S * g.M * g.N > slab_floats) --S;
