@@ -535,7 +535,7 @@ def main():
     ddp = DistributedDataParallel(model, device_ids=[local], reduce_single_rank=force_dist) if use_dist else model
     ddp.train()
     opt = AdamW(model.parameters(), lr=args.lr)
-    opt.allow_overlap(True)   # train_step_fwd_bwd + step run back to back: nothing touches the gradients in between
+    opt.allow_overlap(os.environ.get("KMB_BENCH_NO_OPT_OVERLAP", "0") != "1")   # train_step_fwd_bwd + step run back to back: nothing touches the gradients in between (the env hook: A/B of the per-bucket overlap)
     if use_dist:
         ddp.attach_optimizer(opt)   # each piece's AdamW right behind its all-reduce on the communication stream
 
