@@ -197,6 +197,17 @@ def test_gemm_asm_transposing_reads_are_waited_for(tmp_path):
         checked = [l for l in r.stdout.splitlines() if "transposing reads" in l]
         assert len(checked) >= least, "%s: expected the kernels with inline-asm reads, found %d:\n%s" % (src, len(checked), r.stdout[-2000:])
         assert "total violations 0" in r.stdout
+        # the same compiled code, K loop by K loop (tools/gemm_kloop_audit.py; round 6 removed all of these, profiles/r06_gemm_kloop_audit.md):
+        # no accumulator shuffled between the register files, nothing spilled to scratch inside a K step
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from gemm_kloop_audit import audit_file
+        rows = audit_file(out, src)
+        assert len(rows) >= (29 if src == "gemm.hip" else 12), (src, len(rows))
+        for row in rows:
+            name, accvgpr, scratch = row[0], row[6], row[8]
+            assert accvgpr == 0, "%s: %d v_accvgpr moves inside its K step" % (name, accvgpr)
+            allowed = 1 if name.startswith("gemm_kernel_v11<true, false, 256, 8>") else 0   # (one reload at the TILE switch, in the loop's tail block)
+            assert scratch <= allowed, "%s: %d scratch accesses inside its K step" % (name, scratch)
 
 
 def test_tr_asm_hazard_checker_sees_a_violation(tmp_path):

@@ -80,32 +80,40 @@ def signature(seg):
     return re.sub(r"([A-Za-z])\1{3,}", lambda m: "%s*%d " % (m.group(1), len(m.group(0))), r)
 
 
+def audit_file(path, src="gemm.hip", sig_for=()):
+    """rows (kernel, loop instructions, MFMAs, LDS-DMA pieces, plain LDS reads, transposing LDS reads, v_accvgpr moves, s_nop, scratch, waits) of
+    every GEMM kernel in the device assembly `path` (tests/test_cabi_cpu.py asserts on these for the product build)"""
+    s = open(path).read()
+    ks = list(kernels(s))
+    dm = demangle([k for k, _ in ks])
+    rows = []
+    for name, b in ks:
+        if src != "gemm.hip" and ("lean" not in name and "pair" not in name):
+            continue   # gemm_lean.hip / gemm_pair.hip include gemm.hip's device code: only their own kernels
+        lp = k_loop(b)
+        if lp is None:
+            continue
+        seg = [l.strip() for l in b[lp[0]:lp[1] + 1]]
+        ins = [l for l in seg if l and not l.startswith(";") and not l.startswith(".")]
+        waits = " ".join("vmcnt(%s)" % re.search(r"vmcnt\((\d+)\)", l).group(1) for l in ins if l.startswith("s_waitcnt") and "vmcnt" in l)
+        pretty = dm.get(name, name).replace("(anonymous namespace)::", "")
+        pretty = re.sub(r"\(KmbGemm.*$", "", re.sub(r"^void ", "", pretty))
+        rows.append((pretty, len(ins), sum(l.startswith("v_mfma") for l in ins), sum(l.startswith("global_load_lds") for l in ins),
+                     sum(l.startswith("ds_read") and "_tr_" not in l for l in ins), sum(l.startswith("ds_read_b64_tr") for l in ins),
+                     sum(l.startswith("v_accvgpr") for l in ins), sum(l.startswith("s_nop") for l in ins),
+                     sum(l.startswith("scratch_") for l in ins), waits or "-"))
+        if any(p in pretty for p in sig_for):
+            print("<!-- %s: %s -->" % (pretty, signature(seg)))
+    return rows
+
+
 def main():
     defines = [a for a in sys.argv[1:] if a.startswith("-D")]
     sig_for = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--sig"]
     rows = []
     with tempfile.TemporaryDirectory() as td:
         for src in ("gemm.hip", "gemm_lean.hip", "gemm_pair.hip"):
-            s = open(compile_to_isa(src, defines, td)).read()
-            ks = list(kernels(s))
-            dm = demangle([k for k, _ in ks])
-            for name, b in ks:
-                if src != "gemm.hip" and ("lean" not in name and "pair" not in name):
-                    continue   # gemm_lean.hip / gemm_pair.hip include gemm.hip's device code: only their own kernels
-                lp = k_loop(b)
-                if lp is None:
-                    continue
-                seg = [l.strip() for l in b[lp[0]:lp[1] + 1]]
-                ins = [l for l in seg if l and not l.startswith(";") and not l.startswith(".")]
-                waits = " ".join("vmcnt(%s)" % re.search(r"vmcnt\((\d+)\)", l).group(1) for l in ins if l.startswith("s_waitcnt") and "vmcnt" in l)
-                pretty = dm.get(name, name).replace("(anonymous namespace)::", "")
-                pretty = re.sub(r"\(KmbGemm.*$", "", re.sub(r"^void ", "", pretty))
-                rows.append((pretty, len(ins), sum(l.startswith("v_mfma") for l in ins), sum(l.startswith("global_load_lds") for l in ins),
-                             sum(l.startswith("ds_read") and "_tr_" not in l for l in ins), sum(l.startswith("ds_read_b64_tr") for l in ins),
-                             sum(l.startswith("v_accvgpr") for l in ins), sum(l.startswith("s_nop") for l in ins),
-                             sum(l.startswith("scratch_") for l in ins), waits or "-"))
-                if any(p in pretty for p in sig_for):
-                    print("<!-- %s: %s -->" % (pretty, signature(seg)))
+            rows += audit_file(compile_to_isa(src, defines, td), src, sig_for)
     print("kernel | loop instructions | MFMAs | LDS-DMA pieces | plain / transposing LDS reads | v_accvgpr moves | s_nop | scratch | vector-memory waits")
     print("|---|---|---|---|---|---|---|---|---|")
     for r in rows:
