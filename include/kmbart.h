@@ -300,6 +300,17 @@ int kmb_beam_merge_select(const float* val, const int32_t* idx, int B, int num_b
 int kmb_beam_step(const float* logits, int ld, int V, int B, int num_beams, const float* add, int force_token, int ban_token,
                   int k, int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
                   float* scratch, int64_t scratch_floats, void* stream);
+/* The decode loop's form of kmb_beam_step, on the logits the last kmb_gen_step wrote (`logits` / `ld` as passed there; V and B are
+ * the handle's): same arguments, outputs and selection.  When that step's vocabulary projection ran the all-rows kernel
+ * (257 .. 320 beam rows -- the benchmarked 64 x 5) it also left every row's maximum and sum-exp per 256-column block, and ONE
+ * launch takes the row's log-sum-exp from those and reads only the blocks that can hold one of the k best, instead of
+ * streaming the logits a second time; the scores then differ from kmb_beam_step's in the last bits (the log-sum-exp is
+ * grouped by 197 blocks instead of 4 parts), ties still go to the smaller index.  Any other shape, a forced token, or
+ * KMB_GEN_HEAD_STATS=0 in the environment: kmb_beam_step itself.  Reference: one step of transformers 3.0.2
+ * _generate_beam_search as reached from src/model/mixins.py:336-361, scores adjusted as in mixins.py:386-417. */
+int kmb_gen_beam_step(kmb_handle* h, const float* logits, int ld, int num_beams, const float* add, int force_token, int ban_token,
+                      int k, int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                      float* scratch, int64_t scratch_floats, void* stream);
 int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
 
 /* Data-parallel runs share the GPU between the GEMMs and RCCL's all-reduce kernel (reference: torch DDP's NCCL streams,
@@ -380,6 +391,14 @@ int kmb_op_gemm(const KmbGemm* p, void* stream);
 /* the same product on the "all rows" kernel (one workgroup per 256 output columns holds every row: M <= 320, forward layout, bias
  * only, fp32 output): what a generation decode step's vocabulary projection runs; bit-identical to kmb_op_gemm */
 int kmb_op_gemm_allrows(const KmbGemm* p, void* stream);
+/* ... and its statistics epilogue: stats[(row * blocks + blk) * 2] = max, [... + 1] = sum of exp(v - max) over the
+ * 256 columns of block blk, blocks = ceil(N / 256) (kmb_op_gemm_allrows_stats_floats(N) floats); kmb_beam_step_stats is kmb_beam_step selecting from them
+ * (stats_blocks = ceil(V / 256); what kmb_gen_step + kmb_gen_beam_step run) */
+int64_t kmb_op_gemm_allrows_stats_floats(int N);
+int kmb_op_gemm_allrows_stats(const KmbGemm* p, float* stats, void* stream);
+int kmb_beam_step_stats(const float* logits, int ld, int V, int B, int num_beams, const float* add, int force_token, int ban_token,
+                        int k, int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                        const float* stats, int stats_blocks, void* stream);
 /* n (1 .. 8) independent weight-gradient products dW_i = dY_i^T X_i (both operands token-major, fp32 output, no split-K) as ONE
  * launch walking all their 128 x 128 tiles: what kmb_backward issues per layer when the batch is short (<= 3072 tokens: `group_tokens`,
  * csrc/engine.cpp::backward_impl; torch

@@ -70,7 +70,27 @@ int kmb_op_gemm_allrows(const KmbGemm* p, void* stream) {
   const char* why = kmb_gemm_check(*p);
   if (!why) why = kmb_gemm_allrows_check(*p);
   if (why) return kmb_set_error(why);
-  return hipfail(kmb_gemm_allrows_launch(*p, (hipStream_t)stream), "gemm_allrows");
+  return hipfail(kmb_gemm_allrows_launch(*p, nullptr, (hipStream_t)stream), "gemm_allrows");
+}
+int64_t kmb_op_gemm_allrows_stats_floats(int N) { return (int64_t)kmb_gemm_allrows_stats_floats(N); }
+int kmb_op_gemm_allrows_stats(const KmbGemm* p, float* stats, void* stream) {
+  const char* why = kmb_gemm_check(*p);
+  if (!why) why = kmb_gemm_allrows_check(*p);
+  if (why) return kmb_set_error(why);
+  if (!stats) return kmb_set_error("kmb_op_gemm_allrows_stats: stats is required");
+  return hipfail(kmb_gemm_allrows_launch(*p, stats, (hipStream_t)stream), "gemm_allrows_stats");
+}
+int kmb_beam_step_stats(const float* logits, int ld, int V, int B, int num_beams, const float* add, int force_token, int ban_token,
+                        int k, int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                        const float* stats, int stats_blocks, void* stream) {
+  if (!logits || !out || !stats) return kmb_set_error("kmb_beam_step_stats: missing tensor");
+  if (!next_scores || !next_tokens || !next_beam_idx) return kmb_set_error("kmb_beam_step_stats: missing output");
+  const hipError_t e = kmb_beam_step_stats_launch(logits, ld, V, B, num_beams, add, force_token, ban_token, k, out, eos_token, next_scores,
+                                                  next_tokens, next_beam_idx, stats, stats_blocks, (hipStream_t)stream);
+  if (e == hipErrorNotSupported)
+    return kmb_set_error("kmb_beam_step_stats: unsupported shape (B * num_beams <= 320, k <= 16, num_beams <= 16, V %% 4 == 0, "
+                         "stats_blocks == ceil(V / 256))");
+  return hipfail(e, "beam_step_stats");
 }
 int kmb_op_attn_fwd(const KmbAttn* p, void* stream) {
   const char* why = kmb_attn_check(*p, 0);

@@ -189,6 +189,9 @@ struct kmb_handle {
     // K and V cache ([R, t, d] x 12 buffers: 5-40 us per decode step at batch 64 x 5 beams); the caches are never copied
     // (kc[0] / vc[0] only).  KMB_GEN_HIST=0 restores the physical reorder.
     int32_t* hist[2] = {nullptr, nullptr}; int hcur = 0; bool use_hist = true;
+    // per-block (maximum, sum-exp) pairs the last kmb_gen_step's vocabulary projection left beside the logits at head_stats_for
+    // (head_stats_blocks column blocks; 0: none -- the step ran another GEMM kernel, or no projection): kmb_gen_beam_step selects from them
+    float* head_stats = nullptr; int head_stats_blocks = 0; const float* head_stats_for = nullptr;
     uint64_t packed_version = 0; const bf16_t* packed_at = nullptr;   // the fragment-order copies at wp[0] were made from mirror version ...
   } gen;
 
@@ -1145,10 +1148,14 @@ int kmb_read_status_async(kmb_handle* h, int32_t* status_host, void* stream) {
 // workgroup per 256 vocabulary columns holds ALL rows, so every row of the tied matrix crosses a CU's memory pipe once
 // (gemm.hip "All rows" kernel: 58 -> 47 us at 320 rows, tools/allrows_time.py; at <= 192 rows the 128x128 tiles already read
 // the matrix once or twice and are faster: 31 against 39 us).  Bit-identical either way; KMB_GEMM_ALLROWS=0: always the tuner's pick.
-static int run_vocab_gemm(const KmbGemm& g, hipStream_t s) {
+// stats / stats_blocks (a generation step): the all-rows kernel also leaves every row's per-block (maximum, sum-exp) pairs there and
+// *stats_blocks = their number, for the beam step that follows (loss.hip beam_stats_merge_kernel); 0 when another kernel ran.
+static int run_vocab_gemm(const KmbGemm& g, hipStream_t s, float* stats = nullptr, int* stats_blocks = nullptr) {
   static const bool allrows_ok = !(KMB_DIAG_ENV("KMB_GEMM_ALLROWS") && KMB_DIAG_ENV("KMB_GEMM_ALLROWS")[0] == '0');
+  if (stats_blocks) *stats_blocks = 0;
   if (allrows_ok && !g_f32 && g.M > 256 && g.M <= 320 && kmb_gemm_allrows_check(g) == nullptr) {
-    HIPCHK(kmb_gemm_allrows_launch(g, s));
+    HIPCHK(kmb_gemm_allrows_launch(g, stats_blocks ? stats : nullptr, s));
+    if (stats_blocks && stats) *stats_blocks = kmb_gemm_allrows_blocks(g.N);
     return 0;
   }
   return run_gemm(g, s);
@@ -1995,6 +2002,7 @@ struct GenLayout {
   std::vector<bf16_t*> wp;   // per layer: self q|k|v, self out, cross q, cross out, fc1, fc2 in fragment order (decode.hip)
   uint32_t* bars;            // group-barrier counters of the resident decoder-layers kernel (decode.hip)
   int32_t* hist[2];          // history index of the self-attention caches [R, Tmax], ping-pong over beam reorders
+  float* head_stats;         // the all-rows vocabulary projection's per-block (maximum, sum-exp) pairs (kmb_gen_beam_step)
 };
 constexpr int GEN_MAX_SPLIT = 12;
 
@@ -2042,6 +2050,7 @@ size_t layout_gen(const kmb_handle* h, char* base, size_t cap, int B, int S, int
   g.bars = bp.take<uint32_t>(kmb_decode_layers_bar_words((int)R, Ld > 0 ? Ld : 1) + 64);
 #endif
   g.hist[0] = bp.take<int32_t>(R * Tmax); g.hist[1] = bp.take<int32_t>(R * Tmax);
+  g.head_stats = bp.take<float>(kmb_gemm_allrows_stats_floats(h->V));
   if (out) *out = g;
   return bp.used();
 }
@@ -2085,6 +2094,7 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.last_x = nullptr; G.last_z = nullptr; G.last_g = nullptr; G.last_b = nullptr;
   G.bars = g.bars;
   G.hist[0] = g.hist[0]; G.hist[1] = g.hist[1]; G.hcur = 0;
+  G.head_stats = g.head_stats; G.head_stats_blocks = 0; G.head_stats_for = nullptr;
   { const char* he = getenv("KMB_GEN_HIST"); G.use_hist = !(he && he[0] == '0'); }
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam), all layers in ONE GEMM
   if (Ld > 0) {
@@ -2299,11 +2309,41 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
     bf16_t* t = x; x = xn; xn = t;
   }
   if (!fused) { G.last_x = x; G.last_z = nullptr; }
+  G.head_stats_blocks = 0; G.head_stats_for = nullptr;
   if (logits_out) {
     KmbGemm g = lin_fwd(x, d, h->wb(h->shared), h->flb, R, h->V, d);
     g.out_f32 = logits_out; g.ld_out_f32 = h->Vpad;
-    KCHK(run_vocab_gemm(g, s));
+    // KMB_GEN_HEAD_STATS=0: the projection without its statistics epilogue, the beam step in two launches over the logits (read per call:
+    // tests compare the two in one process)
+    const char* hs_env = getenv("KMB_GEN_HEAD_STATS");
+    const bool want_stats = !(hs_env && hs_env[0] == '0');
+    KCHK(run_vocab_gemm(g, s, want_stats ? G.head_stats : nullptr, want_stats ? &G.head_stats_blocks : nullptr));
+    if (G.head_stats_blocks > 0) G.head_stats_for = logits_out;
   }
+  return 0;
+}
+
+// The beam step of the decode loop on the logits of the last kmb_gen_step (mixins.py:386-417 via transformers 3.0.2
+// _generate_beam_search: log_softmax + beam score, the 2 * num_beams best per batch item, the next step's beams): kmb_beam_step's
+// arguments and outputs.  When that step's vocabulary projection left its per-block statistics (all-rows kernel, 257 .. 320 beam rows),
+// ONE launch selects from them; otherwise kmb_beam_step's two launches over the logits.
+int kmb_gen_beam_step(kmb_handle* h, const float* logits, int ld, int num_beams, const float* add, int force_token, int ban_token, int k,
+                      int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, float* scratch,
+                      int64_t scratch_floats, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  auto& G = h->gen;
+  if (!G.active) return fail("kmb_gen_beam_step: call kmb_gen_begin first");
+  if (!logits || !out || !next_scores || !next_tokens || !next_beam_idx) return fail("kmb_gen_beam_step: missing tensor");
+  if (num_beams != G.nb) return fail("kmb_gen_beam_step: num_beams %d, kmb_gen_begin had %d", num_beams, G.nb);
+  hipError_t e = hipErrorNotSupported;
+  if (force_token < 0 && G.head_stats_blocks > 0 && G.head_stats_for == logits)
+    e = kmb_beam_step_stats_launch(logits, ld, h->V, G.B, num_beams, add, force_token, ban_token, k, out, eos_token, next_scores,
+                                   next_tokens, next_beam_idx, G.head_stats, G.head_stats_blocks, s);
+  if (e == hipErrorNotSupported)
+    e = kmb_beam_step_launch(logits, ld, h->V, G.B, num_beams, add, force_token, ban_token, k, out, eos_token, next_scores, next_tokens,
+                             next_beam_idx, scratch, scratch_floats > 0 ? (size_t)scratch_floats : 0, s);
+  if (e == hipErrorNotSupported) return fail("kmb_gen_beam_step: unsupported shape (k <= 16, num_beams <= 16, num_beams * k <= 256)");
+  HIPCHK(e);
   return 0;
 }
 

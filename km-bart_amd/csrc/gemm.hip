@@ -1258,19 +1258,33 @@ __global__ __launch_bounds__(512) void gemm_kernel_v8(const KmbGemm p) {
 // forward layout, fp32 logits).  The 128x128 kernel re-reads the R activation rows for each of 394 column tiles and the tied
 // matrix for each of 3 row tiles: 463 MB through the CUs' memory pipes for 141 MB of operands, and that pipe (~50 GB/s per CU),
 // not the MFMAs, is what a decode-sized GEMM waits for (51-71 us inside a step).  Here ONE workgroup holds all rows: tile =
-// 320 rows x 256 columns, eight waves 2 x 4 of 160 x 64 (10 x 4 MFMA tiles, 160 accumulator registers), two 72 KB LDS stages
-// filled by LDS-DMA (same K-contiguous images and swizzle as the other kernels), 197 workgroups = one round, each weight row
-// read exactly once: 174 MB.  The K loop is deliberately plain (wait, barrier, 80 MFMAs, barrier, next fetch): 72 KB per K
-// step arrive in ~1.4 us, the MFMAs take 0.5.  Same MFMA, same k order, fp32 bias add: bit-identical to every other variant.
+// 320 rows x 256 columns, eight waves 2 x 4 of 160 x 64 (10 x 4 MFMA tiles, 160 accumulator registers), LDS stages
+// filled by LDS-DMA, 197 workgroups = one round, each weight row read exactly once: 174 MB.  Rounds 4-5: two 72 KB stages of 64 k,
+// a plain loop (wait, barrier, 80 MFMAs, barrier, next fetch); round 6: four 36 KB stages of 32 k, see below.
+// Same MFMA, same k order, fp32 bias add: bit-identical to every other variant.
 // Rows past M are clamped copies of the last row (computed, never stored).
 // (Measured and dropped at the end of round 4: 208-column tiles -- 242 workgroups instead of 197, 26 KB of the tied matrix per K step
 // and workgroup instead of 32 -- 47.0 -> 47.8 us: what is saved on the weight stream comes back as 45 more copies of the row panel.)
 constexpr int VR = 320, VN = 256;
-constexpr int V_A = VR * BK * 2;                  // 40 KB
-constexpr int V_STG = (VR + VN) * BK * 2;         // 72 KB
-constexpr int LDS_VOC = 2 * V_STG;                // 144 KB
+// Round 6: FOUR stages of 32 k (36 KB each, the same 144 KB) instead of two of 64.  The stamps (tools/allrows_stamps.py) put a 64-deep
+// step of the two-stage loop at 2.4-2.8 us -- 1.1 us of MFMAs and a wait for ONE 72 KB stage that was issued a step earlier: with a
+// single stage in flight behind the barrier a CU drew 27 GB/s through its memory pipe, half of what it takes with a deep queue.  Now
+// a step is: wait for the oldest stage, ONE barrier (it also says every wave is done reading the stage before), issue the stage three
+// ahead into that freed buffer, 40 MFMAs -- three stages (108 KB) are in flight under the MFMAs.  A stage image is [rows][32 k] =
+// 64-byte rows, sixteen rows per 1 KB LDS-DMA piece = one MFMA row tile; the 16-byte k chunk c of row r sits in slot c ^ (-(r >> 2) & 3):
+// ds_read_b128 serves the lanes in the groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (guide, LDS section), and with lane =
+// 16 g + r reading chunk g of row r each group then covers all sixteen 16-byte slots of the 256-byte bank row ((r >> 2) & 3 instead of
+// its negative: two lanes per slot, measured).  Same MFMA, same k order (stage s = the old step s / 2, half s & 1):
+// bit-identical sums.  Pieces per stage: 20 of the row panel + 16 of the tied matrix = 5 for waves 0-3, 4 for waves 4-7 (the counted
+// waits differ by wave; the branch is scalar).
+constexpr int VK = 32;
+constexpr int V_A = VR * VK * 2;                  // 20 KB
+constexpr int V_STG = (VR + VN) * VK * 2;         // 36 KB
+constexpr int V_NSTG = 4;
+constexpr int LDS_VOC = V_NSTG * V_STG;           // 144 KB
 
-__global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p) {
+template <bool STATS>
+__global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1282,16 +1296,22 @@ __global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p) {
   for (int i = 0; i < 10; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nt = p.K / BK;
-  uint32_t offA[5], offB[4];
+  const int ns = p.K / VK;
+  // lane l of a piece fills LDS bytes [16 l, 16 l + 16): row l >> 2 of the piece's sixteen, slot l & 3 = chunk (l & 3) ^ (-(l >> 4) & 3)
+  const int prow = lane >> 2, pchunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+  uint32_t offA[3], offB[2];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {   // 40 pieces of 8 rows x 128 bytes: five per wave
-    const int row = (wave * 5 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+  for (int i = 0; i < 3; ++i) {   // row-panel pieces wave, wave + 8 and (waves 0-3) wave + 16
+    const int row = (wave + 8 * i) * 16 + prow;
     const int grow = row < p.M ? row : p.M - 1;
-    offA[i] = (uint32_t)((grow * p.lda + c * 8) * 2);
+    offA[i] = (uint32_t)((grow * p.lda + pchunk * 8) * 2);
   }
-  dma_offsets256<true>(offB, p.ldb, col0, p.N, wave, lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {   // tied-matrix pieces 2 wave, 2 wave + 1
+    const int col = col0 + (2 * wave + i) * 16 + prow;
+    const int gcol = col < p.N ? col : p.N - 1;
+    offB[i] = (uint32_t)(((gcol - col0) * p.ldb + pchunk * 8) * 2);
+  }
   auto uniform_ptr = [](const char* ptr) {
     const uint64_t a = reinterpret_cast<uint64_t>(ptr);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
@@ -1300,50 +1320,152 @@ __global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p) {
   };
   const char* const gA = reinterpret_cast<const char*>(p.A);
   const char* const gB = reinterpret_cast<const char*>(p.B) + (size_t)col0 * p.ldb * 2;
-  auto dma_stage = [&](int ks, int buf) {
-    char* st = smem + buf * V_STG;
-    const char* ga = uniform_ptr(gA + (size_t)ks * BK * 2);
-    const char* gb = uniform_ptr(gB + (size_t)ks * BK * 2);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) dma_piece(ga, offA[i], st + (wave * 5 + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(gb, offB[i], st + V_A + (wave * 4 + i) * 1024);
+  auto dma_stage = [&](int s) {
+    char* st = smem + (s & (V_NSTG - 1)) * V_STG;
+    const char* ga = uniform_ptr(gA + (size_t)s * VK * 2);
+    const char* gb = uniform_ptr(gB + (size_t)s * VK * 2);
+    dma_piece(ga, offA[0], st + wave * 1024);
+    dma_piece(ga, offA[1], st + (wave + 8) * 1024);
+    if (wave < 4) dma_piece(ga, offA[2], st + (wave + 16) * 1024);
+    dma_piece(gb, offB[0], st + V_A + (2 * wave) * 1024);
+    dma_piece(gb, offB[1], st + V_A + (2 * wave + 1) * 1024);
   };
-  dma_stage(0, 0);
-  if (nt > 1) dma_stage(1, 1);
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) __builtin_amdgcn_s_waitcnt(0x0F79);   // vmcnt(9): all but the newer stage's nine pieces have landed
-    else __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
-    __syncthreads();
-    const char* cur = smem + (t & 1) * V_STG;
+  KMB_STAMP(0);
+  KMB_STAMP_ID();
+  dma_stage(0);
+  if (ns > 1) dma_stage(1);
+  if (ns > 2) dma_stage(2);
+  const int frag_off = r * 64 + ((g ^ ((0 - (r >> 2)) & 3)) << 4);
+  for (int s = 0; s < ns; ++s) {
+    // the oldest stage in flight has landed: all but the (up to two) newer ones' pieces -- five per stage for waves 0-3, four for 4-7
+    const int newer = ns - 1 - s;
+    if (wave < 4) {
+      if (newer >= 2) __builtin_amdgcn_s_waitcnt(0x0F7A);        // vmcnt(10)
+      else if (newer == 1) __builtin_amdgcn_s_waitcnt(0x0F75);   // vmcnt(5)
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+    } else {
+      if (newer >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
+      else if (newer == 1) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    // stage s is complete, and every wave is done reading stage s - 1.  NOT __syncthreads(): its fence is a vmcnt(0) -- the rounds 4-5
+    // form of this loop had one, so its counted vmcnt(9) never held and every step drained the stage it had just issued
+    __builtin_amdgcn_s_barrier();
+    if (s == 0) KMB_STAMP(1);
+    if (s == ns / 2) KMB_STAMP(3);
+    // The stage three ahead goes into stage s - 1's buffer, one piece per eight MFMAs: an LDS-DMA piece holds the issuing wave for
+    // 60-180 cycles, and the two waves of a SIMD leave the barrier together -- issued as a burst, both stall at once and the matrix pipe idles
+    const bool more = s + 3 < ns;
+    char* nst = smem + ((s + 3) & (V_NSTG - 1)) * V_STG;
+    const char* ga = uniform_ptr(gA + (size_t)(s + 3) * VK * 2);
+    const char* gb = uniform_ptr(gB + (size_t)(s + 3) * VK * 2);
+    const char* cur = smem + (s & (V_NSTG - 1)) * V_STG + frag_off;
+    // every fragment read of the stage first (14 x 16 bytes per lane), then the MFMAs as the reads return
+    bf16x8 fb[4], fa[10];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fb[4];
+    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(cur + V_A + (wn * 4 + j) * 1024);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag3<true, VN>(cur + V_A, wn * 4 + j, kk, r, g);
+    for (int i = 0; i < 10; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(cur + (wm * 10 + i) * 1024);
 #pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        const bf16x8 fa = read_frag3<true, VR>(cur, wm * 10 + i, kk, r, g);
+    for (int i = 0; i < 10; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);   // C^T tile
+      for (int j = 0; j < 4; ++j) {
+#ifndef KMB_AR_NOMFMA   // (timing builds: the loop without its MFMAs / without its DMA)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // C^T tile
+#else
+        acc[i][j][0] += (float)fa[i][j] + (float)fb[j][1];
+#endif
+      }
+#ifndef KMB_AR_NODMA
+      if (more && (i & 1)) {
+#else
+      if (more && (i & 1) && p.M < 0) {
+#endif
+        if (i == 1) dma_piece(gb, offB[0], nst + V_A + (2 * wave) * 1024);
+        if (i == 3) dma_piece(ga, offA[0], nst + wave * 1024);
+        if (i == 5) dma_piece(gb, offB[1], nst + V_A + (2 * wave + 1) * 1024);
+        if (i == 7) dma_piece(ga, offA[1], nst + (wave + 8) * 1024);
+        if (i == 9 && wave < 4) dma_piece(ga, offA[2], nst + (wave + 16) * 1024);
       }
     }
-    __syncthreads();   // everyone is done reading this buffer
-    if (t + 2 < nt) dma_stage(t + 2, t & 1);
   }
+  __syncthreads();   // (the statistics epilogue reuses the stages)
+  KMB_STAMP(2);
   // transposed accumulators: lane (r, g) holds C[16 i + r][16 j + 4 g .. + 3] -> one 16-byte store per tile and lane
+  if constexpr (!STATS) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = col0 + wn * 64 + j * 16 + g * 4;
-    if (col >= p.N) continue;   // N % 4 == 0 (launcher): a group of four columns is inside or outside
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + wn * 64 + j * 16 + g * 4;
+      if (col >= p.N) continue;   // N % 4 == 0 (launcher): a group of four columns is inside or outside
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int row = wm * 160 + i * 16 + r;
+        if (row < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * p.ld_out_f32 + col) = acc[i][j] + b4;
+      }
+    }
+  } else {
+    // STATS (round 6, the beam step's first stage folded in): besides the logits, every row's (maximum, sum of exp(v - maximum)) over
+    // this workgroup's 256 columns -> stats[(row * blocks + block) * 2 + 0 / 1].  The step's selection kernel (loss.hip
+    // beam_stats_merge_kernel) gets the row's log-sum-exp from the 197 pairs and reads only the blocks whose maximum can hold one of
+    // the k best, instead of streaming the 64 MB of logits a second time.  The exps run between the stores (the epilogue is bound by
+    // the store issue rate, the vector ALUs idle).  Columns >= N count as -inf.
+    float* smax = reinterpret_cast<float*>(smem);   // [VR][4]: per (row, wave column) -- the stages are free behind the K loop's last barrier
+    float* ssum = smax + VR * 4;                    // [VR][4]
+    f32x4 b4[4];
+    bool inside[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + wn * 64 + j * 16 + g * 4;
+      inside[j] = col < p.N;
+      b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr && inside[j]) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + col);
+    }
+    const bool ragged = col0 + VN > p.N;   // the last block only
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      float lm = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = acc[i][j] + b4[j];
+        if (ragged && !inside[j]) acc[i][j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        lm = fmaxf(fmaxf(lm, fmaxf(acc[i][j][0], acc[i][j][1])), fmaxf(acc[i][j][2], acc[i][j][3]));
+      }
+      lm = fmaxf(lm, __shfl_xor(lm, 16, 64));
+      lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
+      if (g == 0) smax[(wm * 160 + i * 16 + r) * 4 + wn] = lm;
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int row = wm * 160 + i * 16 + r;
-      if (row < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * p.ld_out_f32 + col) = acc[i][j] + b4;
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax + row * 4);
+      const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));   // finite: every block has a column < N
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (row < p.M && inside[j])
+          *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * p.ld_out_f32 + col0 + wn * 64 + j * 16 + g * 4) = acc[i][j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum += __expf(acc[i][j][q] - m);
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (g == 0) ssum[row * 4 + wn] = sum;
+    }
+    __syncthreads();
+    if (tid < p.M) {   // M <= VR <= 512 threads
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(smax + tid * 4);
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(ssum + tid * 4);
+      // [row][block] pairs: the selection kernel reads a row's pairs with consecutive lanes (this side: 320 eight-byte stores)
+      float2 ms;
+      ms.x = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      ms.y = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      reinterpret_cast<float2*>(stats)[(size_t)tid * gridDim.x + blockIdx.x] = ms;
     }
   }
+  KMB_STAMP(4);
 }
 
 #endif  // KMB_GEMM_DEVICE_ONLY
@@ -2775,14 +2897,22 @@ const char* kmb_gemm_allrows_check(const KmbGemm& p) {
   return nullptr;
 }
 
-hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream) {
+// stats != nullptr: also the rows' per-block (maximum, sum-exp) pairs, kmb_gemm_allrows_stats_floats(p.N) floats:
+// stats[(row * blocks + block) * 2] = max, [... + 1] = sum of exp(v - max) over the block's 256 columns (blocks = ceil(N / 256))
+int kmb_gemm_allrows_blocks(int N) { return (N + VN - 1) / VN; }
+size_t kmb_gemm_allrows_stats_floats(int N) { return (size_t)kmb_gemm_allrows_blocks(N) * 2 * VR; }
+hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, float* stats, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_allrows, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_VOC);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_allrows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_VOC);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_kernel_allrows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_VOC);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_kernel_allrows, dim3((p.N + VN - 1) / VN), dim3(512), LDS_VOC, stream, p);
+  if (stats != nullptr)
+    hipLaunchKernelGGL(gemm_kernel_allrows<true>, dim3((p.N + VN - 1) / VN), dim3(512), LDS_VOC, stream, p, stats);
+  else
+    hipLaunchKernelGGL(gemm_kernel_allrows<false>, dim3((p.N + VN - 1) / VN), dim3(512), LDS_VOC, stream, p, (float*)nullptr);
   return hipGetLastError();
 }
 

@@ -15,7 +15,10 @@ constexpr int KMB_GEMM_GROUP_MAX = 8;
 const char* kmb_gemm_group_check(const KmbGemm* probs, int n);
 hipError_t kmb_gemm_group_launch(const KmbGemm* probs, int n, hipStream_t stream);
 const char* kmb_gemm_allrows_check(const KmbGemm& p);
-hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, hipStream_t stream);
+// stats != nullptr: also per (row, 256-column block) the maximum logit and the sum of exp(v - maximum), kmb_gemm_allrows_stats_floats(N) floats
+hipError_t kmb_gemm_allrows_launch(const KmbGemm& p, float* stats, hipStream_t stream);
+int kmb_gemm_allrows_blocks(int N);
+size_t kmb_gemm_allrows_stats_floats(int N);
 void kmb_gemm_set_shared_device(int on);   // persistent variants: hand out every tile dynamically
 // variant 6 (gemm_lean.hip): the eight-wave persistent 256 x 256 kernel rebuilt around the bare K loop of tools/mfma_loop.hip
 bool kmb_gemm_lean_ok(const KmbGemm& p);
@@ -156,6 +159,9 @@ hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_
 hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
                                 int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
                                 float* scratch, size_t scratch_floats, hipStream_t stream);
+hipError_t kmb_beam_step_stats_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
+                                      int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                                      const float* stats, int nblk, hipStream_t stream);
 hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out, int eos,
                                  float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, hipStream_t stream);
 // ban_token >= 0: that token's score is -inf AFTER the normalisation (min_length, transformers 3.0.2

@@ -859,6 +859,163 @@ __global__ __launch_bounds__(1024) void beam_combine_merge_kernel(const float* _
 }
 
 
+// ---- the beam step behind the all-rows vocabulary projection's STATS epilogue (round 6) ----
+// gemm.hip's gemm_kernel_allrows<true> leaves, per row and 256-column block, the block's maximum logit and its sum of exp(v - maximum):
+// stats[(row * nblk + blk) * 2], [... + 1].  With them ONE launch does what topk_part_kernel +
+// beam_combine_merge_kernel did, without streaming the 64 MB of logits again (topk_part: 22.9 us of a 553 us decode step):
+//   * log-sum-exp of the row from the nblk pairs;
+//   * T = the (k + 1 if a token is banned)-th largest block maximum: at least k admissible logits are >= T, so the k best are among
+//     the elements >= T, and those sit in the blocks whose maximum is >= T -- typically k or k + 1 blocks of 1 KB, read HS_BATCH at a time;
+//   * the k best of those candidates by (value desc, index asc) key, as everywhere else; then the item's merge (beam_merge_item).
+// More than HS_CAND elements >= T (rows of equal logits): k rounds of "largest key below the previous winner" over the selected blocks.
+// Same selection as the two-launch path; the scores differ from it in the last bits only through the log-sum-exp's grouping
+// (197 blocks of 256 columns instead of 4 parts).
+constexpr int HS_ROWS = 320, HS_COLS = 256, HS_CAND = 128, HS_BLK_MAX = 256, HS_BATCH = 12;   // HS_BATCH: blocks read at a time (k = 10: 10 or 11 blocks)
+
+__device__ __forceinline__ void beam_stats_row(const float* __restrict__ logits, int ldv, int V, const float* __restrict__ stats, int nblk,
+                                               int r, const float* __restrict__ add, int force_token, int ban, int k, float* val_row,
+                                               int32_t* idx_row, unsigned long long* cand, uint16_t* sel, int lane) {
+  const float a = add != nullptr ? add[r] : 0.f;
+  if (force_token >= 0) {   // (topk_combine_row)
+    for (int j = lane; j < k; j += 64) {
+      val_row[j] = j == 0 ? a : -INFINITY;
+      idx_row[j] = j == 0 ? force_token : (j - 1 < force_token ? j - 1 : j);
+    }
+    return;
+  }
+  float mq[4], sq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int blk = lane + 64 * q;
+    const bool in = blk < nblk;
+    const float2 ms = reinterpret_cast<const float2*>(stats)[(size_t)r * nblk + (in ? blk : 0)];
+    mq[q] = in ? ms.x : -INFINITY;
+    sq[q] = in ? ms.y : 0.f;
+  }
+  const float M = wave_max_f32_dpp(fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3])));
+  float S = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (mq[q] != -INFINITY) S += sq[q] * __expf(mq[q] - M);
+  S = wave_sum(S);
+  const float lse = M + __logf(S);
+  // T: the keff-th largest block maximum (a lane's four, sorted, pop one per round: equal maxima are counted one per lane and round)
+  const int keff = k + (ban >= 0 ? 1 : 0);
+  float h0 = mq[0], h1 = mq[1], h2 = mq[2], h3 = mq[3];
+  {
+    float t;
+#define KMB_CSWAP(x, y) t = fminf(x, y); x = fmaxf(x, y); y = t;
+    KMB_CSWAP(h0, h1) KMB_CSWAP(h2, h3) KMB_CSWAP(h0, h2) KMB_CSWAP(h1, h3) KMB_CSWAP(h1, h2)
+#undef KMB_CSWAP
+  }
+  float T = -INFINITY;
+  int cnt = 0;
+  for (int jr = 0; jr < keff && cnt < keff; ++jr) {
+    const float wm = wave_max_f32_dpp(h0);
+    if (wm == -INFINITY) break;
+    const bool mine = h0 == wm;
+    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+    T = wm;
+    if (mine) { h0 = h1; h1 = h2; h2 = h3; h3 = -INFINITY; }
+  }
+  if (cnt < keff) T = -INFINITY;   // fewer blocks than keff: every block is read, every admissible element is a candidate
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int n_sel = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool pick = lane + 64 * q < nblk && mq[q] >= T;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(pick);
+    if (pick) sel[n_sel + __builtin_popcountll(bal & below)] = (uint16_t)(lane + 64 * q);
+    n_sel += __builtin_popcountll(bal);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float* row = logits + (size_t)r * ldv;
+  int n = 0;
+  for (int base = 0; base < n_sel; base += HS_BATCH) {
+    f32x4 x[HS_BATCH];
+    int c0[HS_BATCH];
+#pragma unroll
+    for (int u = 0; u < HS_BATCH; ++u) {   // every load first, clamped
+      const int blk = sel[base + u < n_sel ? base + u : base];
+      c0[u] = blk * HS_COLS + lane * 4;
+      const bool in = base + u < n_sel && c0[u] < V;     // V % 4 == 0, ldv >= V: a group of four is inside or outside
+      x[u] = *reinterpret_cast<const f32x4*>(row + (in ? c0[u] : 0));
+      if (!in) c0[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < HS_BATCH; ++u) {
+      if (base + u < n_sel) {   // wave-uniform (no `break`: the loop must unroll, x[] lives in registers)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool hit = c0[u] >= 0 && x[u][e] >= T && c0[u] + e != ban;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+        if (bal != 0ull) {
+          const int slot = n + __builtin_popcountll(bal & below);
+          if (hit && slot < HS_CAND) cand[slot] = topk_key(x[u][e], c0[u] + e);
+          n += __builtin_popcountll(bal);
+        }
+      }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (n <= HS_CAND) {
+    unsigned long long k0 = lane < n ? cand[lane] : 0ull;
+    unsigned long long k1 = lane + 64 < n ? cand[lane + 64] : 0ull;
+    for (int jr = 0; jr < k; ++jr) {
+      const unsigned long long wk = wave_max_u64(k0 > k1 ? k0 : k1);
+      if (lane == 0) {
+        val_row[jr] = ((wk != 0ull ? topk_key_value(wk) : -INFINITY) - lse) + a;
+        idx_row[jr] = wk != 0ull ? 0x7fffffff - (int)(uint32_t)wk : 0x7fffffff;
+      }
+      if (k0 == wk) k0 = 0ull;
+      if (k1 == wk) k1 = 0ull;
+    }
+    return;
+  }
+  unsigned long long last = ~0ull;   // the exact, slow form (keys are unique: the index is part of the key)
+  for (int jr = 0; jr < k; ++jr) {
+    unsigned long long best = 0ull;
+    if (last != 0ull) {
+      for (int b = 0; b < n_sel; ++b) {
+        const int c = (int)sel[b] * HS_COLS + lane * 4;
+        if (c >= V) continue;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned long long key = (x[e] >= T && c + e != ban) ? topk_key(x[e], c + e) : 0ull;
+          key = key < last ? key : 0ull;
+          best = key > best ? key : best;
+        }
+      }
+      best = wave_max_u64(best);
+      last = best;
+    }
+    if (lane == 0) {
+      val_row[jr] = ((best != 0ull ? topk_key_value(best) : -INFINITY) - lse) + a;
+      idx_row[jr] = best != 0ull ? 0x7fffffff - (int)(uint32_t)best : 0x7fffffff;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void beam_stats_merge_kernel(const float* __restrict__ logits, int ldv, const float* __restrict__ stats,
+                                                                int nblk, const float* __restrict__ add, int force_token, int ban, int nb,
+                                                                int k, int V, int32_t* __restrict__ out, int eos,
+                                                                float* __restrict__ next_scores, int64_t* __restrict__ next_tokens,
+                                                                int32_t* __restrict__ next_beam_idx) {
+  __shared__ float sval[256];
+  __shared__ int32_t sidx[256];
+  __shared__ unsigned long long cand[16][HS_CAND];
+  __shared__ uint16_t sel[16][HS_BLK_MAX + 8];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < nb)
+    beam_stats_row(logits, ldv, V, stats, nblk, b * nb + wave, add, force_token, ban, k, sval + wave * k, sidx + wave * k, cand[wave],
+                   sel[wave], lane);
+  __syncthreads();
+  if (wave == 0) beam_merge_item(sval, sidx, b, lane, nb, k, V, out, eos, next_scores, next_tokens, next_beam_idx);
+}
+
+
 // ------------------------------------------------------------------------------------------------------------------
 // Tied-head cross-entropy WITHOUT a pass over the logits (round 3).  Reference src/model/model.py:397-402:
 //   loss = mean over valid rows of  lse(v_r) - v_r[label_r],   v_r = h_r E^T + b.
@@ -1071,6 +1228,22 @@ hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int 
     hipLaunchKernelGGL((topk_part_kernel<13>), dim3(TOPK_PARTS, rows), dim3(256), 0, stream, logits, ldv, V, ban_token, k, chunks, scratch);
   hipLaunchKernelGGL(beam_combine_merge_kernel, dim3(B), dim3(64 * nb), 0, stream, scratch, add, force_token, nb, k, V, out, eos,
                      next_scores, next_tokens, next_beam_idx);
+  return hipGetLastError();
+}
+
+// The same step from the all-rows projection's per-block statistics (gemm.hip kmb_gemm_allrows_launch with stats): one launch.
+// hipErrorNotSupported: the shape needs kmb_beam_step_launch.
+hipError_t kmb_beam_step_stats_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
+                                      int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
+                                      const float* stats, int nblk, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  if (!(stats != nullptr && nblk >= 1 && nblk <= HS_BLK_MAX && nblk == (V + HS_COLS - 1) / HS_COLS && B * nb <= HS_ROWS && k >= 1 &&
+        k <= TOPK_KMAX && nb >= 1 && nb <= 16 && nb * k <= 256 && (ldv & 3) == 0 && (V & 3) == 0 && ldv >= V &&
+        ((uintptr_t)logits & 15) == 0))
+    return hipErrorNotSupported;
+  if (next_scores != nullptr && (!next_tokens || !next_beam_idx)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_stats_merge_kernel, dim3(B), dim3(64 * nb), 0, stream, logits, ldv, stats, nblk, add, force_token, ban_token, nb,
+                     k, V, out, eos, next_scores, next_tokens, next_beam_idx);
   return hipGetLastError();
 }
 

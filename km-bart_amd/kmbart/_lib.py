@@ -134,6 +134,10 @@ PROTOTYPES = {
     "kmb_beam_merge_select": (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p]),
     "kmb_beam_step": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p,
                                 c_p, C.c_int64, c_p]),
+    "kmb_gen_beam_step": (C.c_int, [c_p, c_p, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p,
+                                    c_p, C.c_int64, c_p]),
+    "kmb_beam_step_stats": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p,
+                                      c_p, c_p, C.c_int, c_p]),
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p]),
     "kmb_logsoftmax_topk_scratch": (C.c_int64, [C.c_int]),
     "kmb_logsoftmax_topk_ws": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p,
@@ -162,6 +166,8 @@ PROTOTYPES = {
     "kmb_pack_features": (C.c_int, [c_p, c_p, C.c_int32, C.c_int32, c_p, c_p]),
     "kmb_op_gemm": (C.c_int, [C.POINTER(KmbGemm), c_p]),
     "kmb_op_gemm_allrows": (C.c_int, [C.POINTER(KmbGemm), c_p]),
+    "kmb_op_gemm_allrows_stats_floats": (C.c_int64, [C.c_int]),
+    "kmb_op_gemm_allrows_stats": (C.c_int, [C.POINTER(KmbGemm), c_p, c_p]),
     "kmb_op_gemm_group": (C.c_int, [C.POINTER(KmbGemm), C.c_int32, c_p]),
     "kmb_op_attn_fwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),
     "kmb_op_attn_bwd": (C.c_int, [C.POINTER(KmbAttn), c_p]),

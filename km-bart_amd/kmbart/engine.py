@@ -602,6 +602,14 @@ class Engine:
         if k <= 16 and num_beams <= 16 and num_beams * k <= 256 and logits.stride(0) % 4 == 0:
             # kmb_beam_step: the rows' top-k lists never leave the workgroup that merges them (one launch less per decode step)
             scr = self._topk_scratch_for(R)
+            if logits is self.__dict__.get("_gen_logits"):
+                # the decode loop: kmb_gen_beam_step selects from the statistics the step's vocabulary projection left (one launch,
+                # no second pass over the logits) when there are any, and is kmb_beam_step otherwise
+                with torch.cuda.device(self.device):
+                    check(self.lib.kmb_gen_beam_step(self.h, ptr(logits), logits.stride(0), int(num_beams), ptr(add), int(force_token),
+                                                     int(ban_token), int(k), ptr(cand), int(eos_token), ptr(nscore), ptr(ntok),
+                                                     ptr(nidx), ptr(scr), scr.numel(), _stream()))
+                return cand, nscore, ntok, nidx
             with torch.cuda.device(self.device):
                 check(self.lib.kmb_beam_step(ptr(logits), logits.stride(0), int(self.config.vocab_size), B, int(num_beams), ptr(add),
                                              int(force_token), int(ban_token), int(k), ptr(cand), int(eos_token), ptr(nscore),
