@@ -307,10 +307,12 @@ int kmb_beam_step(const float* logits, int ld, int V, int B, int num_beams, cons
  * streaming the logits a second time; the scores then differ from kmb_beam_step's in the last bits (the log-sum-exp is
  * grouped by 197 blocks instead of 4 parts), ties still go to the smaller index.  Any other shape, a forced token, or
  * KMB_GEN_HEAD_STATS=0 in the environment: kmb_beam_step itself.  Reference: one step of transformers 3.0.2
- * _generate_beam_search as reached from src/model/mixins.py:336-361, scores adjusted as in mixins.py:386-417. */
+ * _generate_beam_search as reached from src/model/mixins.py:336-361, scores adjusted as in mixins.py:386-417.
+ * reorder_step >= 0: the call is also kmb_gen_reorder(h, next_beam_idx, reorder_step, stream) (_reorder_cache,
+ * src/model/mixins.py:419-434) -- with the history index by the launch that has just chosen the beams; -1: no reorder. */
 int kmb_gen_beam_step(kmb_handle* h, const float* logits, int ld, int num_beams, const float* add, int force_token, int ban_token,
                       int k, int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
-                      float* scratch, int64_t scratch_floats, void* stream);
+                      float* scratch, int64_t scratch_floats, int reorder_step, void* stream);
 int64_t kmb_gen_workspace_bytes(const kmb_handle* h, int B, int S, int num_beams, int max_length, int n_features);
 
 /* Data-parallel runs share the GPU between the GEMMs and RCCL's all-reduce kernel (reference: torch DDP's NCCL streams,

@@ -3,6 +3,7 @@
 // Reference: src/model/modules.py:89-102 (_embed_multi_modal), :133-137 (pos + LN + dropout).
 #include "common.h"
 #include "kernels.h"
+#include "embed_row.h"
 
 namespace {
 
@@ -57,65 +58,10 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
-  const int nch = D >> 3;
   const int src = img_src != nullptr ? img_src[row] : -1;
   const float* erow = src >= 0 ? img_emb + (size_t)src * D : E + (size_t)ids[row] * D;
   const float* prow = P + (size_t)(pos_base + (row % S)) * D;
-  float v[NCH][8];
-  float s = 0.f;
-  // all loads first, from clamped addresses and outside any branch (see ln_fwd_kernel in norm.hip)
-  f32x4 ev[NCH][2], pv[NCH][2], gv[NCH][2], bv[NCH][2];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i < nch ? lane + 64 * i : 0;
-    ev[i][0] = *reinterpret_cast<const f32x4*>(erow + c * 8); ev[i][1] = *reinterpret_cast<const f32x4*>(erow + c * 8 + 4);
-    pv[i][0] = *reinterpret_cast<const f32x4*>(prow + c * 8); pv[i][1] = *reinterpret_cast<const f32x4*>(prow + c * 8 + 4);
-  }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i < nch ? lane + 64 * i : 0;
-    gv[i][0] = *reinterpret_cast<const f32x4*>(gamma + c * 8); gv[i][1] = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
-    bv[i][0] = *reinterpret_cast<const f32x4*>(beta + c * 8); bv[i][1] = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
-  }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
-      const f32x4 e0 = ev[i][0], e1 = ev[i][1], p0 = pv[i][0], p1 = pv[i][1];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[i][e] = e0[e] * scale + p0[e]; v[i][4 + e] = e1[e] * scale + p1[e]; }
-      if (z != nullptr) *reinterpret_cast<u32x4*>(z + (size_t)row * D + c * 8) = pack8(v[i]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i][e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-    }
-  }
-  const float mu = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i)
-    if (lane + 64 * i < nch) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
-    }
-  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-  if (lane == 0 && mean != nullptr) { mean[row] = mu; rstd[row] = rs; }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        o[e] = (v[i][e] - mu) * rs * gv[i][e >> 2][e & 3] + bv[i][e >> 2][e & 3];
-        if (drop.thr16 != 0u)
-          o[e] = drop_keep(drop.seed, (uint32_t)row, (uint32_t)(c * 8 + e), drop.thr16) ? o[e] * drop.scale : 0.f;
-      }
-      *reinterpret_cast<u32x4*>(y + (size_t)row * D + c * 8) = pack8(o);
-    }
-  }
+  embed_ln_row<NCH>(erow, prow, scale, gamma, beta, z, y, mean, rstd, row, D, eps, drop, lane);
 }
 
 // one wave per row; lane owns columns lane + 64*j so that each atomic wave-instruction is 256 contiguous bytes

@@ -192,6 +192,9 @@ struct kmb_handle {
     // per-block (maximum, sum-exp) pairs the last kmb_gen_step's vocabulary projection left beside the logits at head_stats_for
     // (head_stats_blocks column blocks; 0: none -- the step ran another GEMM kernel, or no projection): kmb_gen_beam_step selects from them
     float* head_stats = nullptr; int head_stats_blocks = 0; const float* head_stats_for = nullptr;
+    // x0 already holds the embedded rows of decode step x0_step for the tokens at x0_tokens (kmb_gen_beam_step embedded the tokens it chose
+    // in its own launch): the kmb_gen_step of exactly that step and token buffer skips its embedding launch.  -1: no
+    int x0_step = -1; const int64_t* x0_tokens = nullptr;
     uint64_t packed_version = 0; const bf16_t* packed_at = nullptr;   // the fragment-order copies at wp[0] were made from mirror version ...
   } gen;
 
@@ -2095,6 +2098,7 @@ int kmb_gen_begin(kmb_handle* h, const kmb_batch* batch, int num_beams, int max_
   G.bars = g.bars;
   G.hist[0] = g.hist[0]; G.hist[1] = g.hist[1]; G.hcur = 0;
   G.head_stats = g.head_stats; G.head_stats_blocks = 0; G.head_stats_for = nullptr;
+  G.x0_step = -1; G.x0_tokens = nullptr;
   { const char* he = getenv("KMB_GEN_HIST"); G.use_hist = !(he && he[0] == '0'); }
   // cross-attention K|V of every decoder layer, computed once per batch item (not per beam), all layers in ONE GEMM
   if (Ld > 0) {
@@ -2145,9 +2149,12 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
   const float scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f;
   const KmbDrop nodrop{0u, 0u, 1.f};
   // BartDecoder with use_cache: only the last token, learned position (len-1) + 2
-  HIPCHK(kmb_embed_ln_fwd_launch(tokens, nullptr, h->pf(h->shared), nullptr, h->pf(h->dec_pos),
-                                 h->cfg.extra_pos_embeddings + step, 1, scale, h->pf(h->dec_lne_g),
-                                 h->pf(h->dec_lne_b), nullptr, G.x0, nullptr, nullptr, R, d, eps, nodrop, s));
+  // (skipped when the beam step that chose these tokens has embedded them already: kmb_gen_beam_step, same row code)
+  if (!(G.x0_step == step && G.x0_tokens == tokens))
+    HIPCHK(kmb_embed_ln_fwd_launch(tokens, nullptr, h->pf(h->shared), nullptr, h->pf(h->dec_pos),
+                                   h->cfg.extra_pos_embeddings + step, 1, scale, h->pf(h->dec_lne_g),
+                                   h->pf(h->dec_lne_b), nullptr, G.x0, nullptr, nullptr, R, d, eps, nodrop, s));
+  G.x0_step = -1; G.x0_tokens = nullptr;
   bf16_t* x = G.x0; bf16_t* xn = G.x1;
   // residual projection + LayerNorm (BartDecoderLayer: x = LN(residual + dropout(proj(x)))).  With R = batch x beams rows
   // the projection has 18 output tiles of 128 x 128 and a serial K loop: split K over workgroups and let ONE kernel sum
@@ -2323,27 +2330,59 @@ int kmb_gen_step(kmb_handle* h, const int64_t* tokens, int step, float* logits_o
   return 0;
 }
 
+int kmb_gen_reorder(kmb_handle* h, const int32_t* beam_idx, int step, void* stream);
+
 // The beam step of the decode loop on the logits of the last kmb_gen_step (mixins.py:386-417 via transformers 3.0.2
 // _generate_beam_search: log_softmax + beam score, the 2 * num_beams best per batch item, the next step's beams): kmb_beam_step's
 // arguments and outputs.  When that step's vocabulary projection left its per-block statistics (all-rows kernel, 257 .. 320 beam rows),
 // ONE launch selects from them; otherwise kmb_beam_step's two launches over the logits.
+// reorder_step >= 0: also kmb_gen_reorder(next_beam_idx, reorder_step) (_reorder_cache, mixins.py:419-434) -- with the history index
+// (the default) by the launch that has just chosen the beams, no launch of its own.
 int kmb_gen_beam_step(kmb_handle* h, const float* logits, int ld, int num_beams, const float* add, int force_token, int ban_token, int k,
                       int32_t* out, int eos_token, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, float* scratch,
-                      int64_t scratch_floats, void* stream) {
+                      int64_t scratch_floats, int reorder_step, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   auto& G = h->gen;
   if (!G.active) return fail("kmb_gen_beam_step: call kmb_gen_begin first");
   if (!logits || !out || !next_scores || !next_tokens || !next_beam_idx) return fail("kmb_gen_beam_step: missing tensor");
   if (num_beams != G.nb) return fail("kmb_gen_beam_step: num_beams %d, kmb_gen_begin had %d", num_beams, G.nb);
+  if (reorder_step >= G.Tmax) return fail("kmb_gen_beam_step: reorder_step %d outside the cache (Tmax=%d)", reorder_step, G.Tmax);
+  const bool fold = reorder_step >= 0 && G.use_hist;
+  KmbHistGather hg{G.hist[G.hcur], G.hist[G.hcur ^ 1], G.Tmax, reorder_step + 1};
+  // a reorder means another decode step follows, at position reorder_step + 1, on the tokens chosen here: the same launch embeds them
+  // (G.x0 is free: the step's layers have run).  KMB_GEN_FOLD_EMBED=0: kmb_gen_step's own embedding launch, as before round 6.
+  const char* fe_env = getenv("KMB_GEN_FOLD_EMBED");
+  const int d = h->d;
+  const bool embed = reorder_step >= 0 && reorder_step + 1 < G.Tmax && !(fe_env && fe_env[0] == '0') && (d & 7) == 0 && d > 512 && d <= 1024;
+  KmbEmbedNext en;
+  if (embed) {
+    en.E = h->pf(h->shared); en.prow = h->pf(h->dec_pos) + (size_t)(h->cfg.extra_pos_embeddings + reorder_step + 1) * d;
+    en.gamma = h->pf(h->dec_lne_g); en.beta = h->pf(h->dec_lne_b); en.y = G.x0;
+    en.scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f; en.D = d; en.eps = h->cfg.layer_norm_eps;
+  }
+  G.x0_step = -1; G.x0_tokens = nullptr;
   hipError_t e = hipErrorNotSupported;
   if (force_token < 0 && G.head_stats_blocks > 0 && G.head_stats_for == logits)
     e = kmb_beam_step_stats_launch(logits, ld, h->V, G.B, num_beams, add, force_token, ban_token, k, out, eos_token, next_scores,
-                                   next_tokens, next_beam_idx, G.head_stats, G.head_stats_blocks, s);
+                                   next_tokens, next_beam_idx, G.head_stats, G.head_stats_blocks, s, fold ? &hg : nullptr,
+                                   embed ? &en : nullptr);
   if (e == hipErrorNotSupported)
     e = kmb_beam_step_launch(logits, ld, h->V, G.B, num_beams, add, force_token, ban_token, k, out, eos_token, next_scores, next_tokens,
-                             next_beam_idx, scratch, scratch_floats > 0 ? (size_t)scratch_floats : 0, s);
+                             next_beam_idx, scratch, scratch_floats > 0 ? (size_t)scratch_floats : 0, s, fold ? &hg : nullptr,
+                             embed ? &en : nullptr);
   if (e == hipErrorNotSupported) return fail("kmb_gen_beam_step: unsupported shape (k <= 16, num_beams <= 16, num_beams * k <= 256)");
   HIPCHK(e);
+  if (embed) { G.x0_step = reorder_step + 1; G.x0_tokens = next_tokens; }
+  if (fold) {
+    G.hcur ^= 1;
+    if (G.nb == 1) {   // independent rows: the row -> cross-attention item table follows (kmb_gen_reorder)
+      int32_t* other = G.kv_row == G.kv_row_base ? G.kv_row_base + G.R : G.kv_row_base;
+      HIPCHK(kmb_gather_i32_launch(G.kv_row, next_beam_idx, other, G.R, s));
+      G.kv_row = other;
+    }
+  } else if (reorder_step >= 0) {
+    return kmb_gen_reorder(h, next_beam_idx, reorder_step, stream);   // KMB_GEN_HIST=0: the physical reorder
+  }
   return 0;
 }
 

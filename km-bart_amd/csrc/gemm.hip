@@ -1332,6 +1332,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p, floa
   };
   KMB_STAMP(0);
   KMB_STAMP_ID();
+#ifdef KMB_GEMM_STAMP
+  const uint64_t kmb_c0 = __builtin_amdgcn_s_memtime(), kmb_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   dma_stage(0);
   if (ns > 1) dma_stage(1);
   if (ns > 2) dma_stage(2);
@@ -1353,14 +1356,18 @@ __global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p, floa
     __builtin_amdgcn_s_barrier();
     if (s == 0) KMB_STAMP(1);
     if (s == ns / 2) KMB_STAMP(3);
-    // The stage three ahead goes into stage s - 1's buffer, one piece per eight MFMAs: an LDS-DMA piece holds the issuing wave for
-    // 60-180 cycles, and the two waves of a SIMD leave the barrier together -- issued as a burst, both stall at once and the matrix pipe idles
+    // The stage three ahead goes into stage s - 1's buffer, one piece per eight MFMAs (a piece holds the issuing wave for 60-180 cycles;
+    // as a burst behind the barrier both waves of a SIMD stall at once).  All of the stage's fragment reads first, then its MFMAs.
+    // Measured (tools/allrows_stamps.py, profiles/r06_allrows_kernel_stamps.txt): K loop 31.5 us (rounds 4-5) -> 28 us at 1.96 GHz; the
+    // same loop without its DMA 24.6 us, without DMA and fragment reads (1920 MFMAs per SIMD, 24 barriers) 24.2 us: it runs at the rate of
+    // its MFMAs and barriers, 1.3 PFLOP/s chip-equivalent -- the rate of this library's other GEMM loops.  Two other forms measured the
+    // same 27-29 us: reads one row tile ahead of their MFMAs, and the barrier in the middle of a stage's MFMAs with the next stage's
+    // first fragments prefetched behind it (247 registers).
     const bool more = s + 3 < ns;
     char* nst = smem + ((s + 3) & (V_NSTG - 1)) * V_STG;
     const char* ga = uniform_ptr(gA + (size_t)(s + 3) * VK * 2);
     const char* gb = uniform_ptr(gB + (size_t)(s + 3) * VK * 2);
     const char* cur = smem + (s & (V_NSTG - 1)) * V_STG + frag_off;
-    // every fragment read of the stage first (14 x 16 bytes per lane), then the MFMAs as the reads return
     bf16x8 fb[4], fa[10];
 #pragma unroll
     for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(cur + V_A + (wn * 4 + j) * 1024);
@@ -1369,18 +1376,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p, floa
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#ifndef KMB_AR_NOMFMA   // (timing builds: the loop without its MFMAs / without its DMA)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // C^T tile
-#else
-        acc[i][j][0] += (float)fa[i][j] + (float)fb[j][1];
-#endif
-      }
-#ifndef KMB_AR_NODMA
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // C^T tile
       if (more && (i & 1)) {
-#else
-      if (more && (i & 1) && p.M < 0) {
-#endif
         if (i == 1) dma_piece(gb, offB[0], nst + V_A + (2 * wave) * 1024);
         if (i == 3) dma_piece(ga, offA[0], nst + wave * 1024);
         if (i == 5) dma_piece(gb, offB[1], nst + V_A + (2 * wave + 1) * 1024);
@@ -1391,6 +1388,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_allrows(const KmbGemm p, floa
   }
   __syncthreads();   // (the statistics epilogue reuses the stages)
   KMB_STAMP(2);
+#ifdef KMB_GEMM_STAMP
+  KMB_STAMP_VALUE(5, __builtin_amdgcn_s_memtime() - kmb_c0);        // shader-clock ticks over the K loop ...
+  KMB_STAMP_VALUE(6, __builtin_amdgcn_s_memrealtime() - kmb_r0);    // ... and 100 MHz ticks: the clock the loop ran at
+#endif
   // transposed accumulators: lane (r, g) holds C[16 i + r][16 j + 4 g .. + 3] -> one 16-byte store per tile and lane
   if constexpr (!STATS) {
 #pragma unroll

@@ -156,12 +156,21 @@ hipError_t kmb_ce_bf16_launch(const bf16_t* logits, int ldv, int V, const int64_
 hipError_t kmb_loss_finish_launch(const float* loss_rows, int rows, const int32_t* count, float* loss,
                                   hipStream_t stream);
 // generation: per row log_softmax over V then top-k of (logp + add[row]); writes k (value, index) pairs
+// hist (optional, needs next_*): the launch that picks the next beams also gathers the self-attention caches' history index for them:
+// dst[r][t] = src[next_beam_idx[r]][t], t < nt, rows of ld ints (kmb_gather_hist_launch's work, one launch less per decode step)
+struct KmbHistGather { const int32_t* src; int32_t* dst; int ld, nt; };
+// embed (optional, needs next_*; 512 < D <= 1024): ... and embeds the tokens it has chosen for the next decode step: row r of y [rows, D] bf16 =
+// LayerNorm(E[next_tokens[r]] * scale + prow) (kmb_embed_ln_fwd_launch's work on those tokens, bit-identical rows; E == nullptr: no)
+struct KmbEmbedNext { const float* E = nullptr; const float* prow = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+                      bf16_t* y = nullptr; float scale = 1.f; int D = 0; float eps = 0.f; };
 hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
                                 int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
-                                float* scratch, size_t scratch_floats, hipStream_t stream);
+                                float* scratch, size_t scratch_floats, hipStream_t stream, const KmbHistGather* hist = nullptr,
+                                const KmbEmbedNext* embed = nullptr);
 hipError_t kmb_beam_step_stats_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
                                       int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
-                                      const float* stats, int nblk, hipStream_t stream);
+                                      const float* stats, int nblk, hipStream_t stream, const KmbHistGather* hist = nullptr,
+                                      const KmbEmbedNext* embed = nullptr);
 hipError_t kmb_beam_merge_launch(const float* val, const int32_t* idx, int B, int nb, int k, int V, int32_t* out, int eos,
                                  float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx, hipStream_t stream);
 // ban_token >= 0: that token's score is -inf AFTER the normalisation (min_length, transformers 3.0.2

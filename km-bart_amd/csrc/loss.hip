@@ -4,6 +4,7 @@
 // L2 / Infinity-Cache resident for the second pass.
 #include "common.h"
 #include "kernels.h"
+#include "embed_row.h"
 
 namespace {
 
@@ -790,7 +791,10 @@ __global__ __launch_bounds__(256) void topk_combine_kernel(const float* __restri
 // (val / idx: the nb * k candidates of batch item b -- global memory or LDS; one wave)
 __device__ __forceinline__ void beam_merge_item(const float* val, const int32_t* idx, int b, int lane, int nb, int k, int V,
                                                 int32_t* __restrict__ out, int eos, float* __restrict__ next_scores,
-                                                int64_t* __restrict__ next_tokens, int32_t* __restrict__ next_beam_idx) {
+                                                int64_t* __restrict__ next_tokens, int32_t* __restrict__ next_beam_idx,
+                                                int32_t* snext = nullptr) {
+  // (snext != nullptr: the nb chosen beam rows also into that LDS array [0, 16) and their tokens into [16, 32), for the history gather
+  //  and the next step's embedding that follow in the same launch)
   // one wave per batch item; lane l holds candidates l, l + 64, l + 128, l + 192 (n <= 256) as 64-bit keys
   // (value bits in order | ~position): a selection round is one DPP wave maximum (round 4; the first form ran a shuffle
   // tree over (value, position) pairs, a workgroup barrier and a global load of the winner's token per round: 1 us each)
@@ -825,6 +829,7 @@ __device__ __forceinline__ void beam_merge_item(const float* val, const int32_t*
       out[((size_t)b * k + j) * 2] = __float_as_int(bv);
       out[((size_t)b * k + j) * 2 + 1] = beam * V + tok;
       if (next_scores != nullptr && n_sel < nb && tok != eos) {
+        if (snext != nullptr) { snext[n_sel] = b * nb + beam; snext[16 + n_sel] = tok; }
         const size_t o = (size_t)b * nb + n_sel++;
         next_scores[o] = bv; next_tokens[o] = tok; next_beam_idx[o] = b * nb + beam;
       }
@@ -832,11 +837,35 @@ __device__ __forceinline__ void beam_merge_item(const float* val, const int32_t*
   }
   if (lane == 0 && next_scores != nullptr) {
     for (; n_sel < nb; ++n_sel) {   // cannot happen with k >= 2 * nb (at most one EOS candidate per beam); keep the rows defined
+      if (snext != nullptr) { snext[n_sel] = b * nb; snext[16 + n_sel] = eos >= 0 ? eos : 0; }
       const size_t o = (size_t)b * nb + n_sel;
       next_scores[o] = -1e9f; next_tokens[o] = eos >= 0 ? eos : 0; next_beam_idx[o] = b * nb;
     }
   }
 }
+// The beam reorder of the self-attention caches' history index (optim.hip gather_hist_kernel: dst[r][t] = src[next_beam_idx[r]][t], t < nt)
+// for the item's nb rows, by the wave that has just chosen them: the decode loop's reorder launch folded into its beam step (round 6).
+__device__ __forceinline__ void beam_hist_gather(const KmbHistGather& hg, const int32_t* snext, int b, int nb, int lane) {
+  if (hg.dst == nullptr) return;
+  __builtin_amdgcn_wave_barrier();   // snext was written by lane 0 of this wave
+  for (int e = lane; e < nb * hg.nt; e += 64) {
+    const int i = e / hg.nt, t = e - i * hg.nt;
+    hg.dst[(size_t)(b * nb + i) * hg.ld + t] = hg.src[(size_t)snext[i] * hg.ld + t];
+  }
+}
+
+// ... and the next decode step's input rows: embedding of the chosen tokens + position + LayerNorm (embed.hip's embed_ln_fwd_kernel, the
+// same row code: embed_row.h), one wave per beam row; all the workgroup's threads call this (it has a barrier)
+__device__ __forceinline__ void beam_embed_next(const KmbEmbedNext& en, const int32_t* snext, int b, int nb, int wave, int lane) {
+  if (en.E == nullptr) return;
+  __syncthreads();   // snext[16 ..] was written by wave 0
+  if (wave < nb) {
+    const int row = b * nb + wave;
+    embed_ln_row<2>(en.E + (size_t)snext[16 + wave] * en.D, en.prow, en.scale, en.gamma, en.beta, nullptr, en.y, nullptr, nullptr, row,
+                    en.D, en.eps, KmbDrop{0u, 0u, 1.f}, lane);
+  }
+}
+
 __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx,
                                                         int nb, int k, int V, int32_t* __restrict__ out, int eos,
                                                         float* __restrict__ next_scores, int64_t* __restrict__ next_tokens,
@@ -849,13 +878,19 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void beam_combine_merge_kernel(const float* __restrict__ part, const float* __restrict__ add,
                                                                   int force_token, int nb, int k, int V, int32_t* __restrict__ out,
                                                                   int eos, float* __restrict__ next_scores,
-                                                                  int64_t* __restrict__ next_tokens, int32_t* __restrict__ next_beam_idx) {
+                                                                  int64_t* __restrict__ next_tokens, int32_t* __restrict__ next_beam_idx,
+                                                                  const KmbHistGather hg, const KmbEmbedNext en) {
   __shared__ float sval[256];
   __shared__ int32_t sidx[256];
+  __shared__ int32_t snext[32];
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < nb) topk_combine_row(part, b * nb + wave, add, force_token, k, sval + wave * k, sidx + wave * k, lane);
   __syncthreads();
-  if (wave == 0) beam_merge_item(sval, sidx, b, lane, nb, k, V, out, eos, next_scores, next_tokens, next_beam_idx);
+  if (wave == 0) {
+    beam_merge_item(sval, sidx, b, lane, nb, k, V, out, eos, next_scores, next_tokens, next_beam_idx, snext);
+    beam_hist_gather(hg, snext, b, nb, lane);
+  }
+  beam_embed_next(en, snext, b, nb, wave, lane);
 }
 
 
@@ -1002,9 +1037,11 @@ __global__ __launch_bounds__(1024) void beam_stats_merge_kernel(const float* __r
                                                                 int nblk, const float* __restrict__ add, int force_token, int ban, int nb,
                                                                 int k, int V, int32_t* __restrict__ out, int eos,
                                                                 float* __restrict__ next_scores, int64_t* __restrict__ next_tokens,
-                                                                int32_t* __restrict__ next_beam_idx) {
+                                                                int32_t* __restrict__ next_beam_idx, const KmbHistGather hg,
+                                                                const KmbEmbedNext en) {
   __shared__ float sval[256];
   __shared__ int32_t sidx[256];
+  __shared__ int32_t snext[32];
   __shared__ unsigned long long cand[16][HS_CAND];
   __shared__ uint16_t sel[16][HS_BLK_MAX + 8];
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1012,7 +1049,11 @@ __global__ __launch_bounds__(1024) void beam_stats_merge_kernel(const float* __r
     beam_stats_row(logits, ldv, V, stats, nblk, b * nb + wave, add, force_token, ban, k, sval + wave * k, sidx + wave * k, cand[wave],
                    sel[wave], lane);
   __syncthreads();
-  if (wave == 0) beam_merge_item(sval, sidx, b, lane, nb, k, V, out, eos, next_scores, next_tokens, next_beam_idx);
+  if (wave == 0) {
+    beam_merge_item(sval, sidx, b, lane, nb, k, V, out, eos, next_scores, next_tokens, next_beam_idx, snext);
+    beam_hist_gather(hg, snext, b, nb, lane);
+  }
+  beam_embed_next(en, snext, b, nb, wave, lane);
 }
 
 
@@ -1216,7 +1257,8 @@ hipError_t kmb_logsoftmax_topk_launch(const float* logits, int ldv, int V, int r
 // launch for the rest.  hipErrorNotSupported: the shape needs the separate launches (kmb_logsoftmax_topk_launch + kmb_beam_merge_launch).
 hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
                                 int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
-                                float* scratch, size_t scratch_floats, hipStream_t stream) {
+                                float* scratch, size_t scratch_floats, hipStream_t stream, const KmbHistGather* hist,
+                                const KmbEmbedNext* embed) {
   if (B <= 0) return hipSuccess;
   const int rows = B * nb;
   const int chunks = (ldv / 4 + TOPK_PARTS - 1) / TOPK_PARTS;
@@ -1224,10 +1266,13 @@ hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int 
         nb <= 16 && nb * k <= 256 && (ldv & 3) == 0 && ((uintptr_t)logits & 15) == 0 && chunks <= 13 * 256 && rows <= 65535))
     return hipErrorNotSupported;
   if (next_scores != nullptr && (!next_tokens || !next_beam_idx)) return hipErrorInvalidValue;
+  const KmbHistGather hg = hist != nullptr && next_scores != nullptr ? *hist : KmbHistGather{nullptr, nullptr, 0, 0};
+  KmbEmbedNext en = embed != nullptr && next_scores != nullptr ? *embed : KmbEmbedNext{};
+  if (en.E != nullptr && ((en.D & 7) || en.D > 1024 || en.D <= 512)) return hipErrorInvalidValue;   // embed_ln_row<2>
   if (force_token < 0)
     hipLaunchKernelGGL((topk_part_kernel<13>), dim3(TOPK_PARTS, rows), dim3(256), 0, stream, logits, ldv, V, ban_token, k, chunks, scratch);
   hipLaunchKernelGGL(beam_combine_merge_kernel, dim3(B), dim3(64 * nb), 0, stream, scratch, add, force_token, nb, k, V, out, eos,
-                     next_scores, next_tokens, next_beam_idx);
+                     next_scores, next_tokens, next_beam_idx, hg, en);
   return hipGetLastError();
 }
 
@@ -1235,15 +1280,19 @@ hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int 
 // hipErrorNotSupported: the shape needs kmb_beam_step_launch.
 hipError_t kmb_beam_step_stats_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
                                       int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
-                                      const float* stats, int nblk, hipStream_t stream) {
+                                      const float* stats, int nblk, hipStream_t stream, const KmbHistGather* hist,
+                                      const KmbEmbedNext* embed) {
   if (B <= 0) return hipSuccess;
   if (!(stats != nullptr && nblk >= 1 && nblk <= HS_BLK_MAX && nblk == (V + HS_COLS - 1) / HS_COLS && B * nb <= HS_ROWS && k >= 1 &&
         k <= TOPK_KMAX && nb >= 1 && nb <= 16 && nb * k <= 256 && (ldv & 3) == 0 && (V & 3) == 0 && ldv >= V &&
         ((uintptr_t)logits & 15) == 0))
     return hipErrorNotSupported;
   if (next_scores != nullptr && (!next_tokens || !next_beam_idx)) return hipErrorInvalidValue;
+  const KmbHistGather hg = hist != nullptr && next_scores != nullptr ? *hist : KmbHistGather{nullptr, nullptr, 0, 0};
+  KmbEmbedNext en = embed != nullptr && next_scores != nullptr ? *embed : KmbEmbedNext{};
+  if (en.E != nullptr && ((en.D & 7) || en.D > 1024 || en.D <= 512)) return hipErrorInvalidValue;   // embed_ln_row<2>
   hipLaunchKernelGGL(beam_stats_merge_kernel, dim3(B), dim3(64 * nb), 0, stream, logits, ldv, stats, nblk, add, force_token, ban_token, nb,
-                     k, V, out, eos, next_scores, next_tokens, next_beam_idx);
+                     k, V, out, eos, next_scores, next_tokens, next_beam_idx, hg, en);
   return hipGetLastError();
 }
 

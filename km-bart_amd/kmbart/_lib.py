@@ -135,7 +135,7 @@ PROTOTYPES = {
     "kmb_beam_step": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p,
                                 c_p, C.c_int64, c_p]),
     "kmb_gen_beam_step": (C.c_int, [c_p, c_p, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p, c_p,
-                                    c_p, C.c_int64, c_p]),
+                                    c_p, C.c_int64, C.c_int, c_p]),
     "kmb_beam_step_stats": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, c_p, c_p,
                                       c_p, c_p, C.c_int, c_p]),
     "kmb_logsoftmax_topk": (C.c_int, [c_p, C.c_int, C.c_int, C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p]),

@@ -587,10 +587,12 @@ class Engine:
             cache[key] = torch.empty(shape, dtype=dtype, pin_memory=True)
         return cache[key]
 
-    def beam_step(self, logits, num_beams, k, add, force_token=-1, ban_token=-1, eos_token=-1, cand_out=None):
+    def beam_step(self, logits, num_beams, k, add, force_token=-1, ban_token=-1, eos_token=-1, cand_out=None, reorder_step=-1):
         """beam_candidates plus the next step's beams chosen on the device (kmb_beam_merge_select): returns
         (cand int32 [B, k, 2], next_scores fp32 [R], next_tokens int64 [R], next_beam_idx int32 [R]); nothing is
-        copied to the host.  `add` may be one of the returned next_scores (stream order makes that safe)."""
+        copied to the host.  `add` may be one of the returned next_scores (stream order makes that safe).
+        reorder_step >= 0: the call also reorders the generation caches by next_beam_idx (gen_reorder(next_beam_idx,
+        reorder_step), folded into the beam step's launch when `logits` are gen_step's)."""
         R = logits.shape[0]
         B = R // num_beams
         # cand_out: a page-locked host tensor [B, k, 2] int32 the kernel writes directly (device-visible host memory: no copy
@@ -608,17 +610,22 @@ class Engine:
                 with torch.cuda.device(self.device):
                     check(self.lib.kmb_gen_beam_step(self.h, ptr(logits), logits.stride(0), int(num_beams), ptr(add), int(force_token),
                                                      int(ban_token), int(k), ptr(cand), int(eos_token), ptr(nscore), ptr(ntok),
-                                                     ptr(nidx), ptr(scr), scr.numel(), _stream()))
+                                                     ptr(nidx), ptr(scr), scr.numel(), int(reorder_step), _stream()))
+                    self._keep_idx = nidx
                 return cand, nscore, ntok, nidx
             with torch.cuda.device(self.device):
                 check(self.lib.kmb_beam_step(ptr(logits), logits.stride(0), int(self.config.vocab_size), B, int(num_beams), ptr(add),
                                              int(force_token), int(ban_token), int(k), ptr(cand), int(eos_token), ptr(nscore),
                                              ptr(ntok), ptr(nidx), ptr(scr), scr.numel(), _stream()))
+            if reorder_step >= 0:
+                self.gen_reorder(nidx, reorder_step)
             return cand, nscore, ntok, nidx
         val, idx = self.logsoftmax_topk(logits, k, add=add, force_token=force_token, ban_token=ban_token)
         with torch.cuda.device(self.device):
             check(self.lib.kmb_beam_merge_select(ptr(val), ptr(idx), B, int(num_beams), int(k), int(self.config.vocab_size),
                                                  ptr(cand), int(eos_token), ptr(nscore), ptr(ntok), ptr(nidx), _stream()))
+        if reorder_step >= 0:
+            self.gen_reorder(nidx, reorder_step)
         return cand, nscore, ntok, nidx
 
     def _topk_scratch_for(self, R):

@@ -806,11 +806,10 @@ class MultiModalBartForConditionalGeneration(nn.Module):
                 else:
                     logits = eng.gen_step(last_tokens, cur_len - 1, want_logits=force < 0)
                 # the candidates land in the page-locked staging buffer straight from the kernel (no copy launch per step)
+                # ... and _reorder_cache (mixins.py:419-434) by the same call: the launch that picks the beams permutes the history index
                 cand, beam_scores_dev, last_tokens, beam_idx = eng.beam_step(
                     logits, num_beams, k, beam_scores_dev, force_token=force, ban_token=ban, eos_token=eos,
-                    cand_out=staging[cur_len - 1])
-                if not last:
-                    eng.gen_reorder(beam_idx, cur_len - 1)   # _reorder_cache, mixins.py:419-434
+                    cand_out=staging[cur_len - 1], reorder_step=-1 if last else cur_len - 1)
                 ev = torch.cuda.Event()
                 ev.record()
                 if pending is not None and replay(pending):

@@ -146,9 +146,12 @@ def test_tied_logits_go_to_the_smaller_index():
     assert tok0[:2] == [0, 1] or b[0][0, 0, 1] // V != 0
 
 
-def test_generation_with_and_without_the_statistics_path_returns_the_same_ids():
+@pytest.mark.parametrize("knob,exact", [("KMB_GEN_HEAD_STATS", False), ("KMB_GEN_FOLD_EMBED", True), ("KMB_GEN_HIST", True)])
+def test_generation_with_and_without_the_statistics_path_returns_the_same_ids(knob, exact):
     """model.generate at the benchmarked shape's row count (64 items x 5 beams = 320 rows: the all-rows kernel and its statistics run)
-    with KMB_GEN_HEAD_STATS=0 (two-launch beam step over the logits) and by default: same ids; sequence scores within 1e-5."""
+    with KMB_GEN_HEAD_STATS=0 (two-launch beam step over the logits) and by default: same ids; sequence scores within 1e-5.
+    KMB_GEN_FOLD_EMBED=0 (the next step's embedding by kmb_gen_step's own launch instead of the beam step's) and KMB_GEN_HIST=0 (physical
+    cache reorder by kmb_gen_reorder instead of the history gather folded into the beam step): same ids AND bit-identical scores."""
     from oracle import goldenlib as G
     from oracle import kmbart_oracle as O
     from src.data.synthetic import make_batch
@@ -169,11 +172,13 @@ def test_generation_with_and_without_the_statistics_path_returns_the_same_ids():
     kw = dict(input_ids=b["input_ids"].to(DEV), image_features=[f.to(DEV) for f in b["image_features"]],
               attention_mask=b["attention_mask"].to(DEV), num_beams=5, max_length=12, early_stopping=True)
     got, got_sc = model.generate(return_scores=True, **kw)
-    os.environ["KMB_GEN_HEAD_STATS"] = "0"
+    os.environ[knob] = "0"
     try:
         want, want_sc = model.generate(return_scores=True, **kw)
     finally:
-        os.environ.pop("KMB_GEN_HEAD_STATS", None)
+        os.environ.pop(knob, None)
     assert torch.equal(got, want)
     assert float((got_sc.float() - want_sc.float()).abs().max()) < 1e-5
+    if exact:
+        assert torch.equal(got_sc, want_sc)
     assert len({tuple(r) for r in want.tolist()}) > 8

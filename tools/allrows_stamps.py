@@ -55,3 +55,4 @@ for with_stats in (False, True):
         print("   K steps 6..11                 ", f(s[:, 2] - s[:, 3]))
         print("   epilogue                      ", f(s[:, 4] - s[:, 2]))
         print("   whole workgroup               ", f(s[:, 4] - s[:, 0]))
+        print("   shader clock over the K loop   median %.0f MHz" % float(np.median(s[:, 5] / np.maximum(s[:, 6], 1)) * 100.0))
