@@ -363,7 +363,15 @@ def generation_leg(dev, batch=64, beams=5, max_length=20, reps=5):
     d, L, F, V = VCG_BASE["d_model"], VCG_BASE["decoder_layers"], VCG_BASE["decoder_ffn_dim"], VCG_BASE["vocab_size"]
     R = batch * beams
     weights = 2 * (L * (6 * d * d + 2 * d * F) + V * d)                    # bf16: self q/k/v/o, cross q/o, FFN, tied head
-    logits = R * ((V + 127) // 128 * 128) * model._engine.gen_logits_bytes * 2   # written by the head GEMM, read by the top-k
+    vpad = (V + 127) // 128 * 128
+    logits = R * vpad * model._engine.gen_logits_bytes                           # written by the head GEMM ...
+    if 256 < R <= 320 and os.environ.get("KMB_GEN_HEAD_STATS", "1") != "0":
+        # ... and read back only where a row's best tokens can be (round 6): per row the (max, sum-exp) pairs of the 256-column blocks
+        # (written by the GEMM's epilogue, read by the beam step) and 2 * beams + 1 blocks of 1 KB
+        nblk = (V + 255) // 256
+        logits += R * (2 * nblk * 8 + (2 * beams + 1) * 1024)
+    else:
+        logits *= 2                                                              # ... the top-k kernel streams them again
     del model
     self_kv = 2 * L * R * (steps / 2.0) * d * 2                             # average cache length
     cross_kv = 2 * L * batch * S_ENC * d * 2                                # per batch item, shared by its beams

@@ -38,6 +38,8 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 python3 tools/gemm_traffic_by_shape.py $O/launches_f.txt $(find $O/tpmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/tpmc_write -name "*counter_collection.csv" | head -1) > $O/traffic_by_shape.txt 2>&1
 rm -rf $O/tpmc_fetch $O/tpmc_write
 timeout 100 python tools/topk_time.py 2>&1 | grep -v amdgpu > $O/topk_time.txt
+timeout 100 python tools/allrows_stamps.py 2>&1 | grep -v amdgpu > $O/allrows_stamps.txt   # needs lib/libkmbart_hip_stamp.so (tools/gemm_stamps.py --build)
+timeout 100 python tools/allrows_time.py 2>&1 | grep -v amdgpu > $O/allrows_time.txt
 timeout 200 python tools/decode_stamps.py 2>&1 | grep -v amdgpu > $O/decode_stamps.txt     # needs lib/libkmbart_hip_dstamp.so (tools/decode_stamps.py --build)
 timeout 200 python tools/gen_host_wait.py 64 2>&1 | grep -v amdgpu | tail -1 > $O/gen_host_wait.txt
 tail -1 $O/bench_default.log | cut -c1-400

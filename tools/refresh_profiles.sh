@@ -23,6 +23,7 @@ cp $O/attn_bwd.txt profiles/${R}_attn_bwd_time.txt
 [ -f $O/traffic_by_shape.txt ] && cp $O/traffic_by_shape.txt profiles/${R}_gemm_traffic_by_shape_b${B}.txt
 [ -f $O/gen_trace_neighbours.txt ] && cp $O/gen_trace_neighbours.txt profiles/${R}_generation_trace_neighbours.txt
 cp $O/topk_time.txt profiles/${R}_topk_time.txt
+[ -f $O/allrows_stamps.txt ] && cp $O/allrows_stamps.txt profiles/${R}_allrows_stamps_run.txt && cat $O/allrows_time.txt >> profiles/${R}_allrows_stamps_run.txt
 grep '^{' $O/gen_bench.log | tail -1 > profiles/${R}_generation_bench.json
 python tools/summarize_rocprof.py $O/prof_gen/g_kernel_stats.csv 6 > profiles/${R}_generation_kernel_stats.md
 grep '^{' $O/pretrain.log | tail -1 > profiles/${R}_pretrain_bench.json
