@@ -182,3 +182,54 @@ def test_generation_with_and_without_the_statistics_path_returns_the_same_ids(kn
     if exact:
         assert torch.equal(got_sc, want_sc)
     assert len({tuple(r) for r in want.tolist()}) > 8
+
+
+def _drive(eng, b, nb, steps, folded, fresh_token_buffer=False):
+    """gen_step + beam_step for `steps` steps through the engine API; folded: the beam step also reorders (and embeds the next step's tokens),
+    otherwise gen_reorder is called separately (and gen_step embeds).  Returns the logits of every step and the chosen tokens."""
+    V = eng.config.vocab_size
+    B = b["input_ids"].shape[0]
+    R = B * nb
+    k = max(2, 2 * nb)
+    eng.gen_begin(b["input_ids"].to(DEV), [f.to(DEV) for f in b["image_features"]], b["attention_mask"].to(DEV), nb, steps + 2)
+    tok = torch.full((R,), 2, dtype=torch.int64, device=DEV)
+    add = torch.zeros(R, device=DEV)
+    out = []
+    for t in range(steps):
+        lg = eng.gen_step(tok, t)
+        out.append(lg[:, :V].clone())
+        cand, add, ntok, nidx = eng.beam_step(lg, nb, k, add, eos_token=-1, reorder_step=t if folded else -1)
+        if not folded:
+            eng.gen_reorder(nidx, t)
+        tok = ntok.clone() if fresh_token_buffer else ntok    # a clone: another buffer -- the prepared embedding must not be used blindly
+        out.append(ntok.clone())
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("B,nb", [(64, 5), (300, 1), (12, 4)])
+def test_folded_reorder_and_embedding_equal_the_separate_calls(B, nb):
+    """kmb_gen_beam_step(reorder_step = t) == kmb_gen_beam_step(-1) + kmb_gen_reorder(t) + kmb_gen_step's own embedding, bit for bit over
+    four decode steps: 64 x 5 (statistics path), 300 x 1 (one beam per item: the row -> item table is gathered too), 12 x 4 (48 rows: the
+    two-launch beam step carries the fold); and a token buffer that is NOT the one the beam step embedded is embedded again."""
+    from oracle import goldenlib as G
+    from oracle import kmbart_oracle as O
+    from src.data.synthetic import make_batch
+    from src.model import MultiModalBartConfig, MultiModalBartForConditionalGeneration
+    from test_fullsize_parity_gpu import BASE
+    ocfg = O.OracleConfig.from_dict(BASE)
+    sd = G.golden_state_dict(ocfg, seed=11)
+    sd["model.shared.weight"] = sd["model.shared.weight"] * 8.0
+    sd["model.decoder.embed_positions.weight"] = sd["model.decoder.embed_positions.weight"] * 40.0
+    model = MultiModalBartForConditionalGeneration(MultiModalBartConfig.from_dict(BASE))
+    model.load_state_dict(sd, strict=False)
+    model.to(DEV).eval()
+    b = make_batch(B, seed=B + nb)
+    eng = model._engine
+    want = _drive(eng, b, nb, 4, folded=False)
+    for fresh in (False, True):
+        got = _drive(eng, b, nb, 4, folded=True, fresh_token_buffer=fresh)
+        assert len(got) == len(want)
+        for i, (g_, w_) in enumerate(zip(got, want)):
+            assert torch.equal(g_, w_), (fresh, i)
+    assert len({int(t) for t in want[-1].tolist()}) > 1
