@@ -2358,7 +2358,7 @@ int kmb_gen_beam_step(kmb_handle* h, const float* logits, int ld, int num_beams,
   if (embed) {
     en.E = h->pf(h->shared); en.prow = h->pf(h->dec_pos) + (size_t)(h->cfg.extra_pos_embeddings + reorder_step + 1) * d;
     en.gamma = h->pf(h->dec_lne_g); en.beta = h->pf(h->dec_lne_b); en.y = G.x0;
-    en.scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f; en.D = d; en.eps = h->cfg.layer_norm_eps;
+    en.scale = h->cfg.scale_embedding ? sqrtf((float)d) : 1.f; en.D = d; en.eps = h->cfg.layer_norm_eps; en.V = h->V;
   }
   G.x0_step = -1; G.x0_tokens = nullptr;
   hipError_t e = hipErrorNotSupported;

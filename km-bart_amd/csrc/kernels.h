@@ -162,7 +162,7 @@ struct KmbHistGather { const int32_t* src; int32_t* dst; int ld, nt; };
 // embed (optional, needs next_*; 512 < D <= 1024): ... and embeds the tokens it has chosen for the next decode step: row r of y [rows, D] bf16 =
 // LayerNorm(E[next_tokens[r]] * scale + prow) (kmb_embed_ln_fwd_launch's work on those tokens, bit-identical rows; E == nullptr: no)
 struct KmbEmbedNext { const float* E = nullptr; const float* prow = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
-                      bf16_t* y = nullptr; float scale = 1.f; int D = 0; float eps = 0.f; };
+                      bf16_t* y = nullptr; float scale = 1.f; int D = 0; float eps = 0.f; int V = 0; };   // V: rows of E
 hipError_t kmb_beam_step_launch(const float* logits, int ldv, int V, int B, int nb, const float* add, int force_token, int ban_token,
                                 int k, int32_t* out, int eos, float* next_scores, int64_t* next_tokens, int32_t* next_beam_idx,
                                 float* scratch, size_t scratch_floats, hipStream_t stream, const KmbHistGather* hist = nullptr,

@@ -861,7 +861,9 @@ __device__ __forceinline__ void beam_embed_next(const KmbEmbedNext& en, const in
   __syncthreads();   // snext[16 ..] was written by wave 0
   if (wave < nb) {
     const int row = b * nb + wave;
-    embed_ln_row<2>(en.E + (size_t)snext[16 + wave] * en.D, en.prow, en.scale, en.gamma, en.beta, nullptr, en.y, nullptr, nullptr, row,
+    int tok = snext[16 + wave];
+    tok = tok < 0 ? 0 : (tok >= en.V ? en.V - 1 : tok);   // (a real column unless V < k; never read outside the table)
+    embed_ln_row<2>(en.E + (size_t)tok * en.D, en.prow, en.scale, en.gamma, en.beta, nullptr, en.y, nullptr, nullptr, row,
                     en.D, en.eps, KmbDrop{0u, 0u, 1.f}, lane);
   }
 }
@@ -982,7 +984,7 @@ __device__ __forceinline__ void beam_stats_row(const float* __restrict__ logits,
       if (base + u < n_sel) {   // wave-uniform (no `break`: the loop must unroll, x[] lives in registers)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool hit = c0[u] >= 0 && x[u][e] >= T && c0[u] + e != ban;
+        const bool hit = c0[u] >= 0 && !(x[u][e] < T) && c0[u] + e != ban;   // (!(x < T): a NaN is a candidate, as in the two-launch path)
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
         if (bal != 0ull) {
           const int slot = n + __builtin_popcountll(bal & below);
@@ -994,7 +996,7 @@ __device__ __forceinline__ void beam_stats_row(const float* __restrict__ logits,
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (n <= HS_CAND) {
+  if (n >= k && n <= HS_CAND) {
     unsigned long long k0 = lane < n ? cand[lane] : 0ull;
     unsigned long long k1 = lane + 64 < n ? cand[lane + 64] : 0ull;
     for (int jr = 0; jr < k; ++jr) {
@@ -1008,17 +1010,23 @@ __device__ __forceinline__ void beam_stats_row(const float* __restrict__ logits,
     }
     return;
   }
-  unsigned long long last = ~0ull;   // the exact, slow form (keys are unique: the index is part of the key)
+  // The exact, slow form (keys are unique: the index is part of the key).  Also the way out when the fast form found FEWER than k
+  // candidates, which takes NaNs in the row (block maxima skip them, `mq >= T` skips their blocks): then every block is read and every
+  // admissible element is a candidate, so that -- as in the two-launch path -- the k indices handed on are always real columns.
+  const bool all = n < k;
+  if (all) T = -INFINITY;
+  const int nb_read = all ? nblk : n_sel;
+  unsigned long long last = ~0ull;
   for (int jr = 0; jr < k; ++jr) {
     unsigned long long best = 0ull;
     if (last != 0ull) {
-      for (int b = 0; b < n_sel; ++b) {
-        const int c = (int)sel[b] * HS_COLS + lane * 4;
+      for (int b = 0; b < nb_read; ++b) {
+        const int c = (all ? b : (int)sel[b]) * HS_COLS + lane * 4;
         if (c >= V) continue;
         const f32x4 x = *reinterpret_cast<const f32x4*>(row + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          unsigned long long key = (x[e] >= T && c + e != ban) ? topk_key(x[e], c + e) : 0ull;
+          unsigned long long key = (!(x[e] < T) && c + e != ban) ? topk_key(x[e], c + e) : 0ull;
           key = key < last ? key : 0ull;
           best = key > best ? key : best;
         }

@@ -233,3 +233,25 @@ def test_folded_reorder_and_embedding_equal_the_separate_calls(B, nb):
         for i, (g_, w_) in enumerate(zip(got, want)):
             assert torch.equal(g_, w_), (fresh, i)
     assert len({int(t) for t in want[-1].tolist()}) > 1
+
+
+def test_rows_of_nans_still_hand_on_real_columns():
+    """a diverged model: hidden rows of NaN -> rows of NaN logits (block maxima skip NaNs, so the fast form finds no candidate there).  The
+    tokens handed to the next step are gathered from the embedding table by index: they must be real columns (< V) whatever the scores
+    are, as with the two-launch path; items without such rows are unaffected."""
+    B, nb, k, V = 64, 5, 10, 50320
+    R = B * nb
+    A, W, bias, ld = _problem(R, V, seed=9)
+    A[0:5] = float("nan")        # all five beams of item 0
+    A[7] = float("nan")          # one beam of item 1
+    logits = torch.zeros((R, ld), dtype=torch.float32, device=DEV)
+    stats, nblk = _gemm_stats(A, W, V, bias, logits)
+    assert bool(torch.isnan(logits[0, :V]).all())
+    add = torch.zeros(R, device=DEV)
+    a, b = _both_steps(logits, ld, V, B, nb, k, add, -1, 2, 2, stats, nblk)
+    for (cand, ns, nt, ni) in (a, b):
+        tok = cand[:, :, 1] % V
+        assert int(nt.min()) >= 0 and int(nt.max()) < V
+        assert int(tok.min()) >= 0 and int(tok.max()) < V and int((cand[:, :, 1] // V).max()) < nb
+        assert int(ni.min()) >= 0 and int(ni.max()) < R
+    assert torch.equal(a[0][2:, :, 1], b[0][2:, :, 1]) and torch.equal(a[2][10:], b[2][10:]) and torch.equal(a[3][10:], b[3][10:])
